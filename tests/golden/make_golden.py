@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference; the GPU box has neither this need nor
+that path):      python tests/golden/make_golden.py
+
+The reference has no tests or golden vectors, so the oracle under
+``oracle/`` is pinned against outputs of the reference's own code, imported unmodified from
+/root/reference under three process-local shims:
+  1. torch.Tensor.cuda -> identity   2. torch.nn.Module.cuda -> identity
+  3. torch.solve(B, A) -> (torch.linalg.solve(A, B), None)    (removed from torch)
+``utils.py`` additionally needs empty stand-in *modules* for cv2 / plyfile / torchvision (never
+called on the functions we use) and a matplotlib.use() that ignores the removed ``warn`` kwarg.
+Only inputs and expected outputs are written; no reference source is stored.
+"""
+
+import importlib
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+synthetic = importlib.import_module("endoscopydepthestimation-pytorch_amd.synthetic")
+from oracle import network as onet  # noqa: E402  (only for the deterministic weight generator)
+
+
+def import_reference():
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.solve = lambda b, a: (torch.linalg.solve(a, b), None)
+    for name in ("cv2", "plyfile", "torchvision", "torchvision.utils"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    for name in ("cv2", "plyfile", "torchvision", "torchvision.utils"):
+        sys.modules[name].__file__ = os.path.join(HERE, "_stub_%s.py" % name)
+
+    def cv2_constant(name):     # default-argument constants such as cv2.COLORMAP_JET
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return 0
+    sys.modules["cv2"].__getattr__ = cv2_constant
+    sys.modules["plyfile"].PlyData = object
+    sys.modules["plyfile"].PlyElement = object
+    sys.modules["torchvision"].utils = sys.modules["torchvision.utils"]
+    import matplotlib
+    real_use = matplotlib.use
+    matplotlib.use = lambda backend, **kw: real_use(backend, force=kw.get("force", True))
+    sys.path.insert(0, REF)
+    mods = {n: importlib.import_module(n) for n in ("models", "losses", "scheduler", "utils")}
+    sys.path.remove(REF)
+    return mods
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def geometry_case(ref, n, h, w, seed, path, subsample=1):
+    """All geometry layers + losses of the reference on one synthetic batch, values and input grads."""
+    batch = synthetic.make_batch(n, h, w, seed=seed, sparse_points=min(500, h * w // 6))
+    pred_1 = synthetic.smooth_depth(n, h, w, seed=seed + 100).requires_grad_(True)
+    pred_2 = synthetic.smooth_depth(n, h, w, seed=seed + 200).requires_grad_(True)
+    goal = synthetic.smooth_depth(n, h, w, seed=seed + 300)
+    b = batch["boundaries"]
+    scaling = ref["models"].DepthScalingLayer(epsilon=1.0e-8)
+    flow_layer = ref["models"].FlowfromDepthLayer()
+    warp_layer = ref["models"].DepthWarpingLayer(epsilon=1.0e-8)
+    sfl_fn = ref["losses"].SparseMaskedL1Loss()
+    dcl_fn = ref["losses"].NormalizedDistanceLoss(height=h, width=w)
+    sil_fn = ref["losses"].ScaleInvariantLoss(epsilon=1.0e-8)
+
+    s1, std1 = scaling([pred_1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    s2, std2 = scaling([pred_2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+    f1 = flow_layer([s1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
+    f2 = flow_layer([s2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]])
+    sfl = 0.5 * (sfl_fn([batch["sparse_flows_1"] * b, f1 * b, batch["sparse_flow_masks_1"] * b]) +
+                 sfl_fn([batch["sparse_flows_2"] * b, f2 * b, batch["sparse_flow_masks_2"] * b]))
+    w21, i1 = warp_layer([s1, s2, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],
+                          batch["intrinsics"]])
+    w12, i2 = warp_layer([s2, s1, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"],
+                          batch["intrinsics"]])
+    dcl = 0.5 * (dcl_fn([s1, w21, i1, batch["intrinsics"]]) + dcl_fn([s2, w12, i2, batch["intrinsics"]]))
+    sil = sil_fn([pred_1, goal, b])
+    total = 20.0 * sfl + 0.1 * dcl + 0.3 * sil + 0.05 * (std1 + std2)
+    g1, g2 = torch.autograd.grad(total, [pred_1, pred_2])
+
+    sl = (slice(None), slice(None), slice(None, None, subsample), slice(None, None, subsample))
+    out = {"n": n, "h": h, "w": w, "seed": seed, "subsample": subsample,
+           "std_1": t2n(std1), "std_2": t2n(std2), "sfl": t2n(sfl), "dcl": t2n(dcl), "sil": t2n(sil),
+           "total": t2n(total)}
+    for name, val in (("scaled_1", s1), ("scaled_2", s2), ("flow_1", f1), ("flow_2", f2),
+                      ("warped_21", w21), ("warped_12", w12), ("inter_1", i1), ("inter_2", i2),
+                      ("grad_pred_1", g1), ("grad_pred_2", g2)):
+        out[name] = t2n(val)[sl]
+        out[name + "_sum"] = np.float64(t2n(val).astype(np.float64).sum())
+        out[name + "_abs"] = np.float64(np.abs(t2n(val).astype(np.float64)).sum())
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: float(out[k]) for k in ("sfl", "dcl", "sil", "total")})
+
+
+def known_answers(ref, path):
+    """The known-answer facts of SURVEY.md section 8(c), evaluated by the reference itself."""
+    h, w = 12, 16
+    k = torch.tensor([[[5.0, 0.0, 7.5], [0.0, 5.0, 5.5], [0.0, 0.0, 1.0]]])
+    eye = torch.eye(3).reshape(1, 3, 3)
+    zero_t = torch.zeros(1, 3, 1)
+    ones = torch.ones(1, 1, h, w)
+    d_const = 2.0 * ones
+    rng = np.random.default_rng(5)
+    d2 = torch.from_numpy(rng.uniform(0.5, 1.5, (1, 1, h, w)).astype(np.float32))
+    flow_id = ref["models"].FlowfromDepthLayer()([d_const, ones, zero_t, eye, k])
+    warped_id, inter_id = ref["models"].DepthWarpingLayer()([d_const, d2, ones, zero_t, eye, k])
+    t = torch.tensor([[[0.1], [0.0], [0.0]]])
+    flow_tx = ref["models"].FlowfromDepthLayer()([d_const, ones, t, eye, k])
+    pred = 2.0 * ones
+    sd = torch.zeros(1, 1, h, w)
+    sd[0, 0, 3, 4] = 4.0
+    sd[0, 0, 7, 9] = 6.0
+    sm = (sd > 0).float()
+    scaled, ratio = ref["models"].DepthScalingLayer()([pred, sd, sm])
+    np.savez_compressed(path, h=h, w=w, k=t2n(k), d2=t2n(d2), flow_identity=t2n(flow_id),
+                        warped_identity=t2n(warped_id), intersect_identity=t2n(inter_id),
+                        flow_tx=t2n(flow_tx), scaled=t2n(scaled), ratio=t2n(ratio))
+    print("wrote", path)
+
+
+def load_reference_net(ref, state):
+    net = ref["models"].FCDenseNet57(n_classes=1)
+    net.load_state_dict({k: v.clone() for k, v in state.items()})
+    return net
+
+
+def network_case(ref, n, h, w, seed, path):
+    """FCDenseNet57 of the reference: output, running-stat updates and parameter gradients."""
+    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    net = load_reference_net(ref, state)
+    net.train()
+    rng = np.random.default_rng(seed + 2)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    y = net(x)
+    (y * cot).sum().backward()
+    out = {"n": n, "h": h, "w": w, "seed": seed, "output": t2n(y)}
+    names, norms, sums = [], [], []
+    for name, p in net.named_parameters():
+        names.append(name)
+        norms.append(float(p.grad.double().norm()))
+        sums.append(float(p.grad.double().sum()))
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms)
+    out["grad_sums"] = np.array(sums)
+    keep = ("firstconv.weight", "firstconv.bias", "finalConv.weight", "finalConv.bias",
+            "denseBlocksDown.0.layers.0.conv.weight", "denseBlocksDown.0.layers.3.norm.weight",
+            "denseBlocksDown.0.layers.3.norm.bias", "denseBlocksDown.2.layers.1.conv.bias",
+            "transDownBlocks.1.norm.weight", "transDownBlocks.4.conv.bias",
+            "bottleneck.bottleneck.layers.3.norm.weight", "bottleneck.bottleneck.layers.3.norm.bias",
+            "transUpBlocks.0.convTrans.1.weight", "transUpBlocks.4.convTrans.1.bias",
+            "denseBlocksUp.4.layers.3.conv.weight", "denseBlocksUp.4.layers.0.norm.weight")
+    params = dict(net.named_parameters())
+    for name in keep:
+        out["grad::" + name] = t2n(params[name].grad)
+    buffers = dict(net.named_buffers())
+    for name in ("denseBlocksDown.0.layers.0.norm", "denseBlocksDown.0.layers.3.norm",
+                 "transDownBlocks.2.norm", "bottleneck.bottleneck.layers.2.norm",
+                 "denseBlocksUp.4.layers.3.norm"):
+        out["buf::" + name + ".running_mean"] = t2n(buffers[name + ".running_mean"])
+        out["buf::" + name + ".running_var"] = t2n(buffers[name + ".running_var"])
+    net.eval()
+    with torch.no_grad():
+        out["output_eval"] = t2n(net(x))
+    np.savez_compressed(path, **out)
+    print("wrote", path, "output mean", float(y.mean()))
+
+
+def train_step_case(ref, n, h, w, seed, path):
+    """Two iterations of the reference's batch-loop body (train.py:272-328) with the reference's
+    own modules, torch.optim.SGD and clip_grad_norm_."""
+    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    net = load_reference_net(ref, state)
+    net.train()
+    opt = torch.optim.SGD(net.parameters(), lr=1.0e-3, momentum=0.9)
+    sched = ref["scheduler"].CyclicLR(opt, base_lr=1.0e-4, max_lr=1.0e-3, step_size=4)
+    scaling = ref["models"].DepthScalingLayer(epsilon=1.0e-8)
+    flow_layer = ref["models"].FlowfromDepthLayer()
+    warp_layer = ref["models"].DepthWarpingLayer(epsilon=1.0e-8)
+    sfl_fn = ref["losses"].SparseMaskedL1Loss()
+    dcl_fn = ref["losses"].NormalizedDistanceLoss(height=h, width=w)
+    out = {"n": n, "h": h, "w": w, "seed": seed, "base_lr": 1.0e-4, "max_lr": 1.0e-3, "step_size": 4}
+    for step in range(2):
+        batch = synthetic.make_batch(n, h, w, seed=seed + 10 + step, sparse_points=min(500, h * w // 6))
+        sched.batch_step(batch_iteration=step)
+        b = batch["boundaries"]
+        p1 = net(b * batch["colors_1"])
+        p2 = net(b * batch["colors_2"])
+        s1, _ = scaling([p1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+        s2, _ = scaling([p2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+        f1 = flow_layer([s1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],
+                         batch["intrinsics"]]) * b
+        f2 = flow_layer([s2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"],
+                         batch["intrinsics"]]) * b
+        sfl = 20.0 * 0.5 * (sfl_fn([batch["sparse_flows_1"] * b, f1, batch["sparse_flow_masks_1"] * b]) +
+                            sfl_fn([batch["sparse_flows_2"] * b, f2, batch["sparse_flow_masks_2"] * b]))
+        w21, i1 = warp_layer([s1, s2, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],
+                              batch["intrinsics"]])
+        w12, i2 = warp_layer([s2, s1, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"],
+                              batch["intrinsics"]])
+        dcl = 0.1 * 0.5 * (dcl_fn([s1, w21, i1, batch["intrinsics"]]) +
+                           dcl_fn([s2, w12, i2, batch["intrinsics"]]))
+        loss = dcl + sfl
+        opt.zero_grad()
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+        opt.step()
+        tag = "step%d_" % step
+        out[tag + "loss"] = t2n(loss)
+        out[tag + "dcl"] = t2n(dcl)
+        out[tag + "sfl"] = t2n(sfl)
+        out[tag + "grad_norm"] = t2n(gnorm)
+        out[tag + "lr"] = np.float64(opt.param_groups[0]["lr"])
+        out[tag + "pred_1"] = t2n(p1)
+        out[tag + "param_norms"] = np.array([float(p.double().norm()) for p in net.parameters()])
+        out[tag + "param_sums"] = np.array([float(p.double().sum()) for p in net.parameters()])
+    np.savez_compressed(path, **out)
+    print("wrote", path, "losses", float(out["step0_loss"]), float(out["step1_loss"]))
+
+
+def cyclic_lr_case(ref, path):
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    rows = []
+    for base, peak, size in ((1.0e-4, 1.0e-3, 2000), (1.0e-5, 6.0e-3, 7)):
+        opt = torch.optim.SGD([dummy], lr=peak, momentum=0.9)
+        sched = ref["scheduler"].CyclicLR(opt, base_lr=base, max_lr=peak, step_size=size)
+        for step in list(range(0, 40)) + [1999, 2000, 2001, 3999, 4000, 4001, 12345]:
+            sched.batch_step(batch_iteration=step)
+            rows.append((base, peak, size, step, opt.param_groups[0]["lr"]))
+    np.savez_compressed(path, table=np.array(rows, dtype=np.float64))
+    print("wrote", path)
+
+
+def scatter_case(ref, path):
+    """reference utils.get_torch_training_data on three pairs of the shipped example sequence."""
+    with open(os.path.join(REF, "example_training_data_root", "precompute_4.0_64_0.99.pkl"), "rb") as f:
+        data = pickle.load(f)
+    key = list(data[2].keys())[0]
+    visible_views = data[2][key]
+    points = np.asarray(data[3][key], dtype=np.float64).reshape(-1, 4)
+    mask = data[5][key]
+    view_indexes = data[6][key]
+    extrinsics = [np.asarray(m, dtype=np.float64) for m in data[7][key]]
+    projections = [np.asarray(m, dtype=np.float64) for m in data[8][key]]
+    clean = data[9][key]
+    scale = float(data[13][key])
+    pairs = [(0, 10), (20, 7), (17, 34)]
+    out = {"points": points, "mask": mask, "clean": clean, "scale": scale,
+           "intrinsics": np.asarray(data[4][key], dtype=np.float64), "pairs": np.array(pairs)}
+    for idx, (a, b) in enumerate(pairs):
+        res = ref["utils"].get_torch_training_data(
+            pair_extrinsics=[data[7][key][a], data[7][key][b]],
+            pair_projections=[data[8][key][a], data[8][key][b]],
+            pair_indexes=[visible_views[a], visible_views[b]], point_cloud=data[3][key],
+            mask_boundary=mask, view_indexes_per_point=view_indexes, clean_point_list=clean,
+            visible_view_indexes=visible_views)
+        tag = "pair%d_" % idx
+        out[tag + "extrinsics"] = np.stack([extrinsics[a], extrinsics[b]])
+        out[tag + "projections"] = np.stack([projections[a], projections[b]])
+        out[tag + "visibility"] = np.stack([view_indexes[:, a], view_indexes[:, b]], axis=1)
+        for name, arr in zip(("depth_masks", "depths", "flow_masks", "flows"), res):
+            arr = np.asarray(arr)
+            flat = arr.reshape(2, -1, arr.shape[-1])
+            nz = np.nonzero(np.abs(flat).sum(-1))
+            out[tag + name + "_idx"] = np.stack(nz).astype(np.int32)
+            out[tag + name + "_val"] = flat[nz]
+            out[tag + name + "_shape"] = np.array(arr.shape)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "hits", out["pair0_depths_idx"].shape[1])
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    known_answers(ref, os.path.join(HERE, "known_answers.npz"))
+    geometry_case(ref, 2, 16, 20, 11, os.path.join(HERE, "geometry_2x16x20.npz"))
+    geometry_case(ref, 3, 64, 96, 12, os.path.join(HERE, "geometry_3x64x96.npz"))
+    geometry_case(ref, 1, 256, 320, 13, os.path.join(HERE, "geometry_1x256x320.npz"), subsample=8)
+    network_case(ref, 2, 32, 32, 21, os.path.join(HERE, "network_2x32x32.npz"))
+    network_case(ref, 2, 64, 96, 22, os.path.join(HERE, "network_2x64x96.npz"))
+    train_step_case(ref, 2, 64, 96, 31, os.path.join(HERE, "train_step_2x64x96.npz"))
+    cyclic_lr_case(ref, os.path.join(HERE, "cyclic_lr.npz"))
+    scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
+
+
+if __name__ == "__main__":
+    main()
