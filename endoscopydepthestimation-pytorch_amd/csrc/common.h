@@ -1,0 +1,79 @@
+// Shared device helpers for libendo_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/endo_hip.h"
+
+#define ENDO_CHECK(expr)                                 \
+    do {                                                 \
+        hipError_t _e = (expr);                          \
+        if (_e != hipSuccess) return static_cast<int>(_e); \
+    } while (0)
+
+#define ENDO_LAUNCH_CHECK() ENDO_CHECK(hipGetLastError())
+
+namespace endo {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+// Block-wide sum of K per-thread partials, one fp64 atomic per value per block.
+// scratch: K * (blockDim/64) doubles of LDS.  All threads must call.
+template <int K>
+__device__ __forceinline__ void block_sum_atomic(const float (&part)[K], double* dst, double* scratch) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwave = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double v = wave_sum(static_cast<double>(part[k]));
+        if (lane == 0) scratch[k * nwave + wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+        double v = 0.0;
+        for (int i = 0; i < nwave; ++i) v += scratch[threadIdx.x * nwave + i];
+        atomicAdd(dst + threadIdx.x, v);
+    }
+    __syncthreads();
+}
+
+// live profiling hooks (prof.hip)
+struct ProfScope {
+    int family;
+    hipStream_t stream;
+    void* slot;
+    ProfScope(int family, hipStream_t stream, double flops, double bytes);
+    ~ProfScope();
+};
+
+enum ProfFamily {
+    kProfConv3x3Dense = 0,   // dense-layer conv3x3 Cin->12 forward (BN+ReLU fused on load)
+    kProfConv3x3Up = 1,      // transition-up conv3x3 48->48 forward (nearest x2 fused on load)
+    kProfConv1x1Pool = 2,    // transition-down conv1x1 + maxpool forward
+    kProfConvFirst = 3,      // first conv 3->48
+    kProfConvFinal = 4,      // final conv 192->1 + abs (fwd and bwd)
+    kProfDgradDense = 5,     // dense-layer dgrad + BN/ReLU backward
+    kProfWgradDense = 6,     // dense-layer wgrad
+    kProfDgradOther = 7,     // transition dgrads
+    kProfWgradOther = 8,     // transition / first conv wgrads
+    kProfSmall = 9,          // BN finalize / dY preparation / misc
+    kProfGeometry = 10,      // depth scaling, flow, warp
+    kProfLoss = 11,          // loss reductions
+    kProfOptimizer = 12,     // clip + SGD
+};
+
+}  // namespace endo

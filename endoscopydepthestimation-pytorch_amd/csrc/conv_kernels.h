@@ -1,0 +1,520 @@
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), NCHW planar.
+//
+// One kernel template covers every 3x3 / 1x1 convolution of FC-DenseNet57 forward AND the data
+// gradients of backward (a dgrad is the same convolution with the weight tensor transposed and
+// flipped).  What differs per use is fused into the load path and the epilogue:
+//
+//   load path   PLAIN      raw values                                   (first conv, dgrad inputs)
+//               BNRELU     relu(scale[c] * x + shift[c]); scale/shift are derived in the block
+//                          prologue from the per-channel batch sums (training) or running stats
+//               UPSAMPLE   nearest x2 gather from a half-resolution plane (transition up)
+//               UNPOOL     routes a pooled gradient back through the stored 2x2 argmax (1x1 only)
+//   epilogue    FWD        + bias, store into a channel slice of the level buffer (this replaces
+//                          torch.cat), accumulate per-channel sum / sum^2 for later BN layers
+//               FWD_POOL   + bias, 2x2 max-pool in registers, store pooled value + argmax, stats
+//               DGRAD_BN   ReLU mask + BN backward (training mode) fused: dz = da * [z > 0];
+//                          sum dz and sum dz*xhat -> fp64 atomics; dbuf (+)= gamma*rstd * dz.  The
+//                          mean-subtraction terms of BN backward are affine in x per channel and
+//                          are applied lazily (see small_kernels: bn_bwd_finalize / prep_dy).
+//               DGRAD_SUMPOOL  2x2 sum (backward of nearest x2) and plain store
+//
+// Tiling: a block of 4 waves computes a 32 x 16 pixel tile for NB = 16*Q output channels.  Wave w
+// owns a 16-pixel-wide, 8-row strip; per (input-channel quad, kx) it reads 8+2 A fragments and
+// 3*Q B fragments from LDS and issues 24*Q MFMAs (the three ky taps reuse the A fragments by row
+// shift).  MFMA roles: A[i = pixel x][k = channel], B[k = channel][j = cout]; D[i][j] lands with
+// 4 consecutive x pixels per lane for cout j = lane & 15, so stores are float4 along W.
+// LDS: input tile [KC][rows][cols] with channel stride == 16 (mod 32) dwords and weight tile
+// [tap][KC][NB]; both fragment reads are bank-conflict free for ds_read_b32 (32-lane groups).
+// Global->LDS staging is register-prefetched one K-chunk ahead so HBM latency hides under MFMAs.
+#pragma once
+
+#include "common.h"
+
+namespace endo {
+
+enum InMode { IN_PLAIN = 0, IN_BNRELU = 1, IN_UPSAMPLE = 2, IN_UNPOOL = 3 };
+enum Epilogue { EPI_FWD = 0, EPI_FWD_POOL = 1, EPI_DGRAD_BN = 2, EPI_DGRAD_SUMPOOL = 3 };
+
+constexpr int kTileX = 32;
+constexpr int kTileY = 16;
+constexpr int kConvThreads = 256;
+constexpr int kMaxBnChannels = 384;
+
+struct ConvParams {
+    int n, h, w;      // output grid of the convolution (before any pooling in the epilogue)
+    int tiles_x;
+    // ---- input ----
+    const float* in;
+    int64_t in_ns;    // sample stride (floats)
+    int in_cs;        // channel-plane stride
+    int in_w;         // row stride
+    const uint8_t* in_idx;   // UNPOOL: argmax codes, same indexing as `in`
+    int64_t idx_ns;
+    int cin;          // logical input channels of this launch
+    // BNRELU on the input channels
+    const double* in_sums;   // [cin][2] sum, sum^2 (training)
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* saved;            // [cin][2] mean, rstd written by block 0 for backward
+    double count;            // N*H*W of the normalised tensor
+    float eps, momentum;
+    int training;
+    // ---- weights: the ORIGINAL conv's tensor [w_cout][w_cin][KS][KS] ----
+    const float* wgt;
+    const float* bias;
+    int w_cout, w_cin;
+    // ---- output ----
+    float* out;
+    int64_t out_ns;
+    int out_cs, out_w;
+    int cout;         // logical output channels of this launch
+    uint8_t* out_idx;        // FWD_POOL argmax codes (indexing as `out`)
+    double* out_sums;        // [cout][2] FWD / FWD_POOL statistics of the stored values
+    // ---- DGRAD_BN ----
+    const float* x;          // activations of the output channels (same resolution)
+    int64_t x_ns;
+    int x_cs;
+    const float* bn_saved;   // [cout][2] mean, rstd
+    const float* bn_gamma;
+    const float* bn_beta;
+    double* bn_scratch;      // [cout][2] sum dz, sum dz*xhat
+    int acc_from;            // output channels >= acc_from accumulate into `out`, others overwrite
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int KC>
+struct ConvGeom {
+    static constexpr int kHalo = KS / 2;
+    static constexpr int kRows = kTileY + 2 * kHalo;
+    static constexpr int kCols = kTileX + 2 * kHalo;
+    static constexpr int kPlane = kRows * kCols;
+    // channel stride == 16 (mod 32) so the 4 k-groups of an A fragment hit disjoint banks
+    static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;
+    static constexpr int kPos = (kPlane + kConvThreads - 1) / kConvThreads;   // tile positions per thread
+    static constexpr int kPre = KC * kPos;                                    // staged values per thread per chunk
+};
+
+template <int KS, int KC, int Q, int IN, int EPI>
+__global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParams p) {
+    using G = ConvGeom<KS, KC>;
+    constexpr int KK = KS * KS;
+    constexpr int NB = 16 * Q;
+    constexpr int kWElems = KK * KC * NB;
+    constexpr int kWPre = (kWElems + kConvThreads - 1) / kConvThreads;
+    constexpr bool kDgrad = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_SUMPOOL);
+    constexpr int R = kTileY / 2;   // rows per wave
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_in = smem;                       // [KC][kCS]
+    float* s_w = s_in + KC * G::kCS;          // [KK][KC][NB]
+    float* s_aux = s_w + kWElems;             // BN scale/shift or dgrad constants / reductions
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int x0 = (tile % p.tiles_x) * kTileX;
+    const int y0 = (tile / p.tiles_x) * kTileY;
+    const int co_base = blockIdx.y * NB;
+    const int n = blockIdx.z;
+
+    // ---------------- prologue: per-channel constants ----------------
+    if constexpr (IN == IN_BNRELU) {
+        // s_aux[c] = scale, s_aux[kMaxBnChannels + c] = shift
+        for (int c = tid; c < p.cin; c += kConvThreads) {
+            double mean, var;
+            if (p.training) {
+                mean = p.in_sums[2 * c] / p.count;
+                var = p.in_sums[2 * c + 1] / p.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+            } else {
+                mean = p.running_mean[c];
+                var = p.running_var[c];
+            }
+            const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
+            const float scale = p.gamma[c] * static_cast<float>(rstd);
+            s_aux[c] = scale;
+            s_aux[kMaxBnChannels + c] = p.beta[c] - static_cast<float>(mean) * scale;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+                if (p.saved) {
+                    p.saved[2 * c] = static_cast<float>(mean);
+                    p.saved[2 * c + 1] = static_cast<float>(rstd);
+                }
+                if (p.training) {
+                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * static_cast<float>(mean);
+                    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
+                }
+            }
+        }
+    }
+    if constexpr (EPI == EPI_DGRAD_BN) {
+        // per output channel of this block: scale, shift, mean, rstd at s_aux[2*kMax + 4*j ..]
+        float* cst = s_aux + 2 * kMaxBnChannels;
+        if (tid < NB) {
+            const int c = co_base + tid;
+            float mean = 0.f, rstd = 0.f, scale = 0.f, shift = 0.f;
+            if (c < p.cout) {
+                mean = p.bn_saved[2 * c];
+                rstd = p.bn_saved[2 * c + 1];
+                scale = p.bn_gamma[c] * rstd;
+                shift = p.bn_beta[c] - mean * scale;
+            }
+            cst[4 * tid] = scale; cst[4 * tid + 1] = shift; cst[4 * tid + 2] = mean; cst[4 * tid + 3] = rstd;
+        }
+    }
+
+    // ---------------- accumulators ----------------
+    f32x4 acc[R][Q];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wx = (wave & 1) * 16;      // wave's x offset inside the tile
+    const int wy = (wave >> 1) * R;      // wave's first row inside the tile
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+
+    // Each thread owns kPos fixed positions of the haloed tile and walks the chunk's channels over
+    // them, so the address / bounds arithmetic is done once per block, not once per element.
+    float pre[G::kPre];
+    float wpre[kWPre];
+    int goff[G::kPos];
+    unsigned pos_ok = 0;
+    unsigned pos_code = 0;
+#pragma unroll
+    for (int k = 0; k < G::kPos; ++k) {
+        const int e = tid + k * kConvThreads;
+        goff[k] = 0;
+        if (e < G::kPlane) {
+            const int ry = e / G::kCols;
+            const int rx = e - ry * G::kCols;
+            const int gy = y0 - G::kHalo + ry;
+            const int gx = x0 - G::kHalo + rx;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+                pos_ok |= (1u << k);
+                if constexpr (IN == IN_UPSAMPLE || IN == IN_UNPOOL) {
+                    goff[k] = (gy >> 1) * p.in_w + (gx >> 1);
+                    pos_code |= static_cast<unsigned>(((gy & 1) << 1) | (gx & 1)) << (2 * k);
+                } else {
+                    goff[k] = gy * p.in_w + gx;
+                }
+            }
+        }
+    }
+    const float* in_n = p.in + n * p.in_ns;
+    const uint8_t* idx_n = nullptr;
+    if constexpr (IN == IN_UNPOOL) idx_n = p.in_idx + n * p.idx_ns;
+    const int nchunks = (p.cin + KC - 1) / KC;
+
+    auto load_chunk = [&](int chunk) {
+        const int c_base = chunk * KC;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int ch = c_base + c;
+            const bool ch_ok = ch < p.cin;
+            const int64_t coff = static_cast<int64_t>(ch) * p.in_cs;
+#pragma unroll
+            for (int k = 0; k < G::kPos; ++k) {
+                float v = 0.f;
+                if (ch_ok && (pos_ok & (1u << k))) {
+                    if constexpr (IN == IN_UNPOOL) {
+                        const int code = (pos_code >> (2 * k)) & 3;
+                        v = (idx_n[coff + goff[k]] == code) ? in_n[coff + goff[k]] : 0.f;
+                    } else {
+                        v = in_n[coff + goff[k]];
+                    }
+                }
+                pre[c * G::kPos + k] = v;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWPre; ++k) {
+            const int e = tid + k * kConvThreads;
+            float v = 0.f;
+            if (e < kWElems) {
+                const int j = e % NB;
+                const int rest = e / NB;
+                const int c = rest % KC;
+                const int tap = rest / KC;
+                const int ci = c_base + c;
+                const int co = co_base + j;
+                if (ci < p.cin && co < p.cout) {
+                    if constexpr (kDgrad) {
+                        // logical (ci, co, tap) = original (cout = ci, cin = co, flipped tap)
+                        v = p.wgt[(static_cast<int64_t>(ci) * p.w_cin + co) * KK + (KK - 1 - tap)];
+                    } else {
+                        v = p.wgt[(static_cast<int64_t>(co) * p.w_cin + ci) * KK + tap];
+                    }
+                }
+            }
+            wpre[k] = v;
+        }
+    };
+
+    auto store_chunk = [&](int chunk) {
+        const int c_base = chunk * KC;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+#pragma unroll
+            for (int k = 0; k < G::kPos; ++k) {
+                const int e = tid + k * kConvThreads;
+                if (e < G::kPlane) {
+                    float v = pre[c * G::kPos + k];
+                    if constexpr (IN == IN_BNRELU) {
+                        const int ch = c_base + c;
+                        if (ch < p.cin && (pos_ok & (1u << k))) {
+                            v = fmaf(v, s_aux[ch], s_aux[kMaxBnChannels + ch]);
+                            v = v > 0.f ? v : 0.f;
+                        } else {
+                            v = 0.f;
+                        }
+                    }
+                    s_in[c * G::kCS + e] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWPre; ++k) {
+            const int e = tid + k * kConvThreads;
+            if (e < kWElems) s_w[e] = wpre[k];
+        }
+    };
+
+    load_chunk(0);
+    __syncthreads();   // s_aux ready
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk > 0) __syncthreads();      // everyone done reading the previous tile
+        store_chunk(chunk);
+        __syncthreads();
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+
+#pragma unroll
+        for (int quad = 0; quad < KC / 4; ++quad) {
+            const float* a_base = s_in + (quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
+            const float* b_base = s_w + (quad * 4 + lk) * NB + li;
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                float a[R + KS - 1];
+#pragma unroll
+                for (int r = 0; r < R + KS - 1; ++r) a[r] = a_base[r * G::kCols + dx];
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float b = b_base[(dy * KS + dx) * KC * NB + q * 16];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], b, acc[r][q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- epilogue ----------------
+    // lane holds, for cout j = co_base + q*16 + li, pixels x = x0 + wx + 4*lk + {0..3}, rows y0+wy+r
+    const int px = x0 + wx + 4 * lk;
+    const bool vec_ok = ((p.out_w & 3) == 0) && ((p.w & 3) == 0);
+
+    if constexpr (EPI == EPI_FWD) {
+        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;   // [4 waves][NB][2]
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            const bool co_ok = co < p.cout;
+            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                f32x4 v = acc[r][q];
+                v[0] += bias; v[1] += bias; v[2] += bias; v[3] += bias;
+                if (co_ok && y < p.h) {
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
+                    if (vec_ok && px + 3 < p.w) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (px + e < p.w) { dst[e] = v[e]; s1 += v[e]; s2 += v[e] * v[e]; }
+                    }
+                }
+            }
+            if (p.out_sums) {
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lk == 0) {
+                    s_red[(wave * NB + q * 16 + li) * 2] = s1;
+                    s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
+                }
+            }
+        }
+        if (p.out_sums) {
+            __syncthreads();
+            if (tid < 2 * NB) {
+                const int j = tid >> 1, which = tid & 1;
+                if (co_base + j < p.cout) {
+                    double t = 0.0;
+                    for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                    atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_FWD_POOL) {
+        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;
+        const int ph = p.h >> 1, pw = p.w >> 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            const bool co_ok = co < p.cout;
+            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int yp = (y0 + wy + r) >> 1;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int xp = (px + e) >> 1;
+                    float best = acc[r][q][e] + bias;
+                    int code = 0;
+                    float v = acc[r][q][e + 1] + bias;
+                    if (v > best) { best = v; code = 1; }
+                    v = acc[r + 1][q][e] + bias;
+                    if (v > best) { best = v; code = 2; }
+                    v = acc[r + 1][q][e + 1] + bias;
+                    if (v > best) { best = v; code = 3; }
+                    if (co_ok && yp < ph && xp < pw) {
+                        const int64_t o = static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp;
+                        p.out[n * p.out_ns + o] = best;
+                        p.out_idx[n * p.idx_ns + o] = static_cast<uint8_t>(code);
+                        s1 += best; s2 += best * best;
+                    }
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                s_red[(wave * NB + q * 16 + li) * 2] = s1;
+                s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int j = tid >> 1, which = tid & 1;
+            if (co_base + j < p.cout) {
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
+            }
+        }
+    } else if constexpr (EPI == EPI_DGRAD_BN) {
+        const float* cst = s_aux + 2 * kMaxBnChannels;
+        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int jloc = q * 16 + li;
+            const int co = co_base + jloc;
+            const bool co_ok = co < p.cout;
+            const float scale = cst[4 * jloc], shift = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
+            const bool accumulate = co >= p.acc_from;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                if (co_ok && y < p.h) {
+                    const int64_t xo = n * p.x_ns + static_cast<int64_t>(co) * p.x_cs + y * p.out_w + px;
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
+                    if (vec_ok && px + 3 < p.w) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + xo);
+                        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = fmaf(xv[e], scale, shift);
+                            const float dz = z > 0.f ? acc[r][q][e] : 0.f;
+                            s1 += dz;
+                            s2 += dz * ((xv[e] - mean) * rstd);
+                            o[e] += scale * dz;
+                        }
+                        *reinterpret_cast<f32x4*>(dst) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (px + e < p.w) {
+                                const float xv = p.x[xo + e];
+                                const float z = fmaf(xv, scale, shift);
+                                const float dz = z > 0.f ? acc[r][q][e] : 0.f;
+                                s1 += dz;
+                                s2 += dz * ((xv - mean) * rstd);
+                                dst[e] = (accumulate ? dst[e] : 0.f) + scale * dz;
+                            }
+                        }
+                    }
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                s_red[(wave * NB + jloc) * 2] = s1;
+                s_red[(wave * NB + jloc) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int j = tid >> 1, which = tid & 1;
+            if (co_base + j < p.cout) {
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
+            }
+        }
+    } else {   // EPI_DGRAD_SUMPOOL
+        const int ph = p.h >> 1, pw = p.w >> 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            if (co >= p.cout) continue;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int yp = (y0 + wy + r) >> 1;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int xp = (px + e) >> 1;
+                    if (yp < ph && xp < pw) {
+                        const float v = (acc[r][q][e] + acc[r][q][e + 1]) + (acc[r + 1][q][e] + acc[r + 1][q][e + 1]);
+                        p.out[n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int KC, int Q>
+constexpr size_t conv_smem_bytes() {
+    return sizeof(float) * (KC * ConvGeom<KS, KC>::kCS + KS * KS * KC * 16 * Q + 2 * kMaxBnChannels + 4 * 16 * Q + 4 * 16 * Q * 2);
+}
+
+template <int KS, int KC, int Q, int IN, int EPI>
+inline int launch_conv(const ConvParams& p, hipStream_t stream) {
+    const int tiles_y = (p.h + kTileY - 1) / kTileY;
+    dim3 grid(p.tiles_x * tiles_y, (p.cout + 16 * Q - 1) / (16 * Q), p.n);
+    constexpr size_t smem = conv_smem_bytes<KS, KC, Q>();
+    static bool configured = false;
+    if (!configured && smem > 48 * 1024) {
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, KC, Q, IN, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        configured = true;
+    }
+    conv_mfma_kernel<KS, KC, Q, IN, EPI><<<grid, kConvThreads, smem, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace endo

@@ -1,0 +1,489 @@
+// Differentiable geometry layers: depth scaling, flow-from-depth, depth warping.
+// HBM-bound streaming / gather kernels: every plane is read once per pass, the
+// per-sample camera algebra is recomputed per block in fp64 (27 flops) instead of being
+// materialised, reductions use wave shuffles + one fp64 atomic per block.
+#include "common.h"
+
+namespace endo {
+
+// ------------------------------------------------------------------------------------------
+// camera maps (reference models.py:391-399 / 492-499 / 531-532)
+//   M  = K R^T K^-1,  w  = -K R^T t          (frame-1 pixel + depth -> frame-2 homogeneous pixel)
+//   M2 = K R   K^-1,  w2 =  K t              (only the z row / z entry is ever used)
+// ------------------------------------------------------------------------------------------
+struct Camera {
+    float m[9];
+    float w[3];
+    float m2z[3];
+    float w2z;
+};
+
+__device__ inline void mat3_mul(const double* a, const double* b, double* c) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) c[i * 3 + j] = a[i * 3] * b[j] + a[i * 3 + 1] * b[3 + j] + a[i * 3 + 2] * b[6 + j];
+}
+
+__device__ inline void camera_setup(const float* K, const float* R, const float* t, Camera* cam) {
+    double k[9], r[9], rt[9], ki[9], tv[3];
+    for (int i = 0; i < 9; ++i) { k[i] = K[i]; r[i] = R[i]; }
+    for (int i = 0; i < 3; ++i) { tv[i] = t[i]; for (int j = 0; j < 3; ++j) rt[i * 3 + j] = r[j * 3 + i]; }
+    const double det = k[0] * (k[4] * k[8] - k[5] * k[7]) - k[1] * (k[3] * k[8] - k[5] * k[6]) +
+                       k[2] * (k[3] * k[7] - k[4] * k[6]);
+    const double id = 1.0 / det;
+    ki[0] = (k[4] * k[8] - k[5] * k[7]) * id; ki[1] = (k[2] * k[7] - k[1] * k[8]) * id; ki[2] = (k[1] * k[5] - k[2] * k[4]) * id;
+    ki[3] = (k[5] * k[6] - k[3] * k[8]) * id; ki[4] = (k[0] * k[8] - k[2] * k[6]) * id; ki[5] = (k[2] * k[3] - k[0] * k[5]) * id;
+    ki[6] = (k[3] * k[7] - k[4] * k[6]) * id; ki[7] = (k[1] * k[6] - k[0] * k[7]) * id; ki[8] = (k[0] * k[4] - k[1] * k[3]) * id;
+    double krt[9], m[9], kr[9], m2[9];
+    mat3_mul(k, rt, krt);
+    mat3_mul(krt, ki, m);
+    mat3_mul(k, r, kr);
+    mat3_mul(kr, ki, m2);
+    for (int i = 0; i < 9; ++i) cam->m[i] = static_cast<float>(m[i]);
+    for (int i = 0; i < 3; ++i)
+        cam->w[i] = static_cast<float>(-(krt[i * 3] * tv[0] + krt[i * 3 + 1] * tv[1] + krt[i * 3 + 2] * tv[2]));
+    for (int j = 0; j < 3; ++j) cam->m2z[j] = static_cast<float>(m2[6 + j]);
+    cam->w2z = static_cast<float>(k[6] * tv[0] + k[7] * tv[1] + k[8] * tv[2]);
+}
+
+__device__ __forceinline__ void load_camera(const float* K, const float* R, const float* t, int n, Camera* shared_cam) {
+    if (threadIdx.x == 0) camera_setup(K + 9 * n, R + 9 * n, t + 3 * n, shared_cam);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void ray(const Camera& c, float x, float y, float& qx, float& qy, float& qz) {
+    qx = fmaf(c.m[1], y, c.m[0] * x) + c.m[2];
+    qy = fmaf(c.m[4], y, c.m[3] * x) + c.m[5];
+    qz = fmaf(c.m[7], y, c.m[6] * x) + c.m[8];
+}
+
+// ------------------------------------------------------------------------------------------
+// depth scaling (models.py:346-363)
+// ------------------------------------------------------------------------------------------
+constexpr int kRedThreads = 256;
+constexpr int kRedItems = 8;   // pixels per thread per block
+
+__global__ void __launch_bounds__(kRedThreads) depth_scale_pass1(const float* __restrict__ sd,
+                                                                  const float* __restrict__ sm,
+                                                                  double* stats, int hw) {
+    __shared__ double scratch[2 * (kRedThreads / 64)];
+    const int n = blockIdx.y;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    float part[2] = {0.f, 0.f};
+    for (int i = blockIdx.x * kRedThreads * kRedItems + threadIdx.x, k = 0; k < kRedItems && i < hw; ++k, i += kRedThreads) {
+        const float b = sm[base + i] > 1.0e-8f ? 1.f : 0.f;
+        part[0] += sd[base + i] * b;
+        part[1] += b;
+    }
+    block_sum_atomic<2>(part, stats + 8 * n, scratch);
+}
+
+__global__ void __launch_bounds__(kRedThreads) depth_scale_pass2(const float* __restrict__ pred,
+                                                                  const float* __restrict__ sd,
+                                                                  double* stats, int hw, float eps) {
+    __shared__ double scratch[3 * (kRedThreads / 64)];
+    const int n = blockIdx.y;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    const float mean_sd = static_cast<float>(stats[8 * n + 0]) / static_cast<float>(stats[8 * n + 1]);
+    const float thr = 0.5f * mean_sd;
+    float part[3] = {0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * kRedThreads * kRedItems + threadIdx.x, k = 0; k < kRedItems && i < hw; ++k, i += kRedThreads) {
+        const float s = sd[base + i];
+        if (s > thr) {
+            const float v = s / (eps + pred[base + i]);
+            part[0] += v;
+            part[1] += 1.f;
+            part[2] += v * v;
+        }
+    }
+    block_sum_atomic<3>(part, stats + 8 * n + 2, scratch);
+}
+
+// per-sample scale / std from the sums; also the (N x N)-broadcast ratio of models.py:363
+__global__ void depth_scale_finalize(double* stats, float* ratio, int n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double inv_mean = 0.0, std_mean = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double* s = stats + 8 * i;
+        const double a = s[3];
+        const double scale = s[2] / a;
+        double var = (s[4] - scale * scale * a) / a;
+        if (var < 0.0) var = 0.0;
+        const double sd = sqrt(var);
+        s[5] = scale;
+        s[6] = sd;
+        inv_mean += 1.0 / scale;
+        std_mean += sd;
+    }
+    inv_mean /= n;
+    std_mean /= n;
+    stats[7] = inv_mean;            // mean_i 1/scale_i
+    if (n > 1) stats[8 + 7] = std_mean;   // mean_j std_j   (kept in sample 1's spare slot)
+    *ratio = static_cast<float>(inv_mean * std_mean);
+}
+
+__global__ void __launch_bounds__(256) depth_scale_apply(const float* __restrict__ pred, const double* __restrict__ stats,
+                                                         float* __restrict__ scaled, int hw) {
+    const int n = blockIdx.y;
+    const float scale = static_cast<float>(stats[8 * n + 5]);
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x)
+        scaled[base + i] = scale * pred[base + i];
+}
+
+__global__ void __launch_bounds__(kRedThreads) depth_scale_bwd_reduce(const float* __restrict__ g,
+                                                                      const float* __restrict__ pred,
+                                                                      double* work, int hw) {
+    __shared__ double scratch[kRedThreads / 64];
+    const int n = blockIdx.y;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    float part[1] = {0.f};
+    for (int i = blockIdx.x * kRedThreads * kRedItems + threadIdx.x, k = 0; k < kRedItems && i < hw; ++k, i += kRedThreads)
+        part[0] += g[base + i] * pred[base + i];
+    block_sum_atomic<1>(part, work + n, scratch);
+}
+
+__global__ void __launch_bounds__(256) depth_scale_bwd_apply(const float* __restrict__ g, const float* __restrict__ grad_ratio,
+                                                             const float* __restrict__ pred, const float* __restrict__ sd,
+                                                             const double* __restrict__ stats, const double* __restrict__ work,
+                                                             float* __restrict__ grad_pred, int nsamples, int hw, float eps) {
+    const int n = blockIdx.y;
+    const double* s = stats + 8 * n;
+    const float mean_sd = static_cast<float>(s[0]) / static_cast<float>(s[1]);
+    const float thr = 0.5f * mean_sd;
+    const double a = s[3];
+    const double scale = s[5];
+    const double sdev = s[6];
+    // dL/dsmap_p = c0 + c1 * (smap_p - scale)
+    double c0 = (g ? work[n] : 0.0) / a;
+    double c1 = 0.0;
+    if (grad_ratio) {
+        const double gr = static_cast<double>(*grad_ratio);
+        const double inv_mean = stats[7];
+        const double std_mean = nsamples > 1 ? stats[8 + 7] : sdev;
+        c1 = gr * inv_mean / (nsamples * sdev * a);
+        c0 -= gr * std_mean / (nsamples * scale * scale * a);
+    }
+    const float fscale = static_cast<float>(scale);
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const float p = pred[base + i];
+        float out = g ? fscale * g[base + i] : 0.f;
+        const float sv = sd[base + i];
+        if (sv > thr) {
+            const float den = eps + p;
+            const float smap = sv / den;
+            const float coef = static_cast<float>(c0 + c1 * (static_cast<double>(smap) - scale));
+            out += coef * (-smap / den);
+        }
+        grad_pred[base + i] = out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// flow from depth (models.py:377-451)
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) flow_fwd_kernel(const float* __restrict__ depth, const float* __restrict__ mask,
+                                                       const float* __restrict__ t, const float* __restrict__ R,
+                                                       const float* __restrict__ K, float* __restrict__ flow,
+                                                       int h, int w) {
+    __shared__ Camera cam;
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int hw = h * w;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        const float x = static_cast<float>(xx), y = static_cast<float>(yy);
+        float qx, qy, qz;
+        ray(cam, x, y, qx, qy, qz);
+        const float d = depth[base + i], m = mask[base + i];
+        const float z2 = cam.w[2] + d * qz;
+        const float zt = 1.0e30f * (1.0f - m) + m * z2;
+        const float u2 = (cam.w[0] + d * qx) / zt;
+        const float v2 = (cam.w[1] + d * qy) / zt;
+        flow[2 * base + i] = (u2 - x) / fw;
+        flow[2 * base + hw + i] = (v2 - y) / fh;
+    }
+}
+
+__global__ void __launch_bounds__(256) flow_bwd_kernel(const float* __restrict__ gflow, const float* __restrict__ depth,
+                                                       const float* __restrict__ mask, const float* __restrict__ t,
+                                                       const float* __restrict__ R, const float* __restrict__ K,
+                                                       float* __restrict__ gdepth, int h, int w) {
+    __shared__ Camera cam;
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int hw = h * w;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        float qx, qy, qz;
+        ray(cam, static_cast<float>(xx), static_cast<float>(yy), qx, qy, qz);
+        const float d = depth[base + i], m = mask[base + i];
+        const float z2 = cam.w[2] + d * qz;
+        const float zt = 1.0e30f * (1.0f - m) + m * z2;
+        const float nx = cam.w[0] + d * qx;
+        const float ny = cam.w[1] + d * qy;
+        const float gu = gflow[2 * base + i] / fw;
+        const float gv = gflow[2 * base + hw + i] / fh;
+        // u2 = nx / zt :  d u2 / d d = qx / zt - nx / zt^2 * (m qz)
+        const float gzt = -(gu * nx + gv * ny) / (zt * zt);
+        gdepth[base + i] = gu * qx / zt + gv * qy / zt + gzt * m * qz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// depth warping (models.py:469-554) with the grid_sample of models.py:325-336 folded in.
+// Source location of the CPU grid_sample path: ix = (gx + 1) * (W / 2) - 0.5, gx = 2 (u / W) - 1.
+// ------------------------------------------------------------------------------------------
+struct Taps {
+    float wnw, wne, wsw, wse;   // bilinear weights
+    int x0, y0;                 // north-west tap (valid flags say which taps are in range)
+    bool vw, ve, vn, vs;        // column west/east, row north/south in range
+    float fx, fy;               // fractional parts (w, n in ATen's naming)
+};
+
+__device__ __forceinline__ Taps make_taps(float u2, float v2, int w, int h) {
+    Taps tp;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    const float gx = 2.0f * (u2 / fw) - 1.0f;
+    const float gy = 2.0f * (v2 / fh) - 1.0f;
+    const float ix = (gx + 1.0f) * (fw * 0.5f) - 0.5f;
+    const float iy = (gy + 1.0f) * (fh * 0.5f) - 0.5f;
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float wx = ix - xw, ee = 1.0f - wx;
+    const float ny = iy - yn, ss = 1.0f - ny;
+    tp.wnw = ss * ee; tp.wne = ss * wx; tp.wsw = ny * ee; tp.wse = ny * wx;
+    tp.fx = wx; tp.fy = ny;
+    // range tests in float so that huge / non-finite coordinates never reach an int conversion
+    tp.vw = (xw >= 0.0f) && (xw <= fw - 1.0f);
+    tp.ve = (xw + 1.0f >= 0.0f) && (xw + 1.0f <= fw - 1.0f);
+    tp.vn = (yn >= 0.0f) && (yn <= fh - 1.0f);
+    tp.vs = (yn + 1.0f >= 0.0f) && (yn + 1.0f <= fh - 1.0f);
+    const bool any = (tp.vw || tp.ve) && (tp.vn || tp.vs);
+    tp.x0 = any ? static_cast<int>(xw) : 0;
+    tp.y0 = any ? static_cast<int>(yn) : 0;
+    return tp;
+}
+
+// depth 2 seen from camera 1 at frame-2 pixel (xx, yy):  m * (w2z + (d2 m) * (M2 p)_z)
+__device__ __forceinline__ float depth_in_1(const Camera& c, const float* d2, const float* mask, int64_t base, int w, int xx, int yy,
+                                            float* mask_out, float* s_out) {
+    const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
+    const float m = mask[o];
+    const float s = fmaf(c.m2z[1], static_cast<float>(yy), c.m2z[0] * static_cast<float>(xx)) + c.m2z[2];
+    *mask_out = m;
+    *s_out = s;
+    return m * (c.w2z + (d2[o] * m) * s);
+}
+
+__global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                       const float* __restrict__ mask, const float* __restrict__ t,
+                                                       const float* __restrict__ R, const float* __restrict__ K,
+                                                       float* __restrict__ warped, float* __restrict__ intersect,
+                                                       int h, int w, float eps) {
+    __shared__ Camera cam;
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int hw = h * w;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        float qx, qy, qz;
+        ray(cam, static_cast<float>(xx), static_cast<float>(yy), qx, qy, qz);
+        const float m = mask[base + i];
+        const float dm = d1[base + i] * m;
+        float zt = cam.w[2] + dm * qz;
+        zt = (m > 0.5f) ? zt : eps;
+        zt = (zt > 0.0f) ? zt : eps;
+        const float u2 = (cam.w[0] + dm * qx) / zt;
+        const float v2 = (cam.w[1] + dm * qy) / zt;
+        const Taps tp = make_taps(u2, v2, w, h);
+        float acc = 0.f, macc = 0.f, mm, ss;
+        {
+            float v = 0.f; mm = 0.f;
+            if (tp.vw && tp.vn) v = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0, &mm, &ss);
+            acc = tp.wnw * v; macc = tp.wnw * mm;
+        }
+        {
+            float v = 0.f; mm = 0.f;
+            if (tp.ve && tp.vn) v = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0, &mm, &ss);
+            acc += tp.wne * v; macc += tp.wne * mm;
+        }
+        {
+            float v = 0.f; mm = 0.f;
+            if (tp.vw && tp.vs) v = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0 + 1, &mm, &ss);
+            acc += tp.wsw * v; macc += tp.wsw * mm;
+        }
+        {
+            float v = 0.f; mm = 0.f;
+            if (tp.ve && tp.vs) v = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0 + 1, &mm, &ss);
+            acc += tp.wse * v; macc += tp.wse * mm;
+        }
+        warped[base + i] = acc;
+        intersect[base + i] = (macc * m >= 0.9f) ? 1.0f : 0.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__ gw, const float* __restrict__ d1,
+                                                       const float* __restrict__ d2, const float* __restrict__ mask,
+                                                       const float* __restrict__ t, const float* __restrict__ R,
+                                                       const float* __restrict__ K, float* __restrict__ gd1,
+                                                       float* gd2, int h, int w, float eps) {
+    __shared__ Camera cam;
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int hw = h * w;
+    const int64_t base = static_cast<int64_t>(n) * hw;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const int yy = i / w, xx = i - yy * w;
+        float qx, qy, qz;
+        ray(cam, static_cast<float>(xx), static_cast<float>(yy), qx, qy, qz);
+        const float m = mask[base + i];
+        const float dm = d1[base + i] * m;
+        const float z2 = cam.w[2] + dm * qz;
+        float zt = (m > 0.5f) ? z2 : eps;
+        const bool open = (m > 0.5f) && (zt > 0.0f);
+        zt = (zt > 0.0f) ? zt : eps;
+        const float nx = cam.w[0] + dm * qx;
+        const float ny = cam.w[1] + dm * qy;
+        const Taps tp = make_taps(nx / zt, ny / zt, w, h);
+        const float g = gw[base + i];
+        float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f, mm, ss;
+        if (tp.vw && tp.vn) {
+            vnw = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0, &mm, &ss);
+            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0) * w + tp.x0, g * tp.wnw * mm * ss * mm);
+        }
+        if (tp.ve && tp.vn) {
+            vne = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0, &mm, &ss);
+            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0) * w + tp.x0 + 1, g * tp.wne * mm * ss * mm);
+        }
+        if (tp.vw && tp.vs) {
+            vsw = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0 + 1, &mm, &ss);
+            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0 + 1) * w + tp.x0, g * tp.wsw * mm * ss * mm);
+        }
+        if (tp.ve && tp.vs) {
+            vse = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0 + 1, &mm, &ss);
+            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0 + 1) * w + tp.x0 + 1, g * tp.wse * mm * ss * mm);
+        }
+        const float sfrac = 1.0f - tp.fy, efrac = 1.0f - tp.fx;
+        // d out / d ix, d out / d iy, then grid_sample's (W/2, H/2) and the grid's (2/W, 2/H)
+        float gix = ((vne - vnw) * sfrac + (vse - vsw) * tp.fy) * g;
+        float giy = ((vsw - vnw) * efrac + (vse - vne) * tp.fx) * g;
+        const float gu = gix * (fw * 0.5f) * 2.0f / fw;
+        const float gv = giy * (fh * 0.5f) * 2.0f / fh;
+        float gdm = gu * qx / zt + gv * qy / zt;
+        if (open) gdm += -(gu * nx + gv * ny) / (zt * zt) * qz;
+        gd1[base + i] = gdm * m;
+    }
+}
+
+__global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__ a, const float* __restrict__ mask,
+                                                       float* __restrict__ out, int c, int hw) {
+    const int n = blockIdx.y;
+    const int64_t mbase = static_cast<int64_t>(n) * hw;
+    const int64_t abase = mbase * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const float m = mask[mbase + i];
+        for (int k = 0; k < c; ++k) out[abase + static_cast<int64_t>(k) * hw + i] = a[abase + static_cast<int64_t>(k) * hw + i] * m;
+    }
+}
+
+inline int plane_blocks(int hw, int threads) {
+    int b = (hw + threads - 1) / threads;
+    return b < 1 ? 1 : (b > 1024 ? 1024 : b);
+}
+
+}  // namespace endo
+
+using namespace endo;
+
+extern "C" int endo_depth_scale_fwd(const float* pred, const float* sparse_depth, const float* sparse_mask, float* scaled,
+                                    float* ratio, double* stats, int n, int hw, float eps, void* stream_) {
+    if (!pred || !sparse_depth || !sparse_mask || !scaled || !ratio || !stats || n <= 0 || hw <= 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 6.0 * 4.0 * n * hw);
+    ENDO_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 8 * n, stream));
+    dim3 rgrid((hw + kRedThreads * kRedItems - 1) / (kRedThreads * kRedItems), n);
+    depth_scale_pass1<<<rgrid, kRedThreads, 0, stream>>>(sparse_depth, sparse_mask, stats, hw);
+    depth_scale_pass2<<<rgrid, kRedThreads, 0, stream>>>(pred, sparse_depth, stats, hw, eps);
+    depth_scale_finalize<<<1, 64, 0, stream>>>(stats, ratio, n);
+    depth_scale_apply<<<dim3(plane_blocks(hw, 256), n), 256, 0, stream>>>(pred, stats, scaled, hw);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_depth_scale_bwd(const float* grad_scaled, const float* grad_ratio, const float* pred,
+                                    const float* sparse_depth, const double* stats, float* grad_pred, double* work, int n,
+                                    int hw, float eps, void* stream_) {
+    if (!pred || !sparse_depth || !stats || !grad_pred || !work || n <= 0 || hw <= 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 6.0 * 4.0 * n * hw);
+    ENDO_CHECK(hipMemsetAsync(work, 0, sizeof(double) * n, stream));
+    if (grad_scaled) {
+        dim3 rgrid((hw + kRedThreads * kRedItems - 1) / (kRedThreads * kRedItems), n);
+        depth_scale_bwd_reduce<<<rgrid, kRedThreads, 0, stream>>>(grad_scaled, pred, work, hw);
+    }
+    depth_scale_bwd_apply<<<dim3(plane_blocks(hw, 256), n), 256, 0, stream>>>(grad_scaled, grad_ratio, pred, sparse_depth,
+                                                                               stats, work, grad_pred, n, hw, eps);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_flow_from_depth_fwd(const float* depth, const float* mask, const float* t, const float* R, const float* K,
+                                        float* flow, int n, int h, int w, void* stream_) {
+    if (!depth || !mask || !t || !R || !K || !flow || n <= 0 || h <= 0 || w <= 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 4.0 * 4.0 * n * h * w);
+    flow_fwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(depth, mask, t, R, K, flow, h, w);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_flow_from_depth_bwd(const float* grad_flow, const float* depth, const float* mask, const float* t,
+                                        const float* R, const float* K, float* grad_depth, int n, int h, int w, void* stream_) {
+    if (!grad_flow || !depth || !mask || !t || !R || !K || !grad_depth || n <= 0 || h <= 0 || w <= 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 5.0 * 4.0 * n * h * w);
+    flow_bwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(grad_flow, depth, mask, t, R, K, grad_depth, h, w);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_depth_warp_fwd(const float* depth_1, const float* depth_2, const float* mask, const float* t, const float* R,
+                                   const float* K, float* warped, float* intersect, int n, int h, int w, float eps,
+                                   void* stream_) {
+    if (!depth_1 || !depth_2 || !mask || !t || !R || !K || !warped || !intersect || n <= 0 || h <= 0 || w <= 0)
+        return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 5.0 * 4.0 * n * h * w);
+    warp_fwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(depth_1, depth_2, mask, t, R, K, warped, intersect,
+                                                                           h, w, eps);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_depth_warp_bwd(const float* grad_warped, const float* depth_1, const float* depth_2, const float* mask,
+                                   const float* t, const float* R, const float* K, float* grad_d1, float* grad_d2, int n,
+                                   int h, int w, float eps, void* stream_) {
+    if (!grad_warped || !depth_1 || !depth_2 || !mask || !t || !R || !K || !grad_d1 || !grad_d2 || n <= 0 || h <= 0 || w <= 0)
+        return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    ProfScope prof(kProfGeometry, stream, 0.0, 7.0 * 4.0 * n * h * w);
+    ENDO_CHECK(hipMemsetAsync(grad_d2, 0, sizeof(float) * static_cast<size_t>(n) * h * w, stream));
+    warp_bwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(grad_warped, depth_1, depth_2, mask, t, R, K,
+                                                                           grad_d1, grad_d2, h, w, eps);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_mask_mul(const float* a, const float* mask, float* out, int n, int c, int hw, void* stream_) {
+    if (!a || !mask || !out || n <= 0 || c <= 0 || hw <= 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    mask_mul_kernel<<<dim3(plane_blocks(hw, 256), n), 256, 0, stream>>>(a, mask, out, c, hw);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}

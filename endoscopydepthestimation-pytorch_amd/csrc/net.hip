@@ -1,0 +1,635 @@
+// FC-DenseNet57 forward / backward schedule on the HIP kernels of conv_kernels.h / wgrad_kernels.h.
+//
+// Data layout in HBM (all fp32, NCHW planar, caller-owned):
+//   one "level buffer" U_L per resolution level L = 0..4 (H>>L x W>>L) holding, as channel planes,
+//       [0,48)              transition-up output of the up path
+//       [48, 48+C_L)        down-block input            (C_L = 48 + 48 L)
+//       [48+C_L, 96+C_L)    the 4 x 12 maps the down block adds
+//       [96+C_L, 144+C_L)   the 4 x 12 maps the up block adds
+//   and U_5 (bottleneck, H>>5) = [0,288) input, [288,336) new maps.
+//   Every convolution reads a channel range of a level buffer and writes a disjoint range of the
+//   same (or the next) level buffer, so torch.cat (reference models.py:46,48,52,79) never happens:
+//   the skip connection is simply the range [48, 96+C_L) that both paths address.
+//   The gradient workspace mirrors this layout.
+// Training-mode BatchNorm: per-channel sum / sum^2 (fp64) are produced once, by the epilogue of the
+// kernel that writes the channel, and consumed by every later BN over it (each with its own
+// gamma/beta and running statistics).
+#include <new>
+#include <vector>
+
+#include "wgrad_kernels.h"
+
+namespace endo {
+
+constexpr int kGrowth = 12;
+constexpr int kLayers = 4;
+constexpr int kFirst = 48;
+constexpr int kLevels = 5;
+constexpr int kNew = kGrowth * kLayers;   // 48
+constexpr float kBnEps = 1.0e-5f;
+constexpr float kBnMomentum = 0.1f;
+
+struct ConvP { int64_t w, b; int cout, cin, ks; };
+struct BnP { int64_t g, b; int c; int64_t run; int64_t saved; };   // run: offset in bn_running; saved: offset (pairs) in saved/scratch
+
+struct Table {
+    ConvP first, final_;
+    ConvP down_conv[kLevels][kLayers], td_conv[kLevels], bott_conv[kLayers], tu_conv[kLevels], up_conv[kLevels][kLayers];
+    BnP down_bn[kLevels][kLayers], td_bn[kLevels], bott_bn[kLayers], up_bn[kLevels][kLayers];
+    std::vector<int64_t> param_offsets;   // 210 tensors in .parameters() order
+    std::vector<BnP*> bn_order;           // 49 BN layers in module order
+    int64_t param_floats = 0, bn_floats = 0, bn_width_total = 0;
+};
+
+inline int down_in(int level) { return kFirst + kNew * level; }          // C_L
+inline int level_channels(int level) { return level < kLevels ? 144 + down_in(level) : 288 + kNew; }
+
+static const Table& table() {
+    static Table* t = [] {
+        Table* tb = new Table();
+        int64_t off = 0;
+        auto conv = [&](ConvP& c, int cout, int cin, int ks) {
+            c.cout = cout; c.cin = cin; c.ks = ks;
+            c.w = off; tb->param_offsets.push_back(off); off += static_cast<int64_t>(cout) * cin * ks * ks;
+            c.b = off; tb->param_offsets.push_back(off); off += cout;
+        };
+        int64_t run = 0, saved = 0;
+        auto bn = [&](BnP& b, int c) {
+            b.c = c;
+            b.g = off; tb->param_offsets.push_back(off); off += c;
+            b.b = off; tb->param_offsets.push_back(off); off += c;
+            b.run = run; run += 2 * c;
+            b.saved = saved; saved += c;
+            tb->bn_order.push_back(&b);
+        };
+        conv(tb->first, kFirst, 3, 3);
+        for (int l = 0; l < kLevels; ++l)
+            for (int j = 0; j < kLayers; ++j) { bn(tb->down_bn[l][j], down_in(l) + kGrowth * j); conv(tb->down_conv[l][j], kGrowth, down_in(l) + kGrowth * j, 3); }
+        for (int l = 0; l < kLevels; ++l) { bn(tb->td_bn[l], down_in(l) + kNew); conv(tb->td_conv[l], down_in(l) + kNew, down_in(l) + kNew, 1); }
+        for (int j = 0; j < kLayers; ++j) { bn(tb->bott_bn[j], 288 + kGrowth * j); conv(tb->bott_conv[j], kGrowth, 288 + kGrowth * j, 3); }
+        for (int i = 0; i < kLevels; ++i) conv(tb->tu_conv[i], kNew, kNew, 3);
+        for (int i = 0; i < kLevels; ++i) {
+            const int l = kLevels - 1 - i;
+            for (int j = 0; j < kLayers; ++j) { const int cin = 96 + down_in(l) + kGrowth * j; bn(tb->up_bn[i][j], cin); conv(tb->up_conv[i][j], kGrowth, cin, 3); }
+        }
+        conv(tb->final_, 1, 192, 1);
+        tb->param_floats = off;
+        tb->bn_floats = run;
+        tb->bn_width_total = saved;
+        return tb;
+    }();
+    return *t;
+}
+
+}  // namespace endo
+
+using namespace endo;
+
+struct endo_net {
+    int n, h, w;
+    struct Level { int h, w, t; int64_t plane; int64_t act, grad; int64_t sums; int64_t pq; } lv[kLevels + 1];
+    int64_t pre_off;       // final conv pre-activation (floats, tape)
+    int64_t saved_off;     // BN saved mean/rstd (floats, tape), 2 per BN channel
+    int64_t idx_off[kLevels];   // pool argmax codes (byte offsets from tape base)
+    int64_t sums_off;      // fp64 per-channel sums (byte offset, 8-aligned)
+    int64_t sums_bytes;
+    int64_t tape_floats;
+    int64_t pq_off;        // floats, gradws: P then Q per level channel
+    int64_t pq_floats;
+    int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
+    int64_t scratch_bytes;
+    int64_t gradws_floats;
+};
+
+namespace endo {
+
+// ---------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------
+
+// G = dbuf + P x + Q in place for a channel range (the deferred mean terms of every BN that consumed
+// the channel), and bias gradient += sum G.
+__global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, const float* __restrict__ x, int64_t ns, int plane,
+                                                      const float* __restrict__ pq_p, const float* __restrict__ pq_q,
+                                                      float* bias_grad) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float pc = pq_p[c], qc = pq_q[c];
+    const int64_t base = n * ns + static_cast<int64_t>(c) * plane;
+    float part[1] = {0.f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const float g = dbuf[base + i] + fmaf(pc, x[base + i], qc);
+        dbuf[base + i] = g;
+        part[0] += g;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v = wave_sum(static_cast<double>(part[0]));
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0 && bias_grad) atomicAdd(bias_grad + c, static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]));
+}
+
+// BN parameter gradients from the dgrad epilogue's sums, and the deferred dx terms:
+//   dx = scale*dz - scale*S1/M - scale*rstd*(S2/M)*(x - mean)   =>   P += -scale*rstd*S2/M,
+//   Q += -scale*S1/M + scale*rstd*S2/M*mean          (S1 = sum dz, S2 = sum dz*xhat)
+__global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const float* __restrict__ saved,
+                                       const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                       float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count, int training) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
+        const double s1 = scratch[2 * c], s2 = scratch[2 * c + 1];
+        ggamma[c] += static_cast<float>(s2);
+        gbeta[c] += static_cast<float>(s1);
+        if (training) {
+            const double mean = saved[2 * c], rstd = saved[2 * c + 1];
+            const double scale = gamma[c] * rstd;
+            const double k = scale * rstd * s2 / count;
+            pq_p[c] += static_cast<float>(-k);
+            pq_q[c] += static_cast<float>(-scale * s1 / count + k * mean);
+        }
+    }
+}
+
+// final 1x1 conv 192 -> 1 and |.| (reference models.py:186).  HBM-bound: reads each plane once.
+__global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict__ u, int64_t ns, int plane, int cin,
+                                                        const float* __restrict__ wgt, const float* __restrict__ bias,
+                                                        float* __restrict__ pre, float* __restrict__ out) {
+    __shared__ float s_w[192];
+    for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
+    __syncthreads();
+    const int n = blockIdx.y;
+    const bool vec = (plane & 3) == 0;
+    if (vec) {
+        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            const float* src = u + n * ns + i;
+            for (int c = 0; c < cin; ++c) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(src + static_cast<int64_t>(c) * plane);
+                const float wc = s_w[c];
+                acc[0] = fmaf(v[0], wc, acc[0]); acc[1] = fmaf(v[1], wc, acc[1]);
+                acc[2] = fmaf(v[2], wc, acc[2]); acc[3] = fmaf(v[3], wc, acc[3]);
+            }
+            const float b = bias[0];
+            f32x4 o;
+            for (int e = 0; e < 4; ++e) { acc[e] += b; o[e] = fabsf(acc[e]); }
+            if (pre) *reinterpret_cast<f32x4*>(pre + static_cast<int64_t>(n) * plane + i) = acc;
+            *reinterpret_cast<f32x4*>(out + static_cast<int64_t>(n) * plane + i) = o;
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+            float acc = 0.f;
+            for (int c = 0; c < cin; ++c) acc = fmaf(u[n * ns + static_cast<int64_t>(c) * plane + i], s_w[c], acc);
+            acc += bias[0];
+            if (pre) pre[static_cast<int64_t>(n) * plane + i] = acc;
+            out[static_cast<int64_t>(n) * plane + i] = fabsf(acc);
+        }
+    }
+}
+
+__device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// dbuf[c] = (gout * sign(pre)) * w[c] for all 192 planes (first writer of the level-0 gradient buffer)
+__global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
+                                                             const float* __restrict__ wgt, float* __restrict__ dbuf,
+                                                             int64_t ns, int plane, int cin) {
+    __shared__ float s_w[192];
+    for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
+    __syncthreads();
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const float g = gout[static_cast<int64_t>(n) * plane + i] * sign_of(pre[static_cast<int64_t>(n) * plane + i]);
+        for (int c = 0; c < cin; ++c) dbuf[n * ns + static_cast<int64_t>(c) * plane + i] = g * s_w[c];
+    }
+}
+
+// dw[c] += sum g * u[c]; channel index cin is the bias (sum g)
+__global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
+                                                               const float* __restrict__ u, int64_t ns, int plane, int cin,
+                                                               int nsamples, float* __restrict__ gw, float* __restrict__ gb) {
+    __shared__ double scratch[4];
+    const int c = blockIdx.x;
+    const int64_t total = static_cast<int64_t>(nsamples) * plane;
+    float part[1] = {0.f};
+    for (int64_t e = static_cast<int64_t>(blockIdx.y) * blockDim.x + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.y) * blockDim.x) {
+        const int n = static_cast<int>(e / plane);
+        const int i = static_cast<int>(e - static_cast<int64_t>(n) * plane);
+        const float g = gout[e] * sign_of(pre[e]);
+        part[0] += (c < cin) ? g * u[n * ns + static_cast<int64_t>(c) * plane + i] : g;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double v = wave_sum(static_cast<double>(part[0]));
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]);
+        if (c < cin) atomicAdd(gw + c, t); else atomicAdd(gb, t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// schedule helpers
+// ---------------------------------------------------------------------------------------------
+struct Ctx {
+    const endo_net* net;
+    const float* params;
+    float* bn_running;
+    float* tape;
+    float* grads;
+    float* gradws;
+    int training;
+    hipStream_t stream;
+
+    float* act(int level) const { return tape + net->lv[level].act; }
+    float* gbuf(int level) const { return gradws + net->lv[level].grad; }
+    double* sums(int level) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(tape) + net->sums_off) + net->lv[level].sums; }
+    float* saved(const BnP& b) const { return tape + net->saved_off + 2 * b.saved; }
+    double* scratch(const BnP& b) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(gradws) + net->scratch_off) + 2 * b.saved; }
+    float* pq_p(int level) const { return gradws + net->pq_off + 2 * net->lv[level].pq; }
+    float* pq_q(int level) const { return pq_p(level) + net->lv[level].t; }
+    uint8_t* idx(int level) const { return reinterpret_cast<uint8_t*>(tape) + net->idx_off[level]; }
+};
+
+static void fill_bn_in(const Ctx& c, ConvParams& p, const BnP& b, int level, int ic0) {
+    const auto& lv = c.net->lv[level];
+    p.in_sums = c.sums(level) + 2 * ic0;
+    p.gamma = c.params + b.g;
+    p.beta = c.params + b.b;
+    p.running_mean = c.bn_running + b.run;
+    p.running_var = c.bn_running + b.run + b.c;
+    p.saved = c.tape ? c.saved(b) : nullptr;
+    p.count = static_cast<double>(c.net->n) * lv.h * lv.w;
+    p.eps = kBnEps;
+    p.momentum = kBnMomentum;
+    p.training = c.training;
+}
+
+static void fill_in(const Ctx& c, ConvParams& p, const float* base, int level, int ic0, int cin) {
+    const auto& lv = c.net->lv[level];
+    p.in = base + ic0 * lv.plane;
+    p.in_ns = lv.t * lv.plane;
+    p.in_cs = static_cast<int>(lv.plane);
+    p.in_w = lv.w;
+    p.cin = cin;
+}
+
+static void fill_out(const Ctx& c, ConvParams& p, float* base, int level, int oc0, int cout) {
+    const auto& lv = c.net->lv[level];
+    p.out = base + oc0 * lv.plane;
+    p.out_ns = lv.t * lv.plane;
+    p.out_cs = static_cast<int>(lv.plane);
+    p.out_w = lv.w;
+    p.cout = cout;
+}
+
+static void fill_grid(const Ctx& c, ConvParams& p, int level) {
+    const auto& lv = c.net->lv[level];
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.tiles_x = (lv.w + kTileX - 1) / kTileX;
+}
+
+static double conv_flops(const endo_net* net, int level, int cin, int cout, int ks) {
+    return 2.0 * net->n * net->lv[level].plane * cin * cout * ks * ks;
+}
+
+// dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
+static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
+    ConvParams p{};
+    fill_grid(c, p, level);
+    fill_in(c, p, c.act(level), level, ic0, cv.cin);
+    fill_bn_in(c, p, b, level, ic0);
+    p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
+    fill_out(c, p, c.act(level), level, oc0, cv.cout);
+    p.out_sums = c.sums(level) + 2 * oc0;
+    ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
+                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout));
+    return launch_conv<3, 8, 1, IN_BNRELU, EPI_FWD>(p, c.stream);
+}
+
+// transition down: BN -> ReLU -> conv1x1 -> maxpool2 into the next level (models.py:56-67)
+static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
+    const int next = level + 1;
+    const int oc0 = next < kLevels ? 48 : 0;
+    ConvParams p{};
+    fill_grid(c, p, level);
+    fill_in(c, p, c.act(level), level, 48, cv.cin);
+    fill_bn_in(c, p, b, level, 48);
+    p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
+    fill_out(c, p, c.act(next), next, oc0, cv.cout);
+    p.out_idx = c.idx(level);      // [n][cout][pooled plane] bytes, channel index relative to `out`
+    p.idx_ns = static_cast<int64_t>(cv.cout) * c.net->lv[next].plane;
+    p.out_sums = c.sums(next) + 2 * oc0;
+    ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
+                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
+    return launch_conv<1, 16, 3, IN_BNRELU, EPI_FWD_POOL>(p, c.stream);
+}
+
+// transition up: nearest x2 -> conv3x3 48->48 into channels [0,48) of the finer level (models.py:70-80)
+static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const ConvP& cv) {
+    ConvParams p{};
+    fill_grid(c, p, level);
+    fill_in(c, p, c.act(src_level), src_level, src_c0, cv.cin);
+    p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
+    fill_out(c, p, c.act(level), level, 0, cv.cout);
+    p.out_sums = c.sums(level);
+    ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
+                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
+    return launch_conv<3, 8, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
+}
+
+static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad) {
+    const auto& lv = c.net->lv[level];
+    int bx = static_cast<int>((lv.plane + 1023) / 1024);
+    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.net->n * lv.plane * count);
+    prep_dy_kernel<<<dim3(bx, count, c.net->n), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
+                                                                     lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
+                                                                     c.pq_q(level) + c0, bias_grad);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+static int bn_finalize(const Ctx& c, const BnP& b, int level, int ic0) {
+    const auto& lv = c.net->lv[level];
+    ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
+    bn_bwd_finalize_kernel<<<(b.c + 127) / 128, 128, 0, c.stream>>>(c.scratch(b), c.saved(b), c.params + b.g, c.grads + b.g,
+                                                                     c.grads + b.b, c.pq_p(level) + ic0, c.pq_q(level) + ic0, b.c,
+                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+static void fill_wgrad_grid(const Ctx& c, WgradParams& p, int level) {
+    const auto& lv = c.net->lv[level];
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.tiles_x = (lv.w + kWgTileX - 1) / kWgTileX;
+    p.tiles_y = (lv.h + kWgTileY - 1) / kWgTileY;
+}
+
+// dense layer backward: bias grad + deferred-term fold, wgrad, dgrad fused with ReLU/BN backward
+static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv, int acc_from) {
+    const auto& lv = c.net->lv[level];
+    int rc = prep_dy(c, level, oc0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    {
+        WgradParams p{};
+        fill_wgrad_grid(c, p, level);
+        p.in = c.act(level) + ic0 * lv.plane; p.in_ns = lv.t * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = cv.cin;
+        p.saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b;
+        p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
+        p.dw = c.grads + cv.w;
+        ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+        rc = launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
+        if (rc) return rc;
+    }
+    {
+        ConvParams p{};
+        fill_grid(c, p, level);
+        fill_in(c, p, c.gbuf(level), level, oc0, cv.cout);
+        p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
+        fill_out(c, p, c.gbuf(level), level, ic0, cv.cin);
+        p.x = c.act(level) + ic0 * lv.plane; p.x_ns = lv.t * lv.plane; p.x_cs = static_cast<int>(lv.plane);
+        p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
+        p.bn_scratch = c.scratch(b);
+        p.acc_from = acc_from - ic0;
+        ProfScope prof(kProfDgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (3.0 * cv.cin + cv.cout));
+        rc = launch_conv<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN>(p, c.stream);
+        if (rc) return rc;
+    }
+    return bn_finalize(c, b, level, ic0);
+}
+
+static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
+    const int next = level + 1;
+    const int oc0 = next < kLevels ? 48 : 0;
+    const auto& lv = c.net->lv[level];
+    const auto& nx = c.net->lv[next];
+    int rc = prep_dy(c, next, oc0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    {
+        WgradParams p{};
+        fill_wgrad_grid(c, p, level);
+        p.in = c.act(level) + 48 * lv.plane; p.in_ns = lv.t * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = cv.cin;
+        p.saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b;
+        p.dy = c.gbuf(next) + oc0 * nx.plane; p.dy_ns = nx.t * nx.plane; p.dy_cs = static_cast<int>(nx.plane); p.dy_w = nx.w; p.cout = cv.cout;
+        p.dy_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;
+        p.dw = c.grads + cv.w;
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * cv.cin);
+        rc = launch_wgrad<1, 3, IN_BNRELU, DY_UNPOOL>(p, c.stream);
+        if (rc) return rc;
+    }
+    {
+        ConvParams p{};
+        fill_grid(c, p, level);
+        fill_in(c, p, c.gbuf(next), next, oc0, cv.cout);
+        p.in_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;   // channel index relative to p.in
+        p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
+        fill_out(c, p, c.gbuf(level), level, 48, cv.cin);
+        p.x = c.act(level) + 48 * lv.plane; p.x_ns = lv.t * lv.plane; p.x_cs = static_cast<int>(lv.plane);
+        p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
+        p.bn_scratch = c.scratch(b);
+        p.acc_from = 0;
+        ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * 3.0 * cv.cin);
+        rc = launch_conv<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN>(p, c.stream);
+        if (rc) return rc;
+    }
+    return bn_finalize(c, b, level, 48);
+}
+
+static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const ConvP& cv) {
+    const auto& lv = c.net->lv[level];
+    const auto& sv = c.net->lv[src_level];
+    int rc = prep_dy(c, level, 0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    {
+        WgradParams p{};
+        fill_wgrad_grid(c, p, level);
+        p.in = c.act(src_level) + src_c0 * sv.plane; p.in_ns = sv.t * sv.plane; p.in_cs = static_cast<int>(sv.plane); p.in_w = sv.w; p.cin = cv.cin;
+        p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
+        p.dw = c.grads + cv.w;
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin / 4.0 + cv.cout));
+        rc = launch_wgrad<3, 3, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
+        if (rc) return rc;
+    }
+    ConvParams p{};
+    fill_grid(c, p, level);
+    fill_in(c, p, c.gbuf(level), level, 0, cv.cout);
+    p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
+    fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
+    ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cout + cv.cin / 4.0));
+    return launch_conv<3, 8, 3, IN_PLAIN, EPI_DGRAD_SUMPOOL>(p, c.stream);
+}
+
+static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace endo
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
+    if (!out || n <= 0 || h <= 0 || w <= 0) return ENDO_E_BADARG;
+    if ((h % 32) != 0 || (w % 32) != 0) return ENDO_E_UNSUPPORTED;   // 5 poolings + exact centre crop (models.py:93-97)
+    const Table& tb = table();
+    endo_net* net = new (std::nothrow) endo_net();
+    if (!net) return ENDO_E_BADARG;
+    net->n = n; net->h = h; net->w = w;
+    int64_t off = 0, sums = 0, pq = 0;
+    for (int l = 0; l <= kLevels; ++l) {
+        auto& lv = net->lv[l];
+        lv.h = h >> l; lv.w = w >> l; lv.t = level_channels(l);
+        lv.plane = static_cast<int64_t>(lv.h) * lv.w;
+        lv.act = off; lv.grad = off;
+        off += align_up(static_cast<int64_t>(n) * lv.t * lv.plane, 64);
+        lv.sums = sums; sums += 2 * lv.t;
+        lv.pq = pq; pq += lv.t;
+    }
+    const int64_t acts = off;
+    net->pre_off = off; off += align_up(static_cast<int64_t>(n) * h * w, 64);
+    net->saved_off = off; off += align_up(2 * tb.bn_width_total, 64);
+    int64_t byte_off = off * 4;
+    for (int l = 0; l < kLevels; ++l) {
+        net->idx_off[l] = byte_off;
+        byte_off += align_up(static_cast<int64_t>(n) * (down_in(l) + kNew) * net->lv[l + 1].plane, 256);
+    }
+    net->sums_off = byte_off;
+    net->sums_bytes = sums * 8;
+    byte_off += align_up(net->sums_bytes, 256);
+    net->tape_floats = byte_off / 4;
+    net->pq_off = acts;
+    net->pq_floats = 2 * pq;
+    net->scratch_off = align_up((acts + net->pq_floats) * 4, 256);
+    net->scratch_bytes = tb.bn_width_total * 2 * 8;
+    net->gradws_floats = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
+    *out = net;
+    return 0;
+}
+
+extern "C" void endo_net_destroy(endo_net* net) { delete net; }
+extern "C" int64_t endo_net_param_floats(void) { return table().param_floats; }
+extern "C" int64_t endo_net_bn_floats(void) { return table().bn_floats; }
+extern "C" int64_t endo_net_tape_floats(const endo_net* net) { return net ? net->tape_floats : 0; }
+extern "C" int64_t endo_net_gradws_floats(const endo_net* net) { return net ? net->gradws_floats : 0; }
+extern "C" int64_t endo_net_param_offset(int index) {
+    const Table& tb = table();
+    if (index < 0 || index >= static_cast<int>(tb.param_offsets.size())) return -1;
+    return tb.param_offsets[index];
+}
+extern "C" int64_t endo_net_bn_offset(int bn_index, int which) {
+    const Table& tb = table();
+    if (bn_index < 0 || bn_index >= static_cast<int>(tb.bn_order.size()) || which < 0 || which > 1) return -1;
+    return tb.bn_order[bn_index]->run + which * tb.bn_order[bn_index]->c;
+}
+extern "C" int endo_net_level_channels(int level) { return (level < 0 || level > kLevels) ? -1 : level_channels(level); }
+extern "C" int64_t endo_net_act_offset(const endo_net* net, int level) { return (!net || level < 0 || level > kLevels) ? -1 : net->lv[level].act; }
+
+extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_running, const float* x, float* out, float* tape,
+                            int training, void* stream_) {
+    if (!net || !params || !bn_running || !x || !out || !tape) return ENDO_E_BADARG;
+    const Table& tb = table();
+    Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
+    ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape) + net->sums_off, 0, net->sums_bytes, c.stream));
+    int rc;
+    {   // first conv 3 -> 48 into level-0 channels [48, 96)
+        ConvParams p{};
+        fill_grid(c, p, 0);
+        p.in = x; p.in_ns = 3 * net->lv[0].plane; p.in_cs = static_cast<int>(net->lv[0].plane); p.in_w = net->w; p.cin = 3;
+        p.wgt = params + tb.first.w; p.bias = params + tb.first.b; p.w_cout = kFirst; p.w_cin = 3;
+        fill_out(c, p, c.act(0), 0, 48, kFirst);
+        p.out_sums = c.sums(0) + 2 * 48;
+        ProfScope prof(kProfConvFirst, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * net->lv[0].plane * (3 + kFirst));
+        rc = launch_conv<3, 4, 3, IN_PLAIN, EPI_FWD>(p, c.stream);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < kLevels; ++l) {
+        for (int j = 0; j < kLayers; ++j) {
+            rc = dense_fwd(c, l, 48, 48 + down_in(l) + kGrowth * j, tb.down_bn[l][j], tb.down_conv[l][j]);
+            if (rc) return rc;
+        }
+        rc = td_fwd(c, l, tb.td_bn[l], tb.td_conv[l]);
+        if (rc) return rc;
+    }
+    for (int j = 0; j < kLayers; ++j) {
+        rc = dense_fwd(c, kLevels, 0, 288 + kGrowth * j, tb.bott_bn[j], tb.bott_conv[j]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < kLevels; ++i) {
+        const int l = kLevels - 1 - i;
+        const int src = l + 1;
+        const int src_c0 = (i == 0) ? 288 : 96 + down_in(src);
+        rc = tu_fwd(c, l, src, src_c0, tb.tu_conv[i]);
+        if (rc) return rc;
+        for (int j = 0; j < kLayers; ++j) {
+            rc = dense_fwd(c, l, 0, 96 + down_in(l) + kGrowth * j, tb.up_bn[i][j], tb.up_conv[i][j]);
+            if (rc) return rc;
+        }
+    }
+    {
+        const auto& lv = net->lv[0];
+        ProfScope prof(kProfConvFinal, c.stream, 2.0 * net->n * lv.plane * 192, 4.0 * net->n * lv.plane * 194);
+        int bx = static_cast<int>((lv.plane / 4 + 255) / 256);
+        bx = bx < 1 ? 1 : bx;
+        final_fwd_kernel<<<dim3(bx, net->n), 256, 0, c.stream>>>(c.act(0), lv.t * lv.plane, static_cast<int>(lv.plane), 192,
+                                                                 params + tb.final_.w, params + tb.final_.b, tape + net->pre_off, out);
+        ENDO_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, const float* tape, const float* grad_out,
+                            float* grads, float* gradws, int training, void* stream_) {
+    if (!net || !params || !x || !tape || !grad_out || !grads || !gradws) return ENDO_E_BADARG;
+    const Table& tb = table();
+    Ctx c{net, params, nullptr, const_cast<float*>(tape), grads, gradws, training, static_cast<hipStream_t>(stream_)};
+    // zero the deferred-term tables and the BN reduction scratch
+    ENDO_CHECK(hipMemsetAsync(gradws + net->pq_off, 0,
+                              static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
+    int rc;
+    {
+        const auto& lv = net->lv[0];
+        ProfScope prof(kProfConvFinal, c.stream, 4.0 * net->n * lv.plane * 192, 4.0 * net->n * lv.plane * (2 * 192 + 4));
+        int bx = static_cast<int>((lv.plane + 255) / 256);
+        final_bwd_data_kernel<<<dim3(bx, net->n), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
+                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), 192);
+        int by = static_cast<int>((static_cast<int64_t>(net->n) * lv.plane + 256 * 64 - 1) / (256 * 64));
+        by = by < 1 ? 1 : (by > 64 ? 64 : by);
+        final_bwd_weight_kernel<<<dim3(193, by), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
+                                                                     static_cast<int>(lv.plane), 192, net->n, grads + tb.final_.w,
+                                                                     grads + tb.final_.b);
+        ENDO_LAUNCH_CHECK();
+    }
+    for (int i = kLevels - 1; i >= 0; --i) {
+        const int l = kLevels - 1 - i;
+        for (int j = kLayers - 1; j >= 0; --j) {
+            const int acc_from = (j == kLayers - 1 && l > 0) ? 96 + down_in(l) : 0;
+            rc = dense_bwd(c, l, 0, 96 + down_in(l) + kGrowth * j, tb.up_bn[i][j], tb.up_conv[i][j], acc_from);
+            if (rc) return rc;
+        }
+        const int src = l + 1;
+        const int src_c0 = (i == 0) ? 288 : 96 + down_in(src);
+        rc = tu_bwd(c, l, src, src_c0, tb.tu_conv[i]);
+        if (rc) return rc;
+    }
+    for (int j = kLayers - 1; j >= 0; --j) {
+        rc = dense_bwd(c, kLevels, 0, 288 + kGrowth * j, tb.bott_bn[j], tb.bott_conv[j], j == kLayers - 1 ? 288 : 0);
+        if (rc) return rc;
+    }
+    for (int l = kLevels - 1; l >= 0; --l) {
+        rc = td_bwd(c, l, tb.td_bn[l], tb.td_conv[l]);
+        if (rc) return rc;
+        for (int j = kLayers - 1; j >= 0; --j) {
+            rc = dense_bwd(c, l, 48, 48 + down_in(l) + kGrowth * j, tb.down_bn[l][j], tb.down_conv[l][j], 48);
+            if (rc) return rc;
+        }
+    }
+    {   // first conv: bias grad + weight grad (the image needs no gradient)
+        rc = prep_dy(c, 0, 48, kFirst, grads + tb.first.b);
+        if (rc) return rc;
+        const auto& lv = net->lv[0];
+        WgradParams p{};
+        fill_wgrad_grid(c, p, 0);
+        p.in = x; p.in_ns = 3 * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = 3;
+        p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
+        p.dw = grads + tb.first.w;
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * lv.plane * (3 + kFirst));
+        return launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
+    }
+}

@@ -1,0 +1,82 @@
+"""Data parallelism: one process per GPU, persistent replicas, ONE all-reduce of the flat gradient
+bucket per step (RCCL over xGMI via torch.distributed backend "nccl"), replacing the per-forward
+broadcast / scatter / gather / reduce_add of ``torch.nn.DataParallel`` (reference train.py:197;
+SURVEY.md 2.2 rows C1-C3).  Also the 1-element MAX all-reduce that makes every rank take the same
+branch of the non-finite-loss guard (train.py:317-322).  Backend-agnostic: the CPU tests drive it
+with gloo.
+"""
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, 0
+    rank = int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def shard_range(total, rank, world):
+    """Samples [lo, hi) of a global batch owned by ``rank`` (equal shards)."""
+    if total % world != 0:
+        raise ValueError("global batch %d is not divisible by world size %d" % (total, world))
+    per = total // world
+    return rank * per, (rank + 1) * per
+
+
+class GradientBucket(object):
+    """The flat fp32 gradient buffer of a model replica, reduced with a single collective."""
+
+    def __init__(self, flat_grad_fn):
+        self._flat_grad_fn = flat_grad_fn
+
+    def all_reduce(self):
+        """Sum the bucket over ranks.  Returns the factor (1/world) the optimizer must apply --
+        it is folded into the fused clip+SGD kernel instead of costing a pass of its own."""
+        world = world_size()
+        if world > 1:
+            dist.all_reduce(self._flat_grad_fn(), op=dist.ReduceOp.SUM)
+        return 1.0 / world
+
+
+def agree_nonfinite(flag_tensor):
+    """flag_tensor: 1-element tensor, 1 where this rank's loss is NaN/Inf.  MAX over ranks so the
+    guard of train.py:317-322 is taken by all ranks or none."""
+    if world_size() > 1:
+        dist.all_reduce(flag_tensor, op=dist.ReduceOp.MAX)
+    return flag_tensor
+
+
+def broadcast_buffers(flat_bn, src=0):
+    """BN running statistics are per replica (DataParallel semantics: replica 0's survive).  Call
+    before checkpointing so every rank saves rank 0's statistics."""
+    if world_size() > 1:
+        dist.broadcast(flat_bn, src=src)
+    return flat_bn
+
+
+def mean_scalars(values):
+    """all-reduce(mean) of a small tensor of logged scalars (loss terms)."""
+    world = world_size()
+    if world > 1:
+        dist.all_reduce(values, op=dist.ReduceOp.SUM)
+        values /= world
+    return values

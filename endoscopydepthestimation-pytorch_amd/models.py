@@ -1,0 +1,450 @@
+"""Drop-in replacements for the ``nn.Module`` classes of reference ``models.py`` that ``train.py`` /
+``evaluate.py`` instantiate, running on hand-written HIP kernels for MI355X (libendo_hip.so).
+
+API kept from the reference:
+  * ``FCDenseNet57(n_classes=1)``: ``forward(x: N x 3 x H x W) -> N x 1 x H x W`` (>= 0); same
+    ``state_dict`` key names and ``.parameters()`` order as reference models.py:100-194, so reference
+    checkpoints load and ``torch.optim.SGD`` / ``clip_grad_norm_`` iterate the same 210 tensors.
+  * ``DepthScalingLayer(epsilon)``, ``FlowfromDepthLayer()``, ``DepthWarpingLayer(epsilon)``:
+    ``forward(x)`` takes ONE list argument and returns a tensor or a pair (models.py:346-347,
+    370-371, 460-461).
+Tensors are contiguous NCHW fp32 on the current HIP device; there is no CPU path.
+
+Design notes (DESIGN.md has the full story): parameters are views into one flat fp32 buffer and
+their ``.grad`` are views into one flat gradient buffer -- the kernels accumulate weight gradients
+there directly, the fused clip+SGD step and the single RCCL all-reduce run over the flat buffers.
+"""
+
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+
+GROWTH = 12
+LAYERS = 4
+FIRST = 48
+LEVELS = 5
+
+
+# ---------------------------------------------------------------------------------------------
+# parameter holders (they only own tensors; all arithmetic happens inside the HIP library)
+# ---------------------------------------------------------------------------------------------
+class ConvParams(nn.Module):
+    """weight [cout, cin, k, k] + bias [cout] of one convolution (reference nn.Conv2d slots)."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.kaiming_uniform_(self.weight, a=5 ** 0.5)
+
+
+class FusedBatchNorm2d(nn.Module):
+    """gamma/beta + running statistics of one BatchNorm2d (eps 1e-5, momentum 0.1).  The
+    normalisation itself is fused into the load path of the convolution that follows it."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.num_features = channels
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.register_buffer("running_mean", torch.zeros(channels))
+        self.register_buffer("running_var", torch.ones(channels))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class DenseLayer(nn.Module):          # reference models.py:19-28
+    def __init__(self, cin):
+        super().__init__()
+        self.norm = FusedBatchNorm2d(cin)
+        self.conv = ConvParams(cin, GROWTH, 3)
+
+
+class DenseBlock(nn.Module):          # reference models.py:31-53
+    def __init__(self, cin):
+        super().__init__()
+        self.layers = nn.ModuleList([DenseLayer(cin + j * GROWTH) for j in range(LAYERS)])
+
+
+class TransitionDown(nn.Module):      # reference models.py:56-67
+    def __init__(self, channels):
+        super().__init__()
+        self.norm = FusedBatchNorm2d(channels)
+        self.conv = ConvParams(channels, channels, 1)
+
+
+class _Nearest2x(nn.Module):
+    """Placeholder for nn.Upsample at index 0 of ``convTrans`` (keeps the key 'convTrans.1.*')."""
+
+
+class TransitionUp(nn.Module):        # reference models.py:70-80
+    def __init__(self, channels):
+        super().__init__()
+        self.convTrans = nn.ModuleList([_Nearest2x(), ConvParams(channels, channels, 3)])
+
+
+class Bottleneck(nn.Module):          # reference models.py:83-90
+    def __init__(self, cin):
+        super().__init__()
+        self.bottleneck = DenseBlock(cin)
+
+
+class _NetFunction(torch.autograd.Function):
+    """Whole-network forward/backward as ONE autograd node (the reference builds ~400 per call)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        x = _lib.dev_f32(x, "FCDenseNet57 input")
+        out, tape = net._run_forward(x)
+        ctx.net = net
+        ctx.training = net.training
+        ctx.tape = tape
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        ctx.net._run_backward(x, ctx.tape, grad_out, ctx.training)
+        ctx.tape = None
+        return None, None, None
+
+
+class FCDenseNet(nn.Module):
+    """FC-DenseNet57 (the only configuration the drivers use, reference models.py:190-194)."""
+
+    def __init__(self, n_classes=1):
+        super().__init__()
+        if n_classes != 1:
+            raise ValueError("the MI355X path implements the depth network (n_classes=1) only")
+        self.firstconv = ConvParams(3, FIRST, 3)
+        c = FIRST
+        skips = []
+        self.denseBlocksDown = nn.ModuleList()
+        self.transDownBlocks = nn.ModuleList()
+        for _ in range(LEVELS):
+            self.denseBlocksDown.append(DenseBlock(c))
+            c += GROWTH * LAYERS
+            skips.insert(0, c)
+            self.transDownBlocks.append(TransitionDown(c))
+        self.bottleneck = Bottleneck(c)
+        new = GROWTH * LAYERS
+        self.transUpBlocks = nn.ModuleList()
+        self.denseBlocksUp = nn.ModuleList()
+        for i in range(LEVELS):
+            self.transUpBlocks.append(TransitionUp(new))
+            self.denseBlocksUp.append(DenseBlock(new + skips[i]))
+        self.finalConv = ConvParams(new + skips[-1] + new, 1, 1)
+
+        self._flat = None          # flat parameter storage (all 210 tensors)
+        self._flat_grad = None
+        self._flat_bn = None       # running_mean/var of the 49 BN layers
+        self._nbt = None
+        self._handles = {}
+        self._gradws = {}
+        self._anchor = None
+        self._flatten()
+
+    # ---- flat storage -------------------------------------------------------------------------
+    def _bn_modules(self):
+        return [m for m in self.modules() if isinstance(m, FusedBatchNorm2d)]
+
+    def _flatten(self):
+        """(Re)pack parameters and BN buffers into flat buffers and make the tensors views of them."""
+        params = list(self.parameters())
+        device = params[0].device
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=device)
+        off = 0
+        offsets = []
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1).float())
+            p.data = flat[off:off + n].view(p.shape)
+            p.grad = None
+            offsets.append(off)
+            off += n
+        self._flat, self._offsets, self._params = flat, offsets, params
+        self._flat_grad = None
+        bns = self._bn_modules()
+        width = sum(2 * m.num_features for m in bns)
+        flat_bn = torch.empty(width, dtype=torch.float32, device=device)
+        nbt = torch.empty(len(bns), dtype=torch.long, device=device)
+        off = 0
+        for i, m in enumerate(bns):
+            c = m.num_features
+            flat_bn[off:off + c].copy_(m.running_mean)
+            flat_bn[off + c:off + 2 * c].copy_(m.running_var)
+            nbt[i] = m.num_batches_tracked
+            m._buffers["running_mean"] = flat_bn[off:off + c]
+            m._buffers["running_var"] = flat_bn[off + c:off + 2 * c]
+            m._buffers["num_batches_tracked"] = nbt[i]
+            off += 2 * c
+        self._flat_bn, self._nbt, self._bns = flat_bn, nbt, bns
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._gradws = {}
+
+    def _apply(self, fn, recurse=True):
+        super()._apply(fn, recurse)
+        self._flatten()          # .cuda() / .to() re-allocate every tensor: re-pack into flat buffers
+        return self
+
+    def _views_intact(self):
+        base = self._flat.data_ptr()
+        for p, off in zip(self._params, self._offsets):
+            if p.data_ptr() != base + 4 * off:
+                return False
+        off = 0
+        base = self._flat_bn.data_ptr()
+        for m in self._bns:
+            if m.running_mean.data_ptr() != base + 4 * off:
+                return False
+            off += 2 * m.num_features
+        return True
+
+    def flat_parameters(self):
+        """The flat fp32 buffer all 210 parameters are views of (reference .parameters() order)."""
+        return self._flat
+
+    def flat_gradients(self, create=True):
+        """The flat gradient buffer; every ``p.grad`` is a view of it (zero-filled on (re)attach)."""
+        self._attach_grads(create)
+        return self._flat_grad
+
+    def _attach_grads(self, create=True):
+        if self._flat_grad is None or self._flat_grad.device != self._flat.device:
+            if not create:
+                return
+            self._flat_grad = torch.zeros_like(self._flat)
+            for p, off in zip(self._params, self._offsets):
+                p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
+            return
+        base = self._flat_grad.data_ptr()
+        intact = True
+        for p, off in zip(self._params, self._offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                intact = False
+                break
+        if not intact:       # e.g. optimizer.zero_grad(set_to_none=True): start a fresh accumulation
+            self._flat_grad.zero_()
+            for p, off in zip(self._params, self._offsets):
+                p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
+
+    # ---- HIP library plumbing ------------------------------------------------------------------
+    def _handle(self, n, h, w):
+        key = (n, h, w)
+        if key not in self._handles:
+            lib = _lib.load()
+            if lib.endo_net_param_floats() != self._flat.numel():
+                raise RuntimeError("parameter packing mismatch between Python and libendo_hip.so")
+            hnd = ctypes.c_void_p()
+            _lib.check(lib.endo_net_create(ctypes.byref(hnd), n, h, w), "endo_net_create(%d,%d,%d)" % key)
+            self._handles[key] = (hnd, int(lib.endo_net_tape_floats(hnd)), int(lib.endo_net_gradws_floats(hnd)))
+        return self._handles[key]
+
+    def __del__(self):
+        try:
+            lib = _lib.load()
+            for hnd, _, _ in self._handles.values():
+                lib.endo_net_destroy(hnd)
+        except Exception:
+            pass
+
+    def _run_forward(self, x):
+        lib = _lib.load()
+        x = _lib.dev_f32(x, "FCDenseNet57 input")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected N x 3 x H x W input")
+        if x.device != self._flat.device:
+            raise RuntimeError("model and input are on different devices; call model.cuda() first")
+        if not self._views_intact():
+            self._flatten()
+        n, _, h, w = x.shape
+        hnd, tape_floats, _ = self._handle(n, h, w)
+        tape = torch.empty(tape_floats, dtype=torch.float32, device=x.device)
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        _lib.check(lib.endo_net_fwd(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out),
+                                    _lib.ptr(tape), 1 if self.training else 0, _lib.stream()), "endo_net_fwd")
+        if self.training:
+            self._nbt.add_(1)
+        return out, tape
+
+    def _run_backward(self, x, tape, grad_out, training):
+        lib = _lib.load()
+        n, _, h, w = x.shape
+        hnd, _, gradws_floats = self._handle(n, h, w)
+        key = (n, h, w)
+        if key not in self._gradws:
+            self._gradws[key] = torch.empty(gradws_floats, dtype=torch.float32, device=x.device)
+        self._attach_grads()
+        grad_out = _lib.dev_f32(grad_out, "grad_output")
+        _lib.check(lib.endo_net_bwd(hnd, _lib.ptr(self._flat), _lib.ptr(x), _lib.ptr(tape), _lib.ptr(grad_out),
+                                    _lib.ptr(self._flat_grad), _lib.ptr(self._gradws[key]),
+                                    1 if training else 0, _lib.stream()), "endo_net_bwd")
+
+    def forward(self, x):
+        if torch.is_grad_enabled():
+            return _NetFunction.apply(x, self._anchor, self)
+        out, _ = self._run_forward(x)
+        return out
+
+    def level_buffers(self, x):
+        """Debug/test hook: run a forward and return the six level buffers (views of the tape)."""
+        lib = _lib.load()
+        out, tape = self._run_forward(x)
+        n, _, h, w = x.shape
+        hnd, _, _ = self._handle(n, h, w)
+        levels = []
+        for lvl in range(LEVELS + 1):
+            ch = lib.endo_net_level_channels(lvl)
+            off = lib.endo_net_act_offset(hnd, lvl)
+            hh, ww = h >> lvl, w >> lvl
+            levels.append(tape[off:off + n * ch * hh * ww].view(n, ch, hh, ww))
+        return out, levels
+
+
+def FCDenseNet57(n_classes):
+    return FCDenseNet(n_classes=n_classes)
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry layers
+# ---------------------------------------------------------------------------------------------
+class _DepthScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, sparse_depth, sparse_mask, eps):
+        lib = _lib.load()
+        pred = _lib.dev_f32(pred, "depth estimations")
+        sd = _lib.dev_f32(sparse_depth, "sparse depths")
+        sm = _lib.dev_f32(sparse_mask, "sparse masks")
+        n, hw = pred.shape[0], pred.shape[1] * pred.shape[2] * pred.shape[3]
+        scaled = torch.empty_like(pred)
+        ratio = torch.empty((), dtype=torch.float32, device=pred.device)
+        stats = torch.empty((n, 8), dtype=torch.float64, device=pred.device)
+        _lib.check(lib.endo_depth_scale_fwd(_lib.ptr(pred), _lib.ptr(sd), _lib.ptr(sm), _lib.ptr(scaled), _lib.ptr(ratio),
+                                            _lib.ptr(stats), n, hw, eps, _lib.stream()), "endo_depth_scale_fwd")
+        ctx.save_for_backward(pred, sd, stats)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return scaled, ratio
+
+    @staticmethod
+    def backward(ctx, grad_scaled, grad_ratio):
+        lib = _lib.load()
+        pred, sd, stats = ctx.saved_tensors
+        if grad_scaled is None and grad_ratio is None:
+            return None, None, None, None
+        n, hw = pred.shape[0], pred.shape[1] * pred.shape[2] * pred.shape[3]
+        gs = None if grad_scaled is None else _lib.dev_f32(grad_scaled, "grad")
+        gr = None if grad_ratio is None else _lib.dev_f32(grad_ratio, "grad")
+        grad_pred = torch.empty_like(pred)
+        work = torch.empty((n,), dtype=torch.float64, device=pred.device)
+        _lib.check(lib.endo_depth_scale_bwd(_lib.ptr(gs), _lib.ptr(gr), _lib.ptr(pred), _lib.ptr(sd), _lib.ptr(stats),
+                                            _lib.ptr(grad_pred), _lib.ptr(work), n, hw, ctx.eps, _lib.stream()),
+                   "endo_depth_scale_bwd")
+        return grad_pred, None, None, None
+
+
+class DepthScalingLayer(nn.Module):
+    """reference models.py:339-363: per-sample scale recovery from sparse SfM depths."""
+
+    def __init__(self, epsilon=1.0e-8):
+        super().__init__()
+        self.epsilon = float(epsilon)
+
+    def forward(self, x):
+        absolute_depth_estimations, input_sparse_depths, input_weighted_sparse_masks = x
+        return _DepthScaleFn.apply(absolute_depth_estimations, input_sparse_depths, input_weighted_sparse_masks,
+                                   self.epsilon)
+
+
+def _pose(t, r, k, n):
+    t = _lib.dev_f32(t, "translation vectors").reshape(n, 3)
+    r = _lib.dev_f32(r, "rotation matrices").reshape(n, 9)
+    k = _lib.dev_f32(k, "intrinsic matrices").reshape(n, 9)
+    return t, r, k
+
+
+class _FlowFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, mask, t, r, k):
+        lib = _lib.load()
+        depth = _lib.dev_f32(depth, "depth maps")
+        mask = _lib.dev_f32(mask, "image masks")
+        n, _, h, w = depth.shape
+        t, r, k = _pose(t, r, k, n)
+        flow = torch.empty((n, 2, h, w), dtype=torch.float32, device=depth.device)
+        _lib.check(lib.endo_flow_from_depth_fwd(_lib.ptr(depth), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r), _lib.ptr(k),
+                                                _lib.ptr(flow), n, h, w, _lib.stream()), "endo_flow_from_depth_fwd")
+        ctx.save_for_backward(depth, mask, t, r, k)
+        return flow
+
+    @staticmethod
+    def backward(ctx, grad_flow):
+        lib = _lib.load()
+        depth, mask, t, r, k = ctx.saved_tensors
+        n, _, h, w = depth.shape
+        grad_flow = _lib.dev_f32(grad_flow, "grad")
+        grad_depth = torch.empty_like(depth)
+        _lib.check(lib.endo_flow_from_depth_bwd(_lib.ptr(grad_flow), _lib.ptr(depth), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r),
+                                                _lib.ptr(k), _lib.ptr(grad_depth), n, h, w, _lib.stream()),
+                   "endo_flow_from_depth_bwd")
+        return grad_depth, None, None, None, None
+
+
+class FlowfromDepthLayer(nn.Module):
+    """reference models.py:366-374: dense flow induced by depth + relative pose."""
+
+    def forward(self, x):
+        depth_maps_1, img_masks, translation_vectors, rotation_matrices, intrinsic_matrices = x
+        return _FlowFn.apply(depth_maps_1, img_masks, translation_vectors, rotation_matrices, intrinsic_matrices)
+
+
+class _WarpFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, d1, d2, mask, t, r, k, eps):
+        lib = _lib.load()
+        d1 = _lib.dev_f32(d1, "depth maps 1")
+        d2 = _lib.dev_f32(d2, "depth maps 2")
+        mask = _lib.dev_f32(mask, "image masks")
+        n, _, h, w = d1.shape
+        t, r, k = _pose(t, r, k, n)
+        warped = torch.empty_like(d1)
+        intersect = torch.empty_like(d1)
+        _lib.check(lib.endo_depth_warp_fwd(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r), _lib.ptr(k),
+                                           _lib.ptr(warped), _lib.ptr(intersect), n, h, w, eps, _lib.stream()),
+                   "endo_depth_warp_fwd")
+        ctx.save_for_backward(d1, d2, mask, t, r, k)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(intersect)
+        return warped, intersect
+
+    @staticmethod
+    def backward(ctx, grad_warped, _grad_intersect):
+        lib = _lib.load()
+        d1, d2, mask, t, r, k = ctx.saved_tensors
+        n, _, h, w = d1.shape
+        grad_warped = _lib.dev_f32(grad_warped, "grad")
+        g1 = torch.empty_like(d1)
+        g2 = torch.empty_like(d2)
+        _lib.check(lib.endo_depth_warp_bwd(_lib.ptr(grad_warped), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t),
+                                           _lib.ptr(r), _lib.ptr(k), _lib.ptr(g1), _lib.ptr(g2), n, h, w, ctx.eps,
+                                           _lib.stream()), "endo_depth_warp_bwd")
+        return g1, g2, None, None, None, None, None
+
+
+class DepthWarpingLayer(nn.Module):
+    """reference models.py:454-465: warp depth map 2 into frame 1 + binary intersection mask."""
+
+    def __init__(self, epsilon=1.0e-8):
+        super().__init__()
+        self.epsilon = float(epsilon)
+
+    def forward(self, x):
+        depth_maps_1, depth_maps_2, img_masks, translation_vectors, rotation_matrices, intrinsic_matrices = x
+        warped, intersect = _WarpFn.apply(depth_maps_1, depth_maps_2, img_masks, translation_vectors, rotation_matrices,
+                                          intrinsic_matrices, self.epsilon)
+        return warped, intersect

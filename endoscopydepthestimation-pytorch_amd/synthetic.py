@@ -30,7 +30,7 @@ def boundary_mask(height, width):
     xs = (np.arange(width, dtype=np.float64) + 0.5) / width - 0.5
     ay = np.abs(ys)[:, None]
     ax = np.abs(xs)[None, :]
-    inside = (ax <= 0.43) & (ay <= 0.43) & (ax + ay <= 0.665)
+    inside = (ax <= 0.41) & (ay <= 0.41) & (ax + ay <= 0.622)
     return inside.astype(np.float32)
 
 

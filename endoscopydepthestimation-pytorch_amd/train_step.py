@@ -1,0 +1,112 @@
+"""One training iteration on the MI355X path -- the counterpart of the batch-loop body of reference
+train.py:272-328, built from the drop-in modules of ``models`` / ``losses`` and the fused optimizer.
+
+  colours * boundary -> two network forwards (BN statistics per call, train.py:276-277) -> depth
+  scaling -> flow-from-depth both ways -> boundary masking -> sparse-flow loss -> depth warping
+  both ways -> depth-consistency loss -> weighted sum -> non-finite guard (agreed across ranks)
+  -> backward -> ONE gradient all-reduce -> fused clip_grad_norm_(10) + SGD(0.9).
+"""
+
+import math
+
+import torch
+
+from . import _lib, distributed, losses, models
+
+
+class _MaskMulFn(torch.autograd.Function):
+    """a[n,c,h,w] * mask[n,1,h,w] (train.py:272-273, 293-298); the mask carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, a, mask):
+        lib = _lib.load()
+        a = _lib.dev_f32(a, "tensor")
+        mask = _lib.dev_f32(mask, "mask")
+        n, c, h, w = a.shape
+        out = torch.empty_like(a)
+        _lib.check(lib.endo_mask_mul(_lib.ptr(a), _lib.ptr(mask), _lib.ptr(out), n, c, h * w, _lib.stream()), "endo_mask_mul")
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        lib = _lib.load()
+        (mask,) = ctx.saved_tensors
+        grad = _lib.dev_f32(grad, "grad")
+        n, c, h, w = grad.shape
+        out = torch.empty_like(grad)
+        _lib.check(lib.endo_mask_mul(_lib.ptr(grad), _lib.ptr(mask), _lib.ptr(out), n, c, h * w, _lib.stream()), "endo_mask_mul")
+        return out, None
+
+
+def mask_mul(a, mask):
+    return _MaskMulFn.apply(a, mask)
+
+
+class TrainingStep(object):
+    def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8):
+        self.model = model
+        self.optimizer = optimizer
+        self.sfl_weight = float(sfl_weight)
+        self.dcl_weight = float(dcl_weight)
+        self.depth_scaling_layer = models.DepthScalingLayer(epsilon=epsilon)
+        self.depth_warping_layer = models.DepthWarpingLayer(epsilon=epsilon)
+        self.flow_from_depth_layer = models.FlowfromDepthLayer()
+        self.sparse_flow_loss_function = losses.SparseMaskedL1Loss()
+        self.depth_consistency_loss_function = losses.NormalizedDistanceLoss(height=height, width=width)
+        self.bucket = distributed.GradientBucket(model.flat_gradients)
+
+    def losses(self, batch):
+        """Forward part: returns (loss, depth_consistency_loss, sparse_flow_loss, extras)."""
+        b = batch["boundaries"]
+        colors_1 = mask_mul(batch["colors_1"], b)
+        colors_2 = mask_mul(batch["colors_2"], b)
+        pred_1 = self.model(colors_1)
+        pred_2 = self.model(colors_2)
+        scaled_1, std_1 = self.depth_scaling_layer([pred_1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+        scaled_2, std_2 = self.depth_scaling_layer([pred_2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+        flows_1 = self.flow_from_depth_layer([scaled_1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],
+                                              batch["intrinsics"]])
+        flows_2 = self.flow_from_depth_layer([scaled_2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"],
+                                              batch["intrinsics"]])
+        with torch.no_grad():
+            sparse_flow_masks_1 = mask_mul(batch["sparse_flow_masks_1"], b)
+            sparse_flow_masks_2 = mask_mul(batch["sparse_flow_masks_2"], b)
+            sparse_flows_1 = mask_mul(batch["sparse_flows_1"], b)
+            sparse_flows_2 = mask_mul(batch["sparse_flows_2"], b)
+        flows_1 = mask_mul(flows_1, b)
+        flows_2 = mask_mul(flows_2, b)
+        sfl = self.sfl_weight * 0.5 * (
+            self.sparse_flow_loss_function([sparse_flows_1, flows_1, sparse_flow_masks_1]) +
+            self.sparse_flow_loss_function([sparse_flows_2, flows_2, sparse_flow_masks_2]))
+        warped_21, inter_1 = self.depth_warping_layer([scaled_1, scaled_2, b, batch["translations_1_wrt_2"],
+                                                       batch["rotations_1_wrt_2"], batch["intrinsics"]])
+        warped_12, inter_2 = self.depth_warping_layer([scaled_2, scaled_1, b, batch["translations_2_wrt_1"],
+                                                       batch["rotations_2_wrt_1"], batch["intrinsics"]])
+        dcl = self.dcl_weight * 0.5 * (
+            self.depth_consistency_loss_function([scaled_1, warped_21, inter_1, batch["intrinsics"]]) +
+            self.depth_consistency_loss_function([scaled_2, warped_12, inter_2, batch["intrinsics"]]))
+        extras = {"pred_1": pred_1, "pred_2": pred_2, "scaled_1": scaled_1, "scaled_2": scaled_2,
+                  "warped_21": warped_21, "warped_12": warped_12, "inter_1": inter_1, "inter_2": inter_2,
+                  "std_1": std_1, "std_2": std_2}
+        return dcl + sfl, dcl, sfl, extras
+
+    def __call__(self, batch, lr=None):
+        if lr is not None:
+            for group in self.optimizer.param_groups:
+                group["lr"] = lr
+        loss, dcl, sfl, _ = self.losses(batch)
+        value = loss.item()                       # the reference syncs here too (train.py:317)
+        bad = math.isnan(value) or math.isinf(value)
+        if distributed.world_size() > 1:
+            flag = torch.tensor([1.0 if bad else 0.0], device=loss.device)
+            bad = bool(distributed.agree_nonfinite(flag).item() > 0)
+        if bad:
+            # train.py:317-322 -- with torch >= 2.0 the guarded branch leaves parameters untouched
+            self.optimizer.zero_grad()
+            return {"loss": value, "dcl": float("nan"), "sfl": float("nan"), "skipped": True}
+        self.optimizer.zero_grad()
+        loss.backward()
+        scale = self.bucket.all_reduce()
+        norm = self.optimizer.step(grad_scale=scale)
+        return {"loss": value, "dcl": dcl, "sfl": sfl, "grad_norm": norm, "skipped": False}

@@ -1,0 +1,178 @@
+/*
+ * endo_hip.h -- C ABI of libendo_hip.so, the MI355X (gfx950) implementation of the training hot
+ * path of EndoscopyDepthEstimation-Pytorch.
+ *
+ * The reference has no native layer: its "operator interface" for this path is a set of
+ * torch.nn.Module classes whose forward() bottoms out in ATen kernels.  Each
+ * entry point below replaces the ATen op sequence behind one of those modules; the file:line it
+ * replaces is cited on every declaration.  The Python mirror of the reference's module API
+ * (endoscopydepthestimation-pytorch_amd/{models,losses}.py) binds these symbols with ctypes --
+ * INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous fp32 (or, where said, fp64 / u8 / i32) data on
+ *     the current HIP device; images are NCHW; hw = H*W
+ *   - the caller owns every buffer; the library keeps no pointer past the call (network handles
+ *     excepted: endo_net_create/destroy own their descriptor tables only, never activations)
+ *   - every call launches asynchronously on `stream` (a hipStream_t passed as void*), never
+ *     synchronises the device, and is re-entrant per stream
+ *   - return value: 0 = ok, > 0 = hipError_t, < 0 = argument error (ENDO_E_*)
+ *   - `stats` / `work` arguments are small fp64 device scratch arrays that the call zeroes itself;
+ *     the forward call's `stats` must be handed unchanged to the matching backward call
+ */
+#ifndef ENDO_HIP_H
+#define ENDO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ENDO_E_BADARG (-1)
+#define ENDO_E_UNSUPPORTED (-2)
+
+/* library identification: returns ABI version (bumped on any signature change) */
+int endo_abi_version(void);
+/* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
+const char* endo_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * DepthScalingLayer.forward -- reference models.py:346-363
+ * stats: n x 8 fp64  [sum sd*bin, sum bin, sum smap, sum above, sum smap^2, scale, std, -]
+ * ratio: 1 fp32 = mean over the (N x N) broadcast of std_j / scale_i (the reference divides a
+ *        (N,) tensor by a (N,1,1,1) tensor before torch.mean -- models.py:363)
+ * ------------------------------------------------------------------------------------------- */
+int endo_depth_scale_fwd(const float* pred, const float* sparse_depth, const float* sparse_mask,
+                         float* scaled, float* ratio, double* stats,
+                         int n, int hw, float eps, void* stream);
+/* grad_scaled / grad_ratio may be NULL (output unused); work: n fp64 */
+int endo_depth_scale_bwd(const float* grad_scaled, const float* grad_ratio,
+                         const float* pred, const float* sparse_depth, const double* stats,
+                         float* grad_pred, double* work,
+                         int n, int hw, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FlowfromDepthLayer.forward -- reference models.py:370-374 -> 433-451 -> 377-429
+ * t: n x 3, R: n x 9 (row major), K: n x 9; flow: n x 2 x H x W
+ * ------------------------------------------------------------------------------------------- */
+int endo_flow_from_depth_fwd(const float* depth, const float* mask, const float* t, const float* R,
+                             const float* K, float* flow, int n, int h, int w, void* stream);
+int endo_flow_from_depth_bwd(const float* grad_flow, const float* depth, const float* mask,
+                             const float* t, const float* R, const float* K, float* grad_depth,
+                             int n, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * DepthWarpingLayer.forward -- reference models.py:460-465 -> 469-554, sampler models.py:325-336
+ * (F.grid_sample bilinear / zeros / align_corners=False on the grid (2u/W-1, 2v/H-1))
+ * warped, intersect: n x 1 x H x W.  Backward: grad_d1 written, grad_d2 zeroed then scatter-added.
+ * ------------------------------------------------------------------------------------------- */
+int endo_depth_warp_fwd(const float* depth_1, const float* depth_2, const float* mask,
+                        const float* t, const float* R, const float* K,
+                        float* warped, float* intersect,
+                        int n, int h, int w, float eps, void* stream);
+int endo_depth_warp_bwd(const float* grad_warped, const float* depth_1, const float* depth_2,
+                        const float* mask, const float* t, const float* R, const float* K,
+                        float* grad_d1, float* grad_d2,
+                        int n, int h, int w, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * SparseMaskedL1Loss.forward -- reference losses.py:62-66
+ * flows, flows_hat: n x c x H x W; mask: n x 1 x H x W; stats: n x 2 fp64 [sum m|f-f^|, sum m]
+ * ------------------------------------------------------------------------------------------- */
+int endo_sparse_l1_fwd(const float* flows, const float* flows_hat, const float* mask,
+                       float* loss, double* stats, int n, int c, int hw, float eps, void* stream);
+/* grad_flows / grad_hat may be NULL when that input needs no gradient */
+int endo_sparse_l1_bwd(const float* grad_loss, const float* flows, const float* flows_hat,
+                       const float* mask, const double* stats, float* grad_flows, float* grad_hat,
+                       int n, int c, int hw, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * NormalizedDistanceLoss.forward -- reference losses.py:122-146
+ * stats: n x 4 fp64 [sum m*d, sum m, sum m|P-Pw|_1, sum m(d+|dw|)]
+ * ------------------------------------------------------------------------------------------- */
+int endo_norm_dist_fwd(const float* depth, const float* warped, const float* intersect,
+                       const float* K, float* loss, double* stats,
+                       int n, int h, int w, float eps, void* stream);
+int endo_norm_dist_bwd(const float* grad_loss, const float* depth, const float* warped,
+                       const float* intersect, const float* K, const double* stats,
+                       float* grad_depth, float* grad_warped,
+                       int n, int h, int w, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ScaleInvariantLoss.forward -- reference losses.py:22-32
+ * stats: n x 3 fp64 [sum r^2, sum r, sum b]
+ * ------------------------------------------------------------------------------------------- */
+int endo_scale_inv_fwd(const float* pred, const float* goal, const float* boundary,
+                       float* loss, double* stats, int n, int hw, float eps, void* stream);
+int endo_scale_inv_bwd(const float* grad_loss, const float* pred, const float* goal,
+                       const float* boundary, const double* stats,
+                       float* grad_pred, float* grad_goal, int n, int hw, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * train.py glue that is pure elementwise work between the modules
+ *   endo_mask_mul: out[n,c,hw] = a[n,c,hw] * mask[n,0,hw]   (train.py:272-273, 293-298)
+ * ------------------------------------------------------------------------------------------- */
+int endo_mask_mul(const float* a, const float* mask, float* out, int n, int c, int hw, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FCDenseNet57 -- reference models.py:100-194 (layers models.py:19-97)
+ *
+ * The network is driven through a handle that fixes (N, H, W) and owns only host-side launch
+ * tables.  Parameters, gradients, BN buffers, activations and gradient workspaces live in caller
+ * memory (torch tensors):
+ *   params     fp32, the 210 trainable tensors packed in the reference's .parameters() order
+ *   grads      fp32, same packing; endo_net_bwd ACCUMULATES into it (two forwards share one
+ *              backward accumulation per step, train.py:276-277, 325)
+ *   bn_running fp32, running_mean then running_var of the 49 BN layers in module order
+ *   tape       fp32 activation workspace of endo_net_tape_floats() elements, written by fwd and
+ *              read by bwd (one tape per forward call that will be differentiated)
+ *   gradws     fp32 gradient workspace of endo_net_gradws_floats() elements (scratch for bwd)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct endo_net endo_net;
+
+int endo_net_create(endo_net** out, int n, int h, int w);
+void endo_net_destroy(endo_net* net);
+int64_t endo_net_param_floats(void);                 /* 1 374 865 */
+int64_t endo_net_bn_floats(void);                    /* 2 * sum of BN widths */
+int64_t endo_net_tape_floats(const endo_net* net);
+int64_t endo_net_gradws_floats(const endo_net* net);
+/* offset (in floats) of the i-th trainable tensor inside params/grads, i in [0, 210) */
+int64_t endo_net_param_offset(int index);
+/* offset of running_mean / running_var of the i-th BN layer inside bn_running, i in [0, 49) */
+int64_t endo_net_bn_offset(int bn_index, int which /*0 mean, 1 var*/);
+
+/* x: n x 3 x H x W (already multiplied by the boundary, train.py:272-273); out: n x 1 x H x W >= 0.
+ * training != 0: batch statistics + running-stat update (momentum 0.1, eps 1e-5); 0: running stats.
+ * The tape is always required (it also holds the level buffers the forward pass works in). */
+int endo_net_fwd(endo_net* net, const float* params, float* bn_running, const float* x, float* out,
+                 float* tape, int training, void* stream);
+/* grad_out: n x 1 x H x W; x: the forward call's input.  Accumulates parameter gradients into grads.
+ * The tape must come from a endo_net_fwd call with the same params, x and training flag. */
+int endo_net_bwd(endo_net* net, const float* params, const float* x, const float* tape,
+                 const float* grad_out, float* grads, float* gradws, int training, void* stream);
+/* layout queries (tests inspect intermediate activations through these):
+ * channel count of level buffer `level` (0..5) and its offset (floats) inside the tape */
+int endo_net_level_channels(int level);
+int64_t endo_net_act_offset(const endo_net* net, int level);
+
+/* ---------------------------------------------------------------------------------------------
+ * clip_grad_norm_(params, max_norm) + SGD(momentum) -- reference train.py:327-328, 202
+ * grads are scaled in place by grad_scale (1/world after the all-reduce) and then by the clip
+ * coefficient min(1, max_norm / (norm + 1e-6)); momentum buf = mu * buf + g; p -= lr * buf.
+ * first_step != 0: buf = g.  norm_out: 2 fp64 [sum of squares, pre-clip global L2 norm], written by the call.
+ * ------------------------------------------------------------------------------------------- */
+int endo_sgd_clip_step(float* params, float* grads, float* momentum, double* norm_out,
+                       int64_t count, float lr, float mu, float max_norm, float grad_scale,
+                       int first_step, void* stream);
+
+/* live per-kernel-family timing for bench.py's roofline line (HIP events on the launch stream) */
+#define ENDO_PROF_FAMILIES 16
+int endo_prof_enable(int on);
+int endo_prof_read(int family, double* total_ms, int64_t* launches, double* total_flops, double* total_bytes);
+const char* endo_prof_family_name(int family);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENDO_HIP_H */

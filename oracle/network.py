@@ -132,18 +132,25 @@ def _dense_block(state, prefix, x, training, keep_input):
     return x if keep_input else torch.cat(new, dim=1)
 
 
-def forward(state, x, training=True):
+def forward(state, x, training=True, trace=None):
     """FCDenseNet.forward (models.py:171-187).  ``state`` running buffers are updated in place in
-    training mode, exactly as nn.BatchNorm2d does."""
+    training mode, exactly as nn.BatchNorm2d does.  ``trace`` (optional dict) receives the
+    intermediate maps: skip_L (down block L output), bott_in, bott_new, tu_L, upnew_L."""
     out = F.conv2d(x, state["firstconv.weight"], state["firstconv.bias"], padding=1)
     skips = []
     for i in range(LEVELS):
         out = _dense_block(state, "denseBlocksDown.%d" % i, out, training, keep_input=True)
         skips.append(out)
+        if trace is not None:
+            trace["skip_%d" % i] = out
         p = "transDownBlocks.%d" % i
         a = _bn_relu(state, p + ".norm", out, training)
         out = F.max_pool2d(F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"]), 2)
+    if trace is not None:
+        trace["bott_in"] = out
     out = _dense_block(state, "bottleneck.bottleneck", out, training, keep_input=False)
+    if trace is not None:
+        trace["bott_new"] = out
     for i in range(LEVELS):
         skip = skips.pop()
         p = "transUpBlocks.%d.convTrans.1" % i
@@ -152,8 +159,12 @@ def forward(state, x, training=True):
         dy = (up.shape[2] - skip.shape[2]) // 2
         dx = (up.shape[3] - skip.shape[3]) // 2
         up = up[:, :, dy:dy + skip.shape[2], dx:dx + skip.shape[3]]
+        if trace is not None:
+            trace["tu_%d" % (LEVELS - 1 - i)] = up
         out = torch.cat([up, skip], dim=1)
         out = _dense_block(state, "denseBlocksUp.%d" % i, out, training, keep_input=(i == LEVELS - 1))
+        if trace is not None:
+            trace["upnew_%d" % (LEVELS - 1 - i)] = out[:, -GROWTH * LAYERS_PER_BLOCK:]
     return torch.abs(F.conv2d(out, state["finalConv.weight"], state["finalConv.bias"]))
 
 

@@ -1,0 +1,137 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/endo_hip.h declares,
+and the host-side mirror of the reference interface (module tree, state-dict keys, parameter
+order, flat buffers, LR schedule, sharding) behaves.  No GPU compute is launched here."""
+
+import ctypes
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "endo_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(endo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(ea._lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    names = header_functions()
+    assert len(names) >= 30
+    raw = ctypes.CDLL(ea._lib.LIB_PATH)
+    for name in names:
+        assert hasattr(raw, name), "libendo_hip.so does not export %s" % name
+    assert sorted(ea._lib.SIGNATURES) == names, "ctypes table and header disagree"
+    lib = ea._lib.load()
+    assert lib.endo_abi_version() == 1
+    assert lib.endo_net_param_floats() == 1374865
+    assert lib.endo_net_bn_floats() == 21168
+    assert b"bad argument" in lib.endo_error_string(-1)
+    # argument validation happens before any device work
+    assert lib.endo_depth_scale_fwd(None, None, None, None, None, None, 1, 1, 1e-8, None) == -1
+    hnd = ctypes.c_void_p()
+    assert lib.endo_net_create(ctypes.byref(hnd), 1, 30, 32) == -2          # not a multiple of 32
+    assert lib.endo_net_create(ctypes.byref(hnd), 8, 256, 320) == 0
+    assert lib.endo_net_tape_floats(hnd) > 8 * 192 * 256 * 320
+    assert [lib.endo_net_level_channels(i) for i in range(6)] == [192, 240, 288, 336, 384, 336]
+    lib.endo_net_destroy(hnd)
+
+
+def test_module_tree_matches_reference_state_dict():
+    model = ea.FCDenseNet57(n_classes=1)
+    spec = onet.parameter_spec()
+    sd = model.state_dict()
+    assert list(sd.keys()) == [n for n, _, _ in spec]                       # 357 keys, reference order
+    for name, shape, _ in spec:
+        assert tuple(sd[name].shape) == tuple(shape), name
+    assert [n for n, _ in model.named_parameters()] == onet.trainable_names()  # 210, .parameters() order
+    lib = ea._lib.load()
+    assert [lib.endo_net_param_offset(i) for i in range(210)] == model._offsets
+    bn_off = 0
+    for i, m in enumerate(model._bns):
+        assert lib.endo_net_bn_offset(i, 0) == bn_off and lib.endo_net_bn_offset(i, 1) == bn_off + m.num_features
+        bn_off += 2 * m.num_features
+
+
+def test_flat_buffers_and_checkpoint_roundtrip(tmp_path):
+    state = onet.perturb_affine(onet.synthetic_state(3), 4)
+    model = ea.FCDenseNet57(1)
+    model.load_state_dict(state)
+    flat = model.flat_parameters()
+    want = torch.cat([state[n].reshape(-1) for n in onet.trainable_names()])
+    assert torch.equal(flat, want)
+    assert model._views_intact()
+    model.firstconv.weight.data.add_(1.0)                                   # views alias the flat buffer
+    assert torch.equal(flat[:1296], want[:1296] + 1.0)
+    grads = model.flat_gradients()
+    assert all(p.grad is not None and p.grad.data_ptr() == grads.data_ptr() + 4 * o
+               for p, o in zip(model.parameters(), model._offsets))
+    torch.optim.SGD(model.parameters(), lr=0.1).zero_grad()                 # set_to_none=True
+    assert model.firstconv.weight.grad is None
+    assert model.flat_gradients().abs().sum() == 0 and model.firstconv.weight.grad is not None
+    # reference wire format, 'module.'-prefixed keys (utils.py:674-682, train.py:197)
+    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9)
+    path = tmp_path / "checkpoint_model_epoch_1_validation_0.5.pt"
+    ea.utils.save_model(model, opt, 1, 10, path, 0.5)
+    blob = torch.load(str(path))
+    assert set(blob) == {"model", "optimizer", "epoch", "step", "validation"}
+    assert all(k.startswith("module.") for k in blob["model"])
+    other = ea.FCDenseNet57(1)
+    ea.utils.load_model_state(other, blob["model"])
+    assert torch.equal(other.flat_parameters(), model.flat_parameters())
+
+
+def test_no_cpu_fallback():
+    model = ea.FCDenseNet57(1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ea.DepthScalingLayer()([torch.ones(1, 1, 4, 4)] * 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ea.SparseMaskedL1Loss()([torch.ones(1, 2, 4, 4), torch.ones(1, 2, 4, 4), torch.ones(1, 1, 4, 4)])
+
+
+def test_cyclic_lr_matches_reference(golden):
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    for base, peak, size in ((1.0e-4, 1.0e-3, 2000), (1.0e-5, 6.0e-3, 7)):
+        opt = torch.optim.SGD([dummy], lr=peak, momentum=0.9)
+        sched = ea.scheduler.CyclicLR(opt, base_lr=base, max_lr=peak, step_size=size)
+        for b, p, s, step, lr in golden("cyclic_lr.npz")["table"]:
+            if (b, p, s) == (base, peak, size):
+                sched.batch_step(batch_iteration=int(step))
+                np.testing.assert_allclose(opt.param_groups[0]["lr"], lr, rtol=1e-12)
+    with pytest.raises(TypeError):
+        ea.scheduler.CyclicLR(object())
+
+
+def test_kaiming_init_and_synthetic_batch():
+    model = ea.FCDenseNet57(1)
+    torch.manual_seed(10085)
+    ea.utils.kaiming_weight_zero_bias(model, distribution="normal")
+    w = model.denseBlocksUp[4].layers[3].conv.weight
+    assert abs(float(w.std()) - (2.0 / (180 * 9)) ** 0.5) < 0.1 * (2.0 / (180 * 9)) ** 0.5
+    assert float(model.finalConv.bias.abs().sum()) == 0 and float(model.transDownBlocks[0].norm.weight.min()) == 1
+    batch = ea.synthetic.make_batch(2, 64, 96, seed=1)
+    assert set(batch) == set(ea.synthetic.BATCH_KEYS)
+    assert batch["colors_1"].shape == (2, 3, 64, 96) and batch["sparse_flows_2"].shape == (2, 2, 64, 96)
+    assert 0.5 < float(ea.synthetic.boundary_mask(256, 320).mean()) < 0.65
+    assert int(batch["sparse_depth_masks_1"][0].sum()) == 500
+    r = batch["rotations_1_wrt_2"][0]
+    assert torch.allclose(r @ batch["rotations_2_wrt_1"][0], torch.eye(3), atol=1e-6)
+
+
+def test_shard_range():
+    assert ea.distributed.shard_range(64, 3, 8) == (24, 32)
+    with pytest.raises(ValueError):
+        ea.distributed.shard_range(10, 0, 4)

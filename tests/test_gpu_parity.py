@@ -1,0 +1,448 @@
+"""Parity of the HIP path (through the C ABI, via the drop-in modules) against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE.json's full size --
+through size-independent properties.  Tolerance: BASELINE.json north_star = 1e-4 relative (fp32);
+each assert states the tolerance it uses.  Run with ``pytest -m gpu`` on an MI355X."""
+
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import geometry as ogeo, losses as olos, network as onet, schedule as osch, train_step as ostep
+
+pytestmark = pytest.mark.gpu
+
+ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+synthetic = ea.synthetic
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def rel_err(got, want):
+    got = got.detach().double().cpu()
+    want = want.detach().double().cpu()
+    scale = max(float(want.abs().max()), 1e-30)
+    return float((got - want).abs().max()) / scale
+
+
+def assert_close(got, want, tol, what):
+    err = rel_err(got, want)
+    assert err <= tol, "%s: max abs err / max |ref| = %.3e > %.1e" % (what, err, tol)
+
+
+def geometry_inputs(n, h, w, seed):
+    batch = synthetic.make_batch(n, h, w, seed=seed, sparse_points=min(500, h * w // 6))
+    p1 = synthetic.smooth_depth(n, h, w, seed=seed + 100)
+    p2 = synthetic.smooth_depth(n, h, w, seed=seed + 200)
+    goal = synthetic.smooth_depth(n, h, w, seed=seed + 300)
+    return batch, p1, p2, goal
+
+
+def to_dev(d):
+    return {k: v.to(dev()) for k, v in d.items()}
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry layers and losses, forward + backward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 16, 20), (3, 64, 96), (1, 256, 320), (2, 37, 53)])
+def test_depth_scaling(shape):
+    n, h, w = shape
+    batch, p1, _, _ = geometry_inputs(n, h, w, 41)
+    cot = torch.from_numpy(np.random.default_rng(1).standard_normal((n, 1, h, w)).astype(np.float32))
+    pc = p1.clone().requires_grad_(True)
+    s_ref, r_ref = ogeo.depth_scaling(pc, batch["sparse_depths_1"], batch["sparse_depth_masks_1"])
+    ((s_ref * cot).sum() + 3.0 * r_ref).backward()
+    pg = p1.to(dev()).requires_grad_(True)
+    s, r = ea.DepthScalingLayer(epsilon=1.0e-8)([pg, batch["sparse_depths_1"].to(dev()), batch["sparse_depth_masks_1"].to(dev())])
+    ((s * cot.to(dev())).sum() + 3.0 * r).backward()
+    assert_close(s, s_ref, 1e-5, "scaled depth")
+    assert_close(r, r_ref, 1e-4, "scale std/mean ratio")
+    assert_close(pg.grad, pc.grad, 1e-4, "grad pred")
+    # only the scaled output used (the training path): grad_ratio is None
+    pg2 = p1.to(dev()).requires_grad_(True)
+    s2, _ = ea.DepthScalingLayer()([pg2, batch["sparse_depths_1"].to(dev()), batch["sparse_depth_masks_1"].to(dev())])
+    (s2 * cot.to(dev())).sum().backward()
+    pc2 = p1.clone().requires_grad_(True)
+    s_ref2, _ = ogeo.depth_scaling(pc2, batch["sparse_depths_1"], batch["sparse_depth_masks_1"])
+    (s_ref2 * cot).sum().backward()
+    assert_close(pg2.grad, pc2.grad, 1e-4, "grad pred (scaled only)")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 20), (3, 64, 96), (1, 256, 320), (2, 37, 53)])
+def test_flow_from_depth(shape):
+    n, h, w = shape
+    batch, p1, _, _ = geometry_inputs(n, h, w, 42)
+    cot = torch.from_numpy(np.random.default_rng(2).standard_normal((n, 2, h, w)).astype(np.float32))
+    args = [batch["boundaries"], batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]]
+    dc = p1.clone().requires_grad_(True)
+    f_ref = ogeo.flow_from_depth(dc, *args)
+    (f_ref * cot).sum().backward()
+    dg = p1.to(dev()).requires_grad_(True)
+    f = ea.FlowfromDepthLayer()([dg] + [a.to(dev()) for a in args])
+    (f * cot.to(dev())).sum().backward()
+    assert_close(f, f_ref, 1e-5, "flow")
+    assert_close(dg.grad, dc.grad, 1e-4, "grad depth")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 20), (3, 64, 96), (1, 256, 320), (2, 37, 53)])
+def test_depth_warping(shape):
+    n, h, w = shape
+    batch, p1, p2, _ = geometry_inputs(n, h, w, 43)
+    cot = torch.from_numpy(np.random.default_rng(3).standard_normal((n, 1, h, w)).astype(np.float32))
+    args = [batch["boundaries"], batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]]
+    c1 = p1.clone().requires_grad_(True)
+    c2 = p2.clone().requires_grad_(True)
+    w_ref, overlap = ogeo.depth_warping_parts(c1, c2, *args)
+    (w_ref * cot).sum().backward()
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    warped, inter = ea.DepthWarpingLayer(epsilon=1.0e-8)([g1, g2] + [a.to(dev()) for a in args])
+    (warped * cot.to(dev())).sum().backward()
+    assert_close(warped, w_ref, 1e-5, "warped depth")
+    assert_close(g1.grad, c1.grad, 1e-4, "grad depth 1")
+    assert_close(g2.grad, c2.grad, 1e-4, "grad depth 2")
+    # the intersect mask is a threshold at 0.9: compare away from numerically borderline pixels
+    clear = (overlap.detach() - 0.9).abs() > 1e-5
+    want = (overlap.detach() >= 0.9).float()
+    assert torch.equal(inter.cpu()[clear], want[clear]), "intersect mask"
+    assert not inter.requires_grad
+
+
+def test_warp_edge_cases():
+    """Masked-out pixels (eps division), points behind the camera, out-of-frame samples."""
+    n, h, w = 2, 24, 32
+    batch, p1, p2, _ = geometry_inputs(n, h, w, 44)
+    t = batch["translations_1_wrt_2"].clone()
+    t[0, 2, 0] = 2.0      # pushes z2 <= 0 for sample 0 (depth ~0.3-0.9): the where(z>0) branch
+    t[1, 0, 0] = 0.8      # large lateral motion: most samples fall outside the frame
+    args = [batch["boundaries"], t, batch["rotations_1_wrt_2"], batch["intrinsics"]]
+    cot = torch.ones(n, 1, h, w)
+    c1 = p1.clone().requires_grad_(True)
+    c2 = p2.clone().requires_grad_(True)
+    w_ref, overlap = ogeo.depth_warping_parts(c1, c2, *args)
+    (w_ref * cot).sum().backward()
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    warped, inter = ea.DepthWarpingLayer()([g1, g2] + [a.to(dev()) for a in args])
+    (warped * cot.to(dev())).sum().backward()
+    assert torch.isfinite(warped).all()
+    assert_close(warped, w_ref, 1e-5, "warped (edge cases)")
+    assert_close(g1.grad, c1.grad, 1e-4, "grad d1 (edge cases)")
+    assert_close(g2.grad, c2.grad, 1e-4, "grad d2 (edge cases)")
+    f_ref = ogeo.flow_from_depth(p1, *args)
+    f = ea.FlowfromDepthLayer()([p1.to(dev())] + [a.to(dev()) for a in args])
+    finite = torch.isfinite(f_ref)
+    assert torch.equal(torch.isfinite(f.cpu()), finite)            # the flow layer may emit inf/nan; so must we
+    assert_close(torch.where(finite, f.cpu(), torch.zeros_like(f_ref)).clamp(-1e6, 1e6),
+                 torch.where(finite, f_ref, torch.zeros_like(f_ref)).clamp(-1e6, 1e6), 1e-4, "flow (edge cases)")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 20), (3, 64, 96), (1, 256, 320)])
+def test_losses(shape):
+    n, h, w = shape
+    batch, p1, p2, goal = geometry_inputs(n, h, w, 45)
+    b = batch["boundaries"]
+    rng = np.random.default_rng(4)
+    hat = torch.from_numpy(rng.normal(0, 0.03, (n, 2, h, w)).astype(np.float32))
+    inter = (torch.from_numpy(rng.uniform(0, 1, (n, 1, h, w)).astype(np.float32)) > 0.3).float() * b
+    # sparse flow loss
+    hc = hat.clone().requires_grad_(True)
+    l_ref = olos.sparse_masked_l1(batch["sparse_flows_1"], hc, batch["sparse_flow_masks_1"])
+    l_ref.backward()
+    hg = hat.to(dev()).requires_grad_(True)
+    loss = ea.SparseMaskedL1Loss()([batch["sparse_flows_1"].to(dev()), hg, batch["sparse_flow_masks_1"].to(dev())])
+    loss.backward()
+    assert_close(loss, l_ref, 1e-5, "sparse flow loss")
+    assert_close(hg.grad, hc.grad, 1e-5, "sparse flow loss grad")
+    # depth consistency loss
+    c1 = p1.clone().requires_grad_(True)
+    c2 = p2.clone().requires_grad_(True)
+    l_ref = olos.normalized_distance(c1, c2, inter, batch["intrinsics"])
+    l_ref.backward()
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    loss = ea.NormalizedDistanceLoss(height=h, width=w)([g1, g2, inter.to(dev()), batch["intrinsics"].to(dev())])
+    loss.backward()
+    assert_close(loss, l_ref, 1e-5, "depth consistency loss")
+    assert_close(g1.grad, c1.grad, 1e-4, "dcl grad depth")
+    assert_close(g2.grad, c2.grad, 1e-4, "dcl grad warped")
+    # scale invariant loss
+    c1 = p1.clone().requires_grad_(True)
+    l_ref = olos.scale_invariant(c1, goal, b)
+    l_ref.backward()
+    g1 = p1.to(dev()).requires_grad_(True)
+    loss = ea.ScaleInvariantLoss(epsilon=1.0e-8)([g1, goal.to(dev()), b.to(dev())])
+    loss.backward()
+    assert_close(loss, l_ref, 2e-5, "scale invariant loss")
+    assert_close(g1.grad, c1.grad, 1e-4, "scale invariant grad")
+
+
+def test_geometry_golden(golden):
+    """HIP geometry + losses against the fixture the REFERENCE produced (tests/golden/make_golden.py)."""
+    g = golden("geometry_3x64x96.npz")
+    n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
+    batch, p1, p2, goal = geometry_inputs(n, h, w, seed)
+    batch = to_dev(batch)
+    p1 = p1.to(dev()).requires_grad_(True)
+    p2 = p2.to(dev()).requires_grad_(True)
+    b = batch["boundaries"]
+    scaling, flow_layer, warp_layer = ea.DepthScalingLayer(), ea.FlowfromDepthLayer(), ea.DepthWarpingLayer()
+    s1, std1 = scaling([p1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    s2, std2 = scaling([p2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+    f1 = flow_layer([s1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
+    f2 = flow_layer([s2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]])
+    sfl_fn, dcl_fn, sil_fn = ea.SparseMaskedL1Loss(), ea.NormalizedDistanceLoss(h, w), ea.ScaleInvariantLoss()
+    sfl = 0.5 * (sfl_fn([batch["sparse_flows_1"] * b, f1 * b, batch["sparse_flow_masks_1"] * b]) +
+                 sfl_fn([batch["sparse_flows_2"] * b, f2 * b, batch["sparse_flow_masks_2"] * b]))
+    w21, i1 = warp_layer([s1, s2, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
+    w12, i2 = warp_layer([s2, s1, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]])
+    dcl = 0.5 * (dcl_fn([s1, w21, i1, batch["intrinsics"]]) + dcl_fn([s2, w12, i2, batch["intrinsics"]]))
+    sil = sil_fn([p1, goal.to(dev()), b])
+    total = 20.0 * sfl + 0.1 * dcl + 0.3 * sil + 0.05 * (std1 + std2)
+    total.backward()
+    for key, val in (("sfl", sfl), ("dcl", dcl), ("sil", sil), ("total", total), ("std_1", std1)):
+        assert_close(val, torch.from_numpy(g[key]), 1e-4, key)
+    for key, val in (("scaled_1", s1), ("flow_1", f1), ("flow_2", f2), ("warped_21", w21), ("warped_12", w12),
+                     ("grad_pred_1", p1.grad), ("grad_pred_2", p2.grad)):
+        assert_close(val, torch.from_numpy(g[key]), 1e-4, key)
+    assert float((i1.cpu() != torch.from_numpy(g["inter_1"])).float().mean()) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# network
+# ---------------------------------------------------------------------------------------------
+def make_model(seed):
+    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    model = ea.FCDenseNet57(n_classes=1)
+    missing = model.load_state_dict(state)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return state, model.to(dev())
+
+
+def level_reference(trace, level):
+    """Assemble the oracle's view of level buffer `level` (layout: DESIGN.md / net.hip header)."""
+    if level == 5:
+        return torch.cat([trace["bott_in"], trace["bott_new"]], dim=1)
+    return torch.cat([trace["tu_%d" % level], trace["skip_%d" % level], trace["upnew_%d" % level]], dim=1)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (2, 64, 96), (1, 128, 160)])
+def test_network_forward_levels(shape):
+    n, h, w = shape
+    state, model = make_model(51)
+    x = torch.from_numpy(np.random.default_rng(5).uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    trace = {}
+    y_ref = onet.forward(state, x, training=True, trace=trace)
+    model.train()
+    with torch.no_grad():
+        y, levels = model.level_buffers(x.to(dev()))
+    for lvl in (0, 1, 2, 3, 4, 5):
+        ref = level_reference(trace, lvl)
+        got = levels[lvl].cpu()
+        # report the first channel block that disagrees (localises a faulty layer)
+        for c0 in range(0, ref.shape[1], 12):
+            err = rel_err(got[:, c0:c0 + 12], ref[:, c0:c0 + 12])
+            assert err <= 1e-4, "level %d channels [%d,%d): rel err %.3e" % (lvl, c0, c0 + 12, err)
+    assert_close(y, y_ref, 1e-4, "network output")
+    sd = model.state_dict()
+    for name in ("denseBlocksDown.0.layers.0.norm", "transDownBlocks.2.norm", "bottleneck.bottleneck.layers.3.norm",
+                 "denseBlocksUp.4.layers.3.norm"):
+        assert_close(sd[name + ".running_mean"], state[name + ".running_mean"], 1e-4, name + ".running_mean")
+        assert_close(sd[name + ".running_var"], state[name + ".running_var"], 1e-4, name + ".running_var")
+        assert int(sd[name + ".num_batches_tracked"]) == 1
+    model.eval()
+    with torch.no_grad():
+        y_eval = model(x.to(dev()))
+        assert_close(y_eval, onet.forward(state, x, training=False), 1e-4, "eval-mode output")
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32), (2, 64, 96)])
+def test_network_backward(shape):
+    n, h, w = shape
+    state, model = make_model(52)
+    rng = np.random.default_rng(6)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    names = onet.trainable_names()
+    for nm in names:
+        state[nm].requires_grad_(True)
+    y_ref = onet.forward(state, x, training=True)
+    grads_ref = torch.autograd.grad((y_ref * cot).sum(), [state[nm] for nm in names])
+    model.train()
+    y = model(x.to(dev()))
+    (y * cot.to(dev())).sum().backward()
+    params = dict(model.named_parameters())
+    worst = []
+    for nm, gr in zip(names, grads_ref):
+        got = params[nm].grad
+        assert got is not None, nm
+        worst.append((rel_err(got, gr), nm))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, "parameter gradients, worst offenders: %s" % (worst[:8],)
+    flat_ref = torch.cat([g.reshape(-1) for g in grads_ref])
+    assert_close(model.flat_gradients(), flat_ref, 1e-3, "flat gradient vector")
+    # two backward passes accumulate (train.py:276-277 runs the network twice per step)
+    y = model(x.to(dev()))
+    (y * cot.to(dev())).sum().backward()
+    assert_close(model.flat_gradients(), 2.0 * flat_ref, 1e-3, "accumulated gradient")
+
+
+def test_network_golden(golden):
+    """HIP network against the fixture produced by the REFERENCE FCDenseNet57."""
+    g = golden("network_2x64x96.npz")
+    n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
+    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    model = ea.FCDenseNet57(1)
+    model.load_state_dict(state)
+    model = model.to(dev()).train()
+    rng = np.random.default_rng(seed + 2)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)).to(dev())
+    cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)).to(dev())
+    y = model(x)
+    assert_close(y, torch.from_numpy(g["output"]), 1e-4, "output vs reference fixture")
+    (y * cot).sum().backward()
+    params = dict(model.named_parameters())
+    names = [str(s) for s in g["grad_names"]]
+    assert [nm for nm, _ in model.named_parameters()] == names
+    norms = np.array([float(params[nm].grad.double().norm()) for nm in names])
+    np.testing.assert_allclose(norms, g["grad_norms"], rtol=3e-3, atol=1e-5 * float(g["grad_norms"].max()))
+    for key in g.files:
+        if key.startswith("grad::"):
+            assert_close(params[key[6:]].grad, torch.from_numpy(g[key]), 3e-3, key)
+        if key.startswith("buf::"):
+            assert_close(model.state_dict()[key[5:]], torch.from_numpy(g[key]), 1e-4, key)
+
+
+def test_optimizer_step():
+    model = ea.FCDenseNet57(1).to(dev())
+    ea.utils.kaiming_weight_zero_bias(model, distribution="normal")
+    opt = ea.optim.FusedClipSGD(model, lr=0.01, momentum=0.9, max_norm=10.0)
+    rng = np.random.default_rng(7)
+    p_ref = [p.detach().cpu().clone() for p in model.parameters()]
+    bufs = [None] * len(p_ref)
+    for step, scale in enumerate((5.0, 0.001, 1.0)):       # clipped, not clipped, in between
+        flat = model.flat_gradients()
+        gnp = (rng.standard_normal(flat.numel()) * scale).astype(np.float32)
+        flat.copy_(torch.from_numpy(gnp))
+        g_ref = []
+        off = 0
+        for p in p_ref:
+            g_ref.append(torch.from_numpy(gnp[off:off + p.numel()].copy()).view(p.shape))
+            off += p.numel()
+        norm = opt.step()
+        want = osch.clip_and_sgd(p_ref, g_ref, bufs, 0.01)
+        assert_close(norm, want, 1e-5, "gradient norm step %d" % step)
+        got = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        assert_close(got, torch.cat([p.reshape(-1) for p in p_ref]), 1e-5, "parameters after step %d" % step)
+
+
+def test_train_step_vs_oracle():
+    n, h, w = 2, 64, 96
+    state, model = make_model(53)
+    model.train()
+    opt = ea.optim.FusedClipSGD(model, lr=1.0e-3)
+    step = ea.train_step.TrainingStep(model, opt, h, w, sfl_weight=20.0, dcl_weight=0.1)
+    momentum = {}
+    for it in range(2):
+        batch = synthetic.make_batch(n, h, w, seed=60 + it, sparse_points=500)
+        lr = osch.cyclic_lr(it, 1.0e-4, 1.0e-3, 4)
+        out = step(to_dev(batch), lr=lr)
+        ref = ostep.train_iteration(state, momentum, batch, lr)
+        assert not out["skipped"] and not ref["skipped"]
+        assert abs(out["loss"] - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"])), (it, out["loss"], float(ref["loss"]))
+        assert_close(out["dcl"], ref["dcl"], 1e-4, "dcl")
+        assert_close(out["sfl"], ref["sfl"], 1e-4, "sfl")
+        assert_close(out["grad_norm"], ref["grad_norm"], 2e-3, "grad norm")
+        got = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        want = torch.cat([state[nm].reshape(-1) for nm in onet.trainable_names()])
+        assert_close(got, want, 1e-4, "parameters after iteration %d" % it)
+
+
+def test_train_step_golden(golden):
+    g = golden("train_step_2x64x96.npz")
+    n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
+    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    model = ea.FCDenseNet57(1)
+    model.load_state_dict(state)
+    model = model.to(dev()).train()
+    opt = ea.optim.FusedClipSGD(model, lr=float(g["max_lr"]))
+    sched = ea.scheduler.CyclicLR(opt, base_lr=float(g["base_lr"]), max_lr=float(g["max_lr"]), step_size=int(g["step_size"]))
+    step = ea.train_step.TrainingStep(model, opt, h, w)
+    for it in range(2):
+        batch = synthetic.make_batch(n, h, w, seed=seed + 10 + it, sparse_points=min(500, h * w // 6))
+        sched.batch_step(batch_iteration=it)
+        out = step(to_dev(batch))
+        tag = "step%d_" % it
+        assert abs(out["loss"] - float(g[tag + "loss"])) <= 2e-4 * abs(float(g[tag + "loss"]))
+        assert_close(out["grad_norm"], torch.from_numpy(g[tag + "grad_norm"]), 3e-3, "grad norm")
+        norms = np.array([float(p.double().norm()) for p in model.parameters()])
+        np.testing.assert_allclose(norms, g[tag + "param_norms"], rtol=1e-4, atol=1e-5)
+
+
+def test_nonfinite_guard():
+    n, h, w = 1, 32, 32
+    _, model = make_model(54)
+    model.train()
+    opt = ea.optim.FusedClipSGD(model, lr=1.0e-3)
+    step = ea.train_step.TrainingStep(model, opt, h, w)
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=70, sparse_points=100))
+    batch["sparse_flows_1"][0, 0, 5, 5] = float("nan")
+    batch["sparse_flow_masks_1"][0, 0, 5, 5] = 1.0
+    batch["boundaries"][0, 0, 5, 5] = 1.0
+    before = model.flat_parameters().clone()
+    out = step(batch, lr=1.0e-3)
+    assert out["skipped"]
+    assert torch.equal(before, model.flat_parameters())
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json config 2: N = 8, 256 x 320)
+# ---------------------------------------------------------------------------------------------
+def test_full_size_properties():
+    n, h, w = 8, 256, 320
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=80))
+    b = batch["boundaries"]
+    eye = torch.eye(3, device=dev()).expand(n, 3, 3).contiguous()
+    zero_t = torch.zeros(n, 3, 1, device=dev())
+    d = synthetic.smooth_depth(n, h, w, seed=81).to(dev())
+    ones = torch.ones_like(d)
+    # identity pose: zero flow; warp = half-pixel-shifted bilinear resample; mask zero on row/col 0
+    flow = ea.FlowfromDepthLayer()([d, ones, zero_t, eye, batch["intrinsics"]])
+    assert float(flow.abs().max()) < 1e-5
+    warped, inter = ea.DepthWarpingLayer()([d, d, ones, zero_t, eye, batch["intrinsics"]])
+    assert float(inter[:, :, 0, :].sum()) == 0 and float(inter[:, :, :, 0].sum()) == 0
+    assert float(inter[:, :, 1:, 1:].min()) == 1
+    want = 0.25 * (d[:, :, 1:, 1:] + d[:, :, :-1, 1:] + d[:, :, 1:, :-1] + d[:, :, :-1, :-1])
+    assert_close(warped[:, :, 1:, 1:], want, 1e-5, "identity warp")
+    # depth scaling is invariant to the scale of the prediction
+    s1, _ = ea.DepthScalingLayer()([d, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    s2, _ = ea.DepthScalingLayer()([3.0 * d, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    assert_close(s2, s1, 1e-5, "scale invariance of depth scaling")
+    # losses: zero for identical inputs, per-sample means (shard property used by data parallelism)
+    dcl = ea.NormalizedDistanceLoss(h, w)
+    assert float(dcl([d, d, b, batch["intrinsics"]])) == 0.0
+    full = dcl([d, 1.1 * d, b, batch["intrinsics"]])
+    halves = 0.5 * (dcl([d[:4], 1.1 * d[:4], b[:4], batch["intrinsics"][:4]]) +
+                    dcl([d[4:], 1.1 * d[4:], b[4:], batch["intrinsics"][4:]]))
+    assert_close(full, halves, 1e-5, "mean of shard means")
+    # network: output non-negative, gradient linear in the cotangent, BN batch statistics per call
+    _, model = make_model(55)
+    model.train()
+    x = (batch["colors_1"] * b)
+    y = model(x)
+    assert y.shape == (n, 1, h, w) and float(y.min()) >= 0.0 and torch.isfinite(y).all()
+    cot = torch.randn(n, 1, h, w, device=dev(), generator=torch.Generator(device=dev()).manual_seed(1))
+    opt = ea.optim.FusedClipSGD(model, lr=0.0)
+    opt.zero_grad()
+    (y * cot).sum().backward()
+    g1 = model.flat_gradients().clone()
+    opt.zero_grad()
+    y = model(x)
+    (y * (2.0 * cot)).sum().backward()
+    assert_close(model.flat_gradients(), 2.0 * g1, 1e-3, "gradient linearity at full size")
+    assert torch.isfinite(g1).all()
