@@ -123,7 +123,9 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
 
     // ---------------- prologue: per-channel constants ----------------
     if constexpr (IN == IN_BNRELU) {
-        // s_aux[c] = scale, s_aux[kMaxBnChannels + c] = shift
+        // s_aux[c] = scale (gamma * rstd), s_aux[kMax + c] = mean, s_aux[2 kMax + c] = beta.
+        // z = (x - mean) * scale + beta: subtracting the mean FIRST keeps z accurate near zero, so the
+        // ReLU mask (and hence every gradient) flips no more often than in the reference's fp32 path.
         for (int c = tid; c < p.cin; c += kConvThreads) {
             double mean, var;
             if (p.training) {
@@ -137,7 +139,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
             const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
             const float scale = p.gamma[c] * static_cast<float>(rstd);
             s_aux[c] = scale;
-            s_aux[kMaxBnChannels + c] = p.beta[c] - static_cast<float>(mean) * scale;
+            s_aux[kMaxBnChannels + c] = static_cast<float>(mean);
+            s_aux[2 * kMaxBnChannels + c] = p.beta[c];
             if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
                 if (p.saved) {
                     p.saved[2 * c] = static_cast<float>(mean);
@@ -152,18 +155,18 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
         }
     }
     if constexpr (EPI == EPI_DGRAD_BN) {
-        // per output channel of this block: scale, shift, mean, rstd at s_aux[2*kMax + 4*j ..]
-        float* cst = s_aux + 2 * kMaxBnChannels;
+        // per output channel of this block: scale, beta, mean, rstd at s_aux[3*kMax + 4*j ..]
+        float* cst = s_aux + 3 * kMaxBnChannels;
         if (tid < NB) {
             const int c = co_base + tid;
-            float mean = 0.f, rstd = 0.f, scale = 0.f, shift = 0.f;
+            float mean = 0.f, rstd = 0.f, scale = 0.f, beta = 0.f;
             if (c < p.cout) {
                 mean = p.bn_saved[2 * c];
                 rstd = p.bn_saved[2 * c + 1];
                 scale = p.bn_gamma[c] * rstd;
-                shift = p.bn_beta[c] - mean * scale;
+                beta = p.bn_beta[c];
             }
-            cst[4 * tid] = scale; cst[4 * tid + 1] = shift; cst[4 * tid + 2] = mean; cst[4 * tid + 3] = rstd;
+            cst[4 * tid] = scale; cst[4 * tid + 1] = beta; cst[4 * tid + 2] = mean; cst[4 * tid + 3] = rstd;
         }
     }
 
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
                     if constexpr (IN == IN_BNRELU) {
                         const int ch = c_base + c;
                         if (ch < p.cin && (pos_ok & (1u << k))) {
-                            v = fmaf(v, s_aux[ch], s_aux[kMaxBnChannels + ch]);
+                            v = fmaf(v - s_aux[kMaxBnChannels + ch], s_aux[ch], s_aux[2 * kMaxBnChannels + ch]);
                             v = v > 0.f ? v : 0.f;
                         } else {
                             v = 0.f;
@@ -322,7 +325,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
     const bool vec_ok = ((p.out_w & 3) == 0) && ((p.w & 3) == 0);
 
     if constexpr (EPI == EPI_FWD) {
-        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;   // [4 waves][NB][2]
+        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;   // [4 waves][NB][2]
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int co = co_base + q * 16 + li;
@@ -368,7 +371,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
             }
         }
     } else if constexpr (EPI == EPI_FWD_POOL) {
-        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;
+        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;
         const int ph = p.h >> 1, pw = p.w >> 1;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
@@ -415,14 +418,14 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
             }
         }
     } else if constexpr (EPI == EPI_DGRAD_BN) {
-        const float* cst = s_aux + 2 * kMaxBnChannels;
-        float* s_red = s_aux + 2 * kMaxBnChannels + 4 * NB;
+        const float* cst = s_aux + 3 * kMaxBnChannels;
+        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
             const int jloc = q * 16 + li;
             const int co = co_base + jloc;
             const bool co_ok = co < p.cout;
-            const float scale = cst[4 * jloc], shift = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
+            const float scale = cst[4 * jloc], beta = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
             const bool accumulate = co >= p.acc_from;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -436,10 +439,11 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
                         f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float z = fmaf(xv[e], scale, shift);
+                            const float xc = xv[e] - mean;
+                            const float z = fmaf(xc, scale, beta);
                             const float dz = z > 0.f ? acc[r][q][e] : 0.f;
                             s1 += dz;
-                            s2 += dz * ((xv[e] - mean) * rstd);
+                            s2 += dz * (xc * rstd);
                             o[e] += scale * dz;
                         }
                         *reinterpret_cast<f32x4*>(dst) = o;
@@ -448,10 +452,11 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
                         for (int e = 0; e < 4; ++e) {
                             if (px + e < p.w) {
                                 const float xv = p.x[xo + e];
-                                const float z = fmaf(xv, scale, shift);
+                                const float xc = xv - mean;
+                                const float z = fmaf(xc, scale, beta);
                                 const float dz = z > 0.f ? acc[r][q][e] : 0.f;
                                 s1 += dz;
-                                s2 += dz * ((xv - mean) * rstd);
+                                s2 += dz * (xc * rstd);
                                 dst[e] = (accumulate ? dst[e] : 0.f) + scale * dz;
                             }
                         }
@@ -498,7 +503,7 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
 
 template <int KS, int KC, int Q>
 constexpr size_t conv_smem_bytes() {
-    return sizeof(float) * (KC * ConvGeom<KS, KC>::kCS + KS * KS * KC * 16 * Q + 2 * kMaxBnChannels + 4 * 16 * Q + 4 * 16 * Q * 2);
+    return sizeof(float) * (KC * ConvGeom<KS, KC>::kCS + KS * KS * KC * 16 * Q + 3 * kMaxBnChannels + 4 * 16 * Q + 4 * 16 * Q * 2);
 }
 
 template <int KS, int KC, int Q, int IN, int EPI>

@@ -15,10 +15,10 @@ struct ProfSlot {
 
 static std::mutex g_prof_mutex;
 static std::deque<ProfSlot> g_prof_slots;
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;   // bit f set = time family f
 
 ProfScope::ProfScope(int family_, hipStream_t stream_, double flops, double bytes) : family(family_), stream(stream_), slot(nullptr) {
-    if (!g_prof_on) return;
+    if (!((g_prof_mask >> family_) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     ProfSlot s;
     s.family = family_;
@@ -62,10 +62,10 @@ extern "C" const char* endo_error_string(int code) {
     return "endo: unknown error";
 }
 
-extern "C" int endo_prof_enable(int on) {
+extern "C" int endo_prof_enable(int family_mask) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     prof_clear();
-    g_prof_on = on != 0;
+    g_prof_mask = static_cast<unsigned>(family_mask);
     return 0;
 }
 

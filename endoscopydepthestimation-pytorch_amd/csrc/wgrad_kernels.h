@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                        // [16][kCS]
     float* s_dy = s_in + kWgKC * G::kCS;       // [NB][kDS]
-    __shared__ float s_cst[2 * kWgKC];
+    __shared__ float s_cst[4 * kWgKC];   // scale, mean, beta per input channel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,14 +83,15 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     if constexpr (IN == IN_BNRELU) {
         if (tid < kWgKC) {
             const int c = ci_base + tid;
-            float scale = 0.f, shift = 0.f;
+            float scale = 0.f, mean = 0.f, beta = 0.f;
             if (c < p.cin) {
-                const float mean = p.saved[2 * c], rstd = p.saved[2 * c + 1];
-                scale = p.gamma[c] * rstd;
-                shift = p.beta[c] - mean * scale;
+                mean = p.saved[2 * c];
+                scale = p.gamma[c] * p.saved[2 * c + 1];
+                beta = p.beta[c];
             }
             s_cst[tid] = scale;
-            s_cst[kWgKC + tid] = shift;
+            s_cst[kWgKC + tid] = mean;
+            s_cst[2 * kWgKC + tid] = beta;
         }
     }
 
@@ -173,7 +174,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
                     float v = pre[c * G::kPos + k];
                     if constexpr (IN == IN_BNRELU) {
                         if (ci_base + c < p.cin && (pos_ok & (1u << k))) {
-                            v = fmaf(v, s_cst[c], s_cst[kWgKC + c]);
+                            v = fmaf(v - s_cst[kWgKC + c], s_cst[c], s_cst[2 * kWgKC + c]);
                             v = v > 0.f ? v : 0.f;
                         } else {
                             v = 0.f;

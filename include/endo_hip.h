@@ -166,9 +166,12 @@ int endo_sgd_clip_step(float* params, float* grads, float* momentum, double* nor
                        int64_t count, float lr, float mu, float max_norm, float grad_scale,
                        int first_step, void* stream);
 
-/* live per-kernel-family timing for bench.py's roofline line (HIP events on the launch stream) */
+/* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
+ * stream around every entry of the selected families.  family_mask: bit f enables family f
+ * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read
+ * synchronises on the recorded events and returns totals (ms, launches, algorithmic flops/bytes). */
 #define ENDO_PROF_FAMILIES 16
-int endo_prof_enable(int on);
+int endo_prof_enable(int family_mask);
 int endo_prof_read(int family, double* total_ms, int64_t* launches, double* total_flops, double* total_bytes);
 const char* endo_prof_family_name(int family);
 

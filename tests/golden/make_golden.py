@@ -182,7 +182,7 @@ def network_case(ref, n, h, w, seed, path):
 def train_step_case(ref, n, h, w, seed, path):
     """Two iterations of the reference's batch-loop body (train.py:272-328) with the reference's
     own modules, torch.optim.SGD and clip_grad_norm_."""
-    state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(seed), seed + 1))
     net = load_reference_net(ref, state)
     net.train()
     opt = torch.optim.SGD(net.parameters(), lr=1.0e-3, momentum=0.9)

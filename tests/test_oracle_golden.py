@@ -118,7 +118,7 @@ def test_conv_macs():
 def test_train_step(golden):
     g = golden("train_step_2x64x96.npz")
     n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
-    state = network.perturb_affine(network.synthetic_state(seed), seed + 1)
+    state = network.keep_depth_positive(network.perturb_affine(network.synthetic_state(seed), seed + 1))
     momentum = {}
     for step in range(2):
         batch = synthetic.make_batch(n, h, w, seed=seed + 10 + step, sparse_points=min(500, h * w // 6))
