@@ -1,0 +1,411 @@
+// LDS-DMA variant of the implicit-GEMM convolution (same math, tiling, MFMA roles and epilogues as
+// conv_kernels.h; see the header there).  What changes is how a K-chunk reaches LDS:
+//
+//   * `global_load_lds_dword`: every lane hands the DMA engine its own global address and the wave
+//     writes 64 consecutive LDS dwords -- no staging VGPRs, no ds_write pass, no address VALU in the
+//     loop.  Out-of-image / out-of-range lanes point at a 1-float pad constant instead of branching:
+//     0.0 for raw inputs and weights, NaN for BN+ReLU inputs.
+//   * BN+ReLU moves from the store path to the fragment read: a = max((raw - mean) * scale + beta, 0)
+//     right after the ds_read.  max(NaN, 0) = 0, so the NaN pad is exactly the zero padding of the
+//     post-activation tensor (reference models.py:22-25: the conv pads relu(bn(x)), not x).
+//   * two LDS buffers, ONE barrier per chunk: wait own DMA(c) -> barrier -> issue DMA(c+1) into the
+//     other buffer -> MFMAs on chunk c.  HBM latency hides under the MFMAs of the same block instead
+//     of relying on a co-resident block being in a different phase.
+//   * the ~30-60 staging registers are gone, so the growth-12 forward kernel fits 5 waves/SIMD and a
+//     256x320x8 level-0 launch (1280 tiles) is exactly one round of the chip.
+#pragma once
+
+#include "conv_kernels.h"
+
+namespace endo {
+
+__device__ __attribute__((aligned(16))) float g_pad_consts[8] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
+                                                                  0.0f, 0.0f, 0.0f, 0.0f};   // [0..3] NaN pad, [4..7] zero pad
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int KS, int KC, int Q, int WX, int R, int NBUF, int VEC>
+struct ConvDmaSmem {
+    using G = ConvGeom<KS, KC, WX, R, VEC>;
+    static constexpr int kW = KS * KS * KC * 16 * Q;
+    static constexpr int kBuf = KC * G::kCS + kW;                 // floats per buffer
+    static constexpr int kTail = 4 * 16 * Q + 8 * 16 * Q;       // dgrad constants + reduction scratch
+    static size_t bytes(int bn_cap) { return sizeof(float) * (NBUF * kBuf + 3 * bn_cap + kTail); }
+};
+
+// MINW: minimum waves per SIMD the register allocator must leave room for (__launch_bounds__'s
+// second argument on AMD); 5 for the growth-12 forward kernel so that 5 blocks share a CU.
+// VEC: 1 = dword DMA (any shape), 4 = 16-byte DMA (W % 4 == 0, PLAIN / BNRELU inputs): 4x fewer DMA
+// instructions and address computations per chunk.
+// XF: where BN+ReLU is applied.  0 = on every A-fragment read (3 VALU per read, each LDS value is
+// read by 3 taps); 1 = once, in place in LDS, by the thread whose DMA wrote the value, right after
+// its own vmcnt(0) and before the barrier that publishes the chunk (no extra synchronisation).
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF>
+__global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p) {
+    static_assert(IN != IN_UNPOOL, "UNPOOL needs a compare on load: use the register-staged kernel");
+    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
+    static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE), "16-byte DMA needs contiguous sources");
+    using G = ConvGeom<KS, KC, WX, R, VEC>;
+    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC>;
+    constexpr int KK = KS * KS;
+    constexpr int NB = 16 * Q;
+    constexpr int kWElems = S::kW;
+    constexpr int kWPre = (kWElems + kConvThreads - 1) / kConvThreads;
+    constexpr bool kDgrad = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_SUMPOOL);
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_aux = smem + NBUF * S::kBuf;
+    const int cap = p.bn_cap;      // BN tables: scale [0,cap) mean [cap,2cap) beta [2cap,3cap); then dgrad constants, reductions
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile = blockIdx.x;
+    const int x0 = (tile % p.tiles_x) * G::kTileX;
+    const int y0 = (tile / p.tiles_x) * G::kTileY;
+    const int co_base = blockIdx.y * NB;
+    const int n = blockIdx.z;
+
+    // ---------------- prologue: per-channel constants (identical to conv_mfma_kernel) ----------------
+    if constexpr (IN == IN_BNRELU) {
+        for (int c = tid; c < p.cin; c += kConvThreads) {
+            double mean, var;
+            if (p.training) {
+                mean = p.in_sums[2 * c] / p.count;
+                var = p.in_sums[2 * c + 1] / p.count - mean * mean;
+                if (var < 0.0) var = 0.0;
+            } else {
+                mean = p.running_mean[c];
+                var = p.running_var[c];
+            }
+            const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
+            s_aux[c] = p.gamma[c] * static_cast<float>(rstd);
+            s_aux[cap + c] = static_cast<float>(mean);
+            s_aux[2 * cap + c] = p.beta[c];
+            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
+                if (p.saved) {
+                    p.saved[2 * c] = static_cast<float>(mean);
+                    p.saved[2 * c + 1] = static_cast<float>(rstd);
+                }
+                if (p.training) {
+                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * static_cast<float>(mean);
+                    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
+                }
+            }
+        }
+        // channels past cin (last chunk): any finite constants; their raw values are the NaN pad
+        for (int c = p.cin + tid; c < ((p.cin + KC - 1) / KC) * KC; c += kConvThreads) {
+            s_aux[c] = 0.f; s_aux[cap + c] = 0.f; s_aux[2 * cap + c] = 0.f;
+        }
+    }
+    if constexpr (EPI == EPI_DGRAD_BN) {
+        float* cst = s_aux + 3 * cap;
+        if (tid < NB) {
+            const int c = co_base + tid;
+            float mean = 0.f, rstd = 0.f, scale = 0.f, beta = 0.f;
+            if (c < p.cout) {
+                mean = p.bn_saved[2 * c];
+                rstd = p.bn_saved[2 * c + 1];
+                scale = p.bn_gamma[c] * rstd;
+                beta = p.bn_beta[c];
+            }
+            cst[4 * tid] = scale; cst[4 * tid + 1] = beta; cst[4 * tid + 2] = mean; cst[4 * tid + 3] = rstd;
+        }
+    }
+
+    f32x4 acc[R][Q];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) acc[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wx = (wave % WX) * 16;
+    const int wy = (wave / WX) * R;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+
+    // this thread's fixed tile positions (units of VEC floats): global offset inside a channel plane, or "pad"
+    int goff[G::kPos];
+    unsigned pos_ok = 0;
+#pragma unroll
+    for (int k = 0; k < G::kPos; ++k) {
+        const int e = tid + k * kConvThreads;
+        goff[k] = 0;
+        if (e < G::kUnits) {
+            const int ry = e / (G::kCols / VEC);
+            const int rx = (e - ry * (G::kCols / VEC)) * VEC;
+            const int gy = y0 - G::kHalo + ry;
+            const int gx = x0 - G::kLeft + rx;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {      // W % VEC == 0: a unit is entirely in or out
+                pos_ok |= (1u << k);
+                if constexpr (IN == IN_UPSAMPLE) goff[k] = (gy >> 1) * p.in_w + (gx >> 1);
+                else goff[k] = gy * p.in_w + gx;
+            }
+        }
+    }
+    const float* in_n = p.in + n * p.in_ns;
+    const float* pad_in = g_pad_consts + (IN == IN_BNRELU ? 0 : 4);
+    const float* pad_zero = g_pad_consts + 4;
+    const int nchunks = (p.cin + KC - 1) / KC;
+
+    auto issue_dma = [&](int chunk, int buf) {
+        const int c_base = chunk * KC;
+        float* s_in = smem + buf * S::kBuf;
+        float* s_w = s_in + KC * G::kCS;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int ch = c_base + c;
+            const float* plane = in_n + static_cast<int64_t>(ch) * p.in_cs;
+#pragma unroll
+            for (int k = 0; k < G::kPos; ++k) {
+                const int e0 = k * kConvThreads + wave * 64;          // wave-uniform first unit
+                if (e0 < G::kUnits) {
+                    const bool ok = (ch < p.cin) && (pos_ok & (1u << k));
+                    const float* src = ok ? plane + goff[k] : pad_in;
+                    if (e0 + lane < G::kUnits) {
+                        if constexpr (VEC == 4)
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + c * G::kCS + 4 * e0), 16, 0, 0);
+                        else
+                            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + c * G::kCS + e0), 4, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kWPre; ++k) {
+            const int e0 = k * kConvThreads + wave * 64;
+            if (e0 < kWElems) {
+                const int e = e0 + lane;
+                const int j = e % NB;
+                const int rest = e / NB;
+                const int c = rest % KC;
+                const int tap = rest / KC;
+                const int ci = c_base + c;
+                const int co = co_base + j;
+                const float* src = pad_zero;
+                if (e < kWElems && ci < p.cin && co < p.cout) {
+                    if constexpr (kDgrad) src = p.wgt + (static_cast<int64_t>(ci) * p.w_cin + co) * KK + (KK - 1 - tap);
+                    else src = p.wgt + (static_cast<int64_t>(co) * p.w_cin + ci) * KK + tap;
+                }
+                if (e < kWElems) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_w + e0), 4, 0, 0);
+            }
+        }
+    };
+
+    // DGRAD_BN: the epilogue's operands (activations x, and the gradient buffer it accumulates into)
+    // do not depend on the MFMAs, so their loads are issued now and fly under the whole K loop.
+    constexpr int PR = (EPI == EPI_DGRAD_BN) ? R : 1, PQ = (EPI == EPI_DGRAD_BN) ? Q : 1;
+    f32x4 xpre[PR][PQ], dpre[PR][PQ];
+    bool use_pre = false;
+    if constexpr (EPI == EPI_DGRAD_BN) {
+        use_pre = ((p.out_w & 3) == 0) && ((p.w & 3) == 0);
+        if (use_pre) {
+            const int px = x0 + wx + 4 * lk;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int co = co_base + q * 16 + li;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int y = y0 + wy + r;
+                    xpre[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dpre[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (co < p.cout && y < p.h && px + 3 < p.w) {
+                        xpre[r][q] = *reinterpret_cast<const f32x4*>(p.x + n * p.x_ns + static_cast<int64_t>(co) * p.x_cs + y * p.out_w + px);
+                        if (co >= p.acc_from)
+                            dpre[r][q] = *reinterpret_cast<const f32x4*>(p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px);
+                    }
+                }
+            }
+        }
+    }
+
+    constexpr bool kInPlace = (IN == IN_BNRELU) && (XF == 1);
+    auto transform_own = [&](int chunk, int buf) {
+        if constexpr (kInPlace) {
+            float* s_in = smem + buf * S::kBuf;
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                const int ch = chunk * KC + c;
+                const float sc = s_aux[ch], mn = s_aux[cap + ch], bt = s_aux[2 * cap + ch];
+#pragma unroll
+                for (int k = 0; k < G::kPos; ++k) {
+                    const int e = tid + k * kConvThreads;
+                    if (e < G::kUnits) {
+                        if constexpr (VEC == 4) {
+                            f32x4* q = reinterpret_cast<f32x4*>(s_in + c * G::kCS + 4 * e);
+                            f32x4 v = *q;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaxf(fmaf(v[i] - mn, sc, bt), 0.f);
+                            *q = v;
+                        } else {
+                            float* q = s_in + c * G::kCS + e;
+                            *q = __builtin_fmaxf(fmaf(*q - mn, sc, bt), 0.f);
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    auto compute = [&](int chunk, int buf) {
+        const float* s_in = smem + buf * S::kBuf;
+        const float* s_w = s_in + KC * G::kCS;
+#pragma unroll
+        for (int quad = 0; quad < KC / 4; ++quad) {
+            const float* a_base = s_in + (quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li + G::kColOff;
+            const float* b_base = s_w + (quad * 4 + lk) * NB + li;
+            float sc = 1.f, mn = 0.f, bt = 0.f;
+            if constexpr (IN == IN_BNRELU && !kInPlace) {
+                const int ch = chunk * KC + quad * 4 + lk;
+                sc = s_aux[ch]; mn = s_aux[cap + ch]; bt = s_aux[2 * cap + ch];
+            }
+#pragma unroll
+            for (int dx = 0; dx < KS; ++dx) {
+                float a[R + KS - 1];
+#pragma unroll
+                for (int r = 0; r < R + KS - 1; ++r) {
+                    float v = a_base[r * G::kCols + dx];
+                    if constexpr (IN == IN_BNRELU && !kInPlace) v = __builtin_fmaxf(fmaf(v - mn, sc, bt), 0.f);
+                    a[r] = v;
+                }
+#pragma unroll
+                for (int dy = 0; dy < KS; ++dy) {
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const float b = b_base[(dy * KS + dx) * KC * NB + q * 16];
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], b, acc[r][q], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    issue_dma(0, 0);
+    if constexpr (kInPlace) {
+        // pipeline: [DMA(c+1) -> other buffer] [MFMAs(c)] [own DMA(c+1) landed -> transform own values] [barrier]
+        __syncthreads();                              // s_aux (BN constants) visible
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        transform_own(0, 0);
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            if (chunk + 1 < nchunks) issue_dma(chunk + 1, (chunk + 1) & 1);
+            compute(chunk, chunk & 1);
+            if (chunk + 1 < nchunks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                transform_own(chunk + 1, (chunk + 1) & 1);
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            // own DMA of this chunk has landed; after the barrier everybody's has, and everybody has
+            // finished reading the other buffer (chunk - 1), so it can be refilled
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (NBUF == 2 && chunk + 1 < nchunks) issue_dma(chunk + 1, (chunk + 1) & 1);
+            compute(chunk, chunk % NBUF);
+            if (NBUF == 1 && chunk + 1 < nchunks) {      // single buffer: refill only once everybody is done reading
+                __syncthreads();
+                issue_dma(chunk + 1, 0);
+            }
+        }
+    }
+
+    if constexpr (EPI == EPI_DGRAD_BN) {
+        if (use_pre) {
+            const float* cst = s_aux + 3 * cap;
+            float* s_red = s_aux + 3 * cap + 4 * NB;
+            const int px = x0 + wx + 4 * lk;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int jloc = q * 16 + li;
+                const int co = co_base + jloc;
+                const float scale = cst[4 * jloc], beta = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int y = y0 + wy + r;
+                    if (co < p.cout && y < p.h && px + 3 < p.w) {
+                        f32x4 o = dpre[r][q];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xc = xpre[r][q][e] - mean;
+                            const float z = fmaf(xc, scale, beta);
+                            const float dz = z > 0.f ? acc[r][q][e] : 0.f;
+                            s1 += dz;
+                            s2 += dz * (xc * rstd);
+                            o[e] += scale * dz;
+                        }
+                        *reinterpret_cast<f32x4*>(p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px) = o;
+                    }
+                }
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lk == 0) {
+                    s_red[((tid >> 6) * NB + jloc) * 2] = s1;
+                    s_red[((tid >> 6) * NB + jloc) * 2 + 1] = s2;
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * NB) {
+                const int j = tid >> 1, which = tid & 1;
+                if (co_base + j < p.cout) {
+                    double t = 0.0;
+                    for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                    atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
+                }
+            }
+            return;
+        }
+    }
+    conv_epilogue<Q, EPI, R>(p, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
+}
+
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0>
+inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
+    static_assert(XF == 0 || NBUF == 2 || IN != IN_BNRELU, "the in-place transform pipeline is written for two buffers");
+    using G = ConvGeom<KS, KC, WX, R, VEC>;
+    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC>;
+    p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
+    p.bn_cap = (IN == IN_BNRELU) ? ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16 : 0;
+    const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
+    dim3 grid(p.tiles_x * tiles_y, (p.cout + 16 * Q - 1) / (16 * Q), p.n);
+    const size_t smem = S::bytes(p.bn_cap);
+    static size_t configured = 0;
+    if (smem > 48 * 1024 && smem > configured) {
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        configured = smem;
+    }
+    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF><<<grid, kConvThreads, smem, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// 16-byte DMA whenever the input rows are float4-aligned, dword DMA otherwise
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW = 1>
+inline int launch_conv_dma(const ConvParams& p, hipStream_t stream) {
+    if constexpr (IN != IN_UPSAMPLE) {
+        const bool aligned = (p.w % 4 == 0) && (p.in_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
+                             (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
+        if (aligned) return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 4>(p, stream);
+    }
+    return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 1>(p, stream);
+}
+
+// tile-shape choice as launch_conv_auto; KC is the per-chunk depth of the double-buffered pipeline
+template <int KS, int KC, int Q, int IN, int EPI, int BIG_R = 8, int NBUF = 2, int BIG_MINW = 1>
+inline int launch_conv_dma_auto(const ConvParams& p, hipStream_t stream) {
+    const long tiles_big = static_cast<long>((p.w + 31) / 32) * ((p.h + 15) / 16) * p.n;
+    if (tiles_big >= 512) return launch_conv_dma<KS, KC, Q, IN, EPI, 2, BIG_R, NBUF, BIG_MINW>(p, stream);
+    const long tiles_mid = static_cast<long>((p.w + 15) / 16) * ((p.h + 15) / 16) * p.n;
+    if (tiles_mid >= 384) return launch_conv_dma<KS, KC, Q, IN, EPI, 1, 4, NBUF>(p, stream);
+    constexpr int KCS = (NBUF == 2 && KS == 3 && KC <= 8) ? 16 : KC;
+    return launch_conv_dma<KS, KCS, Q, IN, EPI, 1, 2, NBUF>(p, stream);
+}
+
+}  // namespace endo

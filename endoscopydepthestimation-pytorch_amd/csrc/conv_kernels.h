@@ -35,8 +35,6 @@ namespace endo {
 enum InMode { IN_PLAIN = 0, IN_BNRELU = 1, IN_UPSAMPLE = 2, IN_UNPOOL = 3 };
 enum Epilogue { EPI_FWD = 0, EPI_FWD_POOL = 1, EPI_DGRAD_BN = 2, EPI_DGRAD_SUMPOOL = 3 };
 
-constexpr int kTileX = 32;
-constexpr int kTileY = 16;
 constexpr int kConvThreads = 256;
 constexpr int kMaxBnChannels = 384;
 
@@ -81,31 +79,233 @@ struct ConvParams {
     const float* bn_beta;
     double* bn_scratch;      // [cout][2] sum dz, sum dz*xhat
     int acc_from;            // output channels >= acc_from accumulate into `out`, others overwrite
+    int bn_cap;              // LDS-DMA kernels: capacity (channels) of the BN constant tables, set by the launcher
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int KC>
+// Tile shape: WX waves side by side (16 pixels each), 4/WX waves stacked, R rows per wave.
+//   <WX=2, R=8>  32 x 16 pixels  -- full-resolution levels
+//   <WX=1, R=4>  16 x 16 pixels  -- mid levels (more blocks to fill 256 CUs)
+//   <WX=1, R=2>  16 x  8 pixels  -- the 32x40 ... 8x10 levels
+template <int KS, int KC, int WX, int R, int VEC = 1>
 struct ConvGeom {
+    static constexpr int kTileX = 16 * WX;
+    static constexpr int kTileY = R * (4 / WX);
     static constexpr int kHalo = KS / 2;
     static constexpr int kRows = kTileY + 2 * kHalo;
-    static constexpr int kCols = kTileX + 2 * kHalo;
+    // VEC == 4 (16-byte LDS-DMA): the tile starts 4 pixels left of the output tile so that every
+    // row is a whole number of aligned float4s; the 3 extra columns per side are never read
+    static constexpr int kLeft = (VEC == 4 && KS == 3) ? 4 : kHalo;
+    static constexpr int kCols = kTileX + 2 * kLeft;
+    static constexpr int kColOff = kLeft - kHalo;          // fragment column = x - x0 + dx + kColOff
     static constexpr int kPlane = kRows * kCols;
     // channel stride == 16 (mod 32) so the 4 k-groups of an A fragment hit disjoint banks
     static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;
-    static constexpr int kPos = (kPlane + kConvThreads - 1) / kConvThreads;   // tile positions per thread
+    static constexpr int kUnits = kPlane / VEC;                                // DMA / staging units per channel
+    static constexpr int kPos = (kUnits + kConvThreads - 1) / kConvThreads;   // units per thread
     static constexpr int kPre = KC * kPos;                                    // staged values per thread per chunk
 };
 
-template <int KS, int KC, int Q, int IN, int EPI>
+// Epilogue shared by the register-staged and the LDS-DMA kernels.  `cst` holds the DGRAD_BN
+// per-channel constants (4 per output channel of the block), `s_red` 8*NB floats of reduction scratch.
+template <int Q, int EPI, int R>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[R][Q], const float* cst, float* s_red,
+                                              int x0, int y0, int wx, int wy, int co_base, int n) {
+    constexpr int NB = 16 * Q;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    (void)cst; (void)s_red; (void)wave;
+    // lane holds, for cout j = co_base + q*16 + li, pixels x = x0 + wx + 4*lk + {0..3}, rows y0+wy+r
+    const int px = x0 + wx + 4 * lk;
+    const bool vec_ok = ((p.out_w & 3) == 0) && ((p.w & 3) == 0);
+
+    if constexpr (EPI == EPI_FWD) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            const bool co_ok = co < p.cout;
+            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                f32x4 v = acc[r][q];
+                v[0] += bias; v[1] += bias; v[2] += bias; v[3] += bias;
+                if (co_ok && y < p.h) {
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
+                    if (vec_ok && px + 3 < p.w) {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (px + e < p.w) { dst[e] = v[e]; s1 += v[e]; s2 += v[e] * v[e]; }
+                    }
+                }
+            }
+            if (p.out_sums) {
+                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (lk == 0) {
+                    s_red[(wave * NB + q * 16 + li) * 2] = s1;
+                    s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
+                }
+            }
+        }
+        if (p.out_sums) {
+            __syncthreads();
+            if (tid < 2 * NB) {
+                const int j = tid >> 1, which = tid & 1;
+                if (co_base + j < p.cout) {
+                    double t = 0.0;
+                    for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                    atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_FWD_POOL) {
+        const int ph = p.h >> 1, pw = p.w >> 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            const bool co_ok = co < p.cout;
+            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int yp = (y0 + wy + r) >> 1;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int xp = (px + e) >> 1;
+                    float best = acc[r][q][e] + bias;
+                    int code = 0;
+                    float v = acc[r][q][e + 1] + bias;
+                    if (v > best) { best = v; code = 1; }
+                    v = acc[r + 1][q][e] + bias;
+                    if (v > best) { best = v; code = 2; }
+                    v = acc[r + 1][q][e + 1] + bias;
+                    if (v > best) { best = v; code = 3; }
+                    if (co_ok && yp < ph && xp < pw) {
+                        const int64_t o = static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp;
+                        p.out[n * p.out_ns + o] = best;
+                        p.out_idx[n * p.idx_ns + o] = static_cast<uint8_t>(code);
+                        s1 += best; s2 += best * best;
+                    }
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                s_red[(wave * NB + q * 16 + li) * 2] = s1;
+                s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int j = tid >> 1, which = tid & 1;
+            if (co_base + j < p.cout) {
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
+            }
+        }
+    } else if constexpr (EPI == EPI_DGRAD_BN) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int jloc = q * 16 + li;
+            const int co = co_base + jloc;
+            const bool co_ok = co < p.cout;
+            const float scale = cst[4 * jloc], beta = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
+            const bool accumulate = co >= p.acc_from;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                if (co_ok && y < p.h) {
+                    const int64_t xo = n * p.x_ns + static_cast<int64_t>(co) * p.x_cs + y * p.out_w + px;
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
+                    if (vec_ok && px + 3 < p.w) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + xo);
+                        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xc = xv[e] - mean;
+                            const float z = fmaf(xc, scale, beta);
+                            const float dz = z > 0.f ? acc[r][q][e] : 0.f;
+                            s1 += dz;
+                            s2 += dz * (xc * rstd);
+                            o[e] += scale * dz;
+                        }
+                        *reinterpret_cast<f32x4*>(dst) = o;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (px + e < p.w) {
+                                const float xv = p.x[xo + e];
+                                const float xc = xv - mean;
+                                const float z = fmaf(xc, scale, beta);
+                                const float dz = z > 0.f ? acc[r][q][e] : 0.f;
+                                s1 += dz;
+                                s2 += dz * (xc * rstd);
+                                dst[e] = (accumulate ? dst[e] : 0.f) + scale * dz;
+                            }
+                        }
+                    }
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                s_red[(wave * NB + jloc) * 2] = s1;
+                s_red[(wave * NB + jloc) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * NB) {
+            const int j = tid >> 1, which = tid & 1;
+            if (co_base + j < p.cout) {
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
+            }
+        }
+    } else {   // EPI_DGRAD_SUMPOOL
+        const int ph = p.h >> 1, pw = p.w >> 1;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int co = co_base + q * 16 + li;
+            if (co >= p.cout) continue;
+#pragma unroll
+            for (int r = 0; r < R; r += 2) {
+                const int yp = (y0 + wy + r) >> 1;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const int xp = (px + e) >> 1;
+                    if (yp < ph && xp < pw) {
+                        const float v = (acc[r][q][e] + acc[r][q][e + 1]) + (acc[r + 1][q][e] + acc[r + 1][q][e + 1]);
+                        p.out[n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R>
 __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParams p) {
-    using G = ConvGeom<KS, KC>;
+    using G = ConvGeom<KS, KC, WX, R>;
+    constexpr int kTileX = G::kTileX;
+    constexpr int kTileY = G::kTileY;
     constexpr int KK = KS * KS;
     constexpr int NB = 16 * Q;
     constexpr int kWElems = KK * KC * NB;
     constexpr int kWPre = (kWElems + kConvThreads - 1) / kConvThreads;
     constexpr bool kDgrad = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_SUMPOOL);
-    constexpr int R = kTileY / 2;   // rows per wave
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                       // [KC][kCS]
@@ -177,8 +377,8 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
 #pragma unroll
         for (int q = 0; q < Q; ++q) acc[r][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int wx = (wave & 1) * 16;      // wave's x offset inside the tile
-    const int wy = (wave >> 1) * R;      // wave's first row inside the tile
+    const int wx = (wave % WX) * 16;     // wave's x offset inside the tile
+    const int wy = (wave / WX) * R;      // wave's first row inside the tile
     const int li = lane & 15;
     const int lk = lane >> 4;
 
@@ -320,206 +520,44 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
     }
 
     // ---------------- epilogue ----------------
-    // lane holds, for cout j = co_base + q*16 + li, pixels x = x0 + wx + 4*lk + {0..3}, rows y0+wy+r
-    const int px = x0 + wx + 4 * lk;
-    const bool vec_ok = ((p.out_w & 3) == 0) && ((p.w & 3) == 0);
-
-    if constexpr (EPI == EPI_FWD) {
-        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;   // [4 waves][NB][2]
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int co = co_base + q * 16 + li;
-            const bool co_ok = co < p.cout;
-            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int y = y0 + wy + r;
-                f32x4 v = acc[r][q];
-                v[0] += bias; v[1] += bias; v[2] += bias; v[3] += bias;
-                if (co_ok && y < p.h) {
-                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
-                    if (vec_ok && px + 3 < p.w) {
-                        *reinterpret_cast<f32x4*>(dst) = v;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { s1 += v[e]; s2 += v[e] * v[e]; }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (px + e < p.w) { dst[e] = v[e]; s1 += v[e]; s2 += v[e] * v[e]; }
-                    }
-                }
-            }
-            if (p.out_sums) {
-                s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-                s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (lk == 0) {
-                    s_red[(wave * NB + q * 16 + li) * 2] = s1;
-                    s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
-                }
-            }
-        }
-        if (p.out_sums) {
-            __syncthreads();
-            if (tid < 2 * NB) {
-                const int j = tid >> 1, which = tid & 1;
-                if (co_base + j < p.cout) {
-                    double t = 0.0;
-                    for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
-                    atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
-                }
-            }
-        }
-    } else if constexpr (EPI == EPI_FWD_POOL) {
-        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;
-        const int ph = p.h >> 1, pw = p.w >> 1;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int co = co_base + q * 16 + li;
-            const bool co_ok = co < p.cout;
-            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < R; r += 2) {
-                const int yp = (y0 + wy + r) >> 1;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int xp = (px + e) >> 1;
-                    float best = acc[r][q][e] + bias;
-                    int code = 0;
-                    float v = acc[r][q][e + 1] + bias;
-                    if (v > best) { best = v; code = 1; }
-                    v = acc[r + 1][q][e] + bias;
-                    if (v > best) { best = v; code = 2; }
-                    v = acc[r + 1][q][e + 1] + bias;
-                    if (v > best) { best = v; code = 3; }
-                    if (co_ok && yp < ph && xp < pw) {
-                        const int64_t o = static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp;
-                        p.out[n * p.out_ns + o] = best;
-                        p.out_idx[n * p.idx_ns + o] = static_cast<uint8_t>(code);
-                        s1 += best; s2 += best * best;
-                    }
-                }
-            }
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lk == 0) {
-                s_red[(wave * NB + q * 16 + li) * 2] = s1;
-                s_red[(wave * NB + q * 16 + li) * 2 + 1] = s2;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * NB) {
-            const int j = tid >> 1, which = tid & 1;
-            if (co_base + j < p.cout) {
-                double t = 0.0;
-                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
-                atomicAdd(p.out_sums + 2 * (co_base + j) + which, t);
-            }
-        }
-    } else if constexpr (EPI == EPI_DGRAD_BN) {
-        const float* cst = s_aux + 3 * kMaxBnChannels;
-        float* s_red = s_aux + 3 * kMaxBnChannels + 4 * NB;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int jloc = q * 16 + li;
-            const int co = co_base + jloc;
-            const bool co_ok = co < p.cout;
-            const float scale = cst[4 * jloc], beta = cst[4 * jloc + 1], mean = cst[4 * jloc + 2], rstd = cst[4 * jloc + 3];
-            const bool accumulate = co >= p.acc_from;
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int y = y0 + wy + r;
-                if (co_ok && y < p.h) {
-                    const int64_t xo = n * p.x_ns + static_cast<int64_t>(co) * p.x_cs + y * p.out_w + px;
-                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + y * p.out_w + px;
-                    if (vec_ok && px + 3 < p.w) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + xo);
-                        f32x4 o = accumulate ? *reinterpret_cast<const f32x4*>(dst) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float xc = xv[e] - mean;
-                            const float z = fmaf(xc, scale, beta);
-                            const float dz = z > 0.f ? acc[r][q][e] : 0.f;
-                            s1 += dz;
-                            s2 += dz * (xc * rstd);
-                            o[e] += scale * dz;
-                        }
-                        *reinterpret_cast<f32x4*>(dst) = o;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (px + e < p.w) {
-                                const float xv = p.x[xo + e];
-                                const float xc = xv - mean;
-                                const float z = fmaf(xc, scale, beta);
-                                const float dz = z > 0.f ? acc[r][q][e] : 0.f;
-                                s1 += dz;
-                                s2 += dz * (xc * rstd);
-                                dst[e] = (accumulate ? dst[e] : 0.f) + scale * dz;
-                            }
-                        }
-                    }
-                }
-            }
-            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lk == 0) {
-                s_red[(wave * NB + jloc) * 2] = s1;
-                s_red[(wave * NB + jloc) * 2 + 1] = s2;
-            }
-        }
-        __syncthreads();
-        if (tid < 2 * NB) {
-            const int j = tid >> 1, which = tid & 1;
-            if (co_base + j < p.cout) {
-                double t = 0.0;
-                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
-                atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
-            }
-        }
-    } else {   // EPI_DGRAD_SUMPOOL
-        const int ph = p.h >> 1, pw = p.w >> 1;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int co = co_base + q * 16 + li;
-            if (co >= p.cout) continue;
-#pragma unroll
-            for (int r = 0; r < R; r += 2) {
-                const int yp = (y0 + wy + r) >> 1;
-#pragma unroll
-                for (int e = 0; e < 4; e += 2) {
-                    const int xp = (px + e) >> 1;
-                    if (yp < ph && xp < pw) {
-                        const float v = (acc[r][q][e] + acc[r][q][e + 1]) + (acc[r + 1][q][e] + acc[r + 1][q][e + 1]);
-                        p.out[n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp] = v;
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<Q, EPI, R>(p, acc, s_aux + 3 * kMaxBnChannels, s_aux + 3 * kMaxBnChannels + 4 * NB, x0, y0, wx, wy, co_base, n);
 }
 
-template <int KS, int KC, int Q>
+template <int KS, int KC, int Q, int WX, int R>
 constexpr size_t conv_smem_bytes() {
-    return sizeof(float) * (KC * ConvGeom<KS, KC>::kCS + KS * KS * KC * 16 * Q + 3 * kMaxBnChannels + 4 * 16 * Q + 4 * 16 * Q * 2);
+    return sizeof(float) * (KC * ConvGeom<KS, KC, WX, R>::kCS + KS * KS * KC * 16 * Q + 3 * kMaxBnChannels + 4 * 16 * Q + 4 * 16 * Q * 2);
 }
 
-template <int KS, int KC, int Q, int IN, int EPI>
-inline int launch_conv(const ConvParams& p, hipStream_t stream) {
-    const int tiles_y = (p.h + kTileY - 1) / kTileY;
+// p.tiles_x is filled in here from the tile shape of the chosen instantiation
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R>
+inline int launch_conv(ConvParams p, hipStream_t stream) {
+    using G = ConvGeom<KS, KC, WX, R>;
+    static_assert(G::kPre <= 64 && G::kPos <= 16, "staging registers");
+    p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
+    const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     dim3 grid(p.tiles_x * tiles_y, (p.cout + 16 * Q - 1) / (16 * Q), p.n);
-    constexpr size_t smem = conv_smem_bytes<KS, KC, Q>();
+    constexpr size_t smem = conv_smem_bytes<KS, KC, Q, WX, R>();
     static bool configured = false;
     if (!configured && smem > 48 * 1024) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, KC, Q, IN, EPI>),
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, KC, Q, IN, EPI, WX, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         configured = true;
     }
-    conv_mfma_kernel<KS, KC, Q, IN, EPI><<<grid, kConvThreads, smem, stream>>>(p);
+    conv_mfma_kernel<KS, KC, Q, IN, EPI, WX, R><<<grid, kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
+}
+
+// Pick the tile shape from the image size: big tiles where there are enough of them to fill the
+// chip, small tiles on the coarse levels (fewer wasted MFMAs on partial tiles, more blocks).
+template <int KS, int KC, int Q, int IN, int EPI, int BIG_R = 8>
+inline int launch_conv_auto(const ConvParams& p, hipStream_t stream) {
+    const long tiles_big = static_cast<long>((p.w + 31) / 32) * ((p.h + 15) / 16) * p.n;
+    if (tiles_big >= 512) return launch_conv<KS, KC, Q, IN, EPI, 2, BIG_R>(p, stream);
+    const long tiles_mid = static_cast<long>((p.w + 15) / 16) * ((p.h + 15) / 16) * p.n;
+    if (tiles_mid >= 384) return launch_conv<KS, KC, Q, IN, EPI, 1, 4>(p, stream);
+    constexpr int KCS = (KS == 3 && KC == 8) ? 16 : KC;     // fewer, fatter K-chunks when a block is alone on its CU
+    return launch_conv<KS, KCS, Q, IN, EPI, 1, 2>(p, stream);
 }
 
 }  // namespace endo

@@ -17,7 +17,8 @@
 #include <new>
 #include <vector>
 
-#include "wgrad_kernels.h"
+#include "dgrad_kernels.h"
+#include "wgrad_taps_kernels.h"
 
 namespace endo {
 
@@ -116,14 +117,24 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
     const int c = blockIdx.y, n = blockIdx.z;
     const float pc = pq_p[c], qc = pq_q[c];
     const int64_t base = n * ns + static_cast<int64_t>(c) * plane;
-    float part[1] = {0.f};
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
-        const float g = dbuf[base + i] + fmaf(pc, x[base + i], qc);
-        dbuf[base + i] = g;
-        part[0] += g;
+    float part = 0.f;
+    if ((plane & 3) == 0) {
+        for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
+            f32x4 g = *reinterpret_cast<const f32x4*>(dbuf + base + i);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { g[e] += fmaf(pc, xv[e], qc); part += g[e]; }
+            *reinterpret_cast<f32x4*>(dbuf + base + i) = g;
+        }
+    } else {
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+            const float g = dbuf[base + i] + fmaf(pc, x[base + i], qc);
+            dbuf[base + i] = g;
+            part += g;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double v = wave_sum(static_cast<double>(part[0]));
+    double v = wave_sum(static_cast<double>(part));
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0 && bias_grad) atomicAdd(bias_grad + c, static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]));
@@ -283,7 +294,6 @@ static void fill_out(const Ctx& c, ConvParams& p, float* base, int level, int oc
 static void fill_grid(const Ctx& c, ConvParams& p, int level) {
     const auto& lv = c.net->lv[level];
     p.n = c.net->n; p.h = lv.h; p.w = lv.w;
-    p.tiles_x = (lv.w + kTileX - 1) / kTileX;
 }
 
 static double conv_flops(const endo_net* net, int level, int cin, int cout, int ks) {
@@ -301,7 +311,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     p.out_sums = c.sums(level) + 2 * oc0;
     ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
                    4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout));
-    return launch_conv<3, 8, 1, IN_BNRELU, EPI_FWD>(p, c.stream);
+    return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
 }
 
 // transition down: BN -> ReLU -> conv1x1 -> maxpool2 into the next level (models.py:56-67)
@@ -319,7 +329,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.out_sums = c.sums(next) + 2 * oc0;
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
-    return launch_conv<1, 16, 3, IN_BNRELU, EPI_FWD_POOL>(p, c.stream);
+    return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL>(p, c.stream);
 }
 
 // transition up: nearest x2 -> conv3x3 48->48 into channels [0,48) of the finer level (models.py:70-80)
@@ -332,13 +342,13 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     p.out_sums = c.sums(level);
     ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
                    4.0 * c.net->n * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
-    return launch_conv<3, 8, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
+    return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
 static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad) {
     const auto& lv = c.net->lv[level];
-    int bx = static_cast<int>((lv.plane + 1023) / 1024);
-    bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+    int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
+    bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
     ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.net->n * lv.plane * count);
     prep_dy_kernel<<<dim3(bx, count, c.net->n), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
@@ -377,7 +387,7 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
-        rc = launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
+        rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
     {
@@ -391,7 +401,7 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.bn_scratch = c.scratch(b);
         p.acc_from = acc_from - ic0;
         ProfScope prof(kProfDgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (3.0 * cv.cin + cv.cout));
-        rc = launch_conv<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN>(p, c.stream);
+        rc = launch_dgrad_dense_auto(p, c.stream);
         if (rc) return rc;
     }
     return bn_finalize(c, b, level, ic0);
@@ -413,7 +423,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.dy_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * cv.cin);
-        rc = launch_wgrad<1, 3, IN_BNRELU, DY_UNPOOL>(p, c.stream);
+        rc = launch_wgrad1x1(p, c.stream);
         if (rc) return rc;
     }
     {
@@ -428,7 +438,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.bn_scratch = c.scratch(b);
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * 3.0 * cv.cin);
-        rc = launch_conv<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN>(p, c.stream);
+        rc = launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
         if (rc) return rc;
     }
     return bn_finalize(c, b, level, 48);
@@ -446,7 +456,7 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin / 4.0 + cv.cout));
-        rc = launch_wgrad<3, 3, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
+        rc = launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
     ConvParams p{};
@@ -455,7 +465,7 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
     ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cout + cv.cin / 4.0));
-    return launch_conv<3, 8, 3, IN_PLAIN, EPI_DGRAD_SUMPOOL>(p, c.stream);
+    return launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_DGRAD_SUMPOOL, 4>(p, c.stream);
 }
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
@@ -536,7 +546,7 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
         fill_out(c, p, c.act(0), 0, 48, kFirst);
         p.out_sums = c.sums(0) + 2 * 48;
         ProfScope prof(kProfConvFirst, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * net->lv[0].plane * (3 + kFirst));
-        rc = launch_conv<3, 4, 3, IN_PLAIN, EPI_FWD>(p, c.stream);
+        rc = launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_FWD>(p, c.stream);
         if (rc) return rc;
     }
     for (int l = 0; l < kLevels; ++l) {
@@ -630,6 +640,6 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
         p.dw = grads + tb.first.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * lv.plane * (3 + kFirst));
-        return launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
+        return wgrad_taps_ok(p) ? launch_wgrad_taps<48, IN_PLAIN>(p, c.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
     }
 }

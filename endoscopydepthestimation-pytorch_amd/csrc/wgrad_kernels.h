@@ -256,8 +256,10 @@ inline int launch_wgrad(const WgradParams& p, hipStream_t stream) {
     const int ci_chunks = (p.cin + kWgKC - 1) / kWgKC;
     const int co_sets = (p.cout + 16 * Q - 1) / (16 * Q);
     const int tiles_total = p.tiles_x * p.tiles_y * p.n;
-    int groups = 1536 / (ci_chunks * co_sets);
+    // ~1024 blocks in total; at most 384 blocks add into the same dW element (atomic contention)
+    int groups = 1024 / (ci_chunks * co_sets);
     if (groups < 1) groups = 1;
+    if (groups > 384) groups = 384;
     if (groups > tiles_total) groups = tiles_total;
     dim3 grid(ci_chunks, groups, co_sets);
     constexpr size_t smem = wgrad_smem_bytes<KS, Q>();
@@ -268,6 +270,152 @@ inline int launch_wgrad(const WgradParams& p, hipStream_t stream) {
         configured = true;
     }
     wgrad_mfma_kernel<KS, Q, IN, DY><<<grid, kConvThreads, smem, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// 1x1 weight gradient (transition down): dW[co][ci] += sum_p dY[co][p] * a[ci][p], a plain GEMM with
+// K = all pixels.  The 3x3 kernel above re-stages a tile for 16 MFMAs per wave; here a block owns a
+// 96 x 96 (co x ci) tile of dW, streams 64-pixel chunks of both operands through LDS (dY un-pooled on
+// the fly from the pooled gradient + argmax codes, a = relu(bn(x)) from the saved statistics) and
+// issues 144 MFMAs per wave per chunk: wave (wr, wc) owns 3 x 3 sixteen-wide sub-tiles.
+// ---------------------------------------------------------------------------------------------
+constexpr int kW1Tile = 96;
+constexpr int kW1Chunk = 64;
+constexpr int kW1Stride = kW1Chunk + 2;     // == 2 (mod 32): conflict-free (16 channels x 2 pixels) reads
+constexpr int kW1Rows = 2 * kW1Tile;        // 96 dY rows then 96 activation rows
+constexpr int kW1Pre = kW1Rows * kW1Chunk / kConvThreads;   // 48 staged values per thread
+
+__global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const WgradParams p) {
+    __shared__ float s_t[kW1Rows * kW1Stride];
+    __shared__ float s_cst[3 * kW1Tile];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int co_base = blockIdx.y * kW1Tile;
+    const int ci_base = blockIdx.z * kW1Tile;
+    const int plane = p.h * p.w;
+    const int chunks_per_sample = (plane + kW1Chunk - 1) / kW1Chunk;
+    const int chunks_total = chunks_per_sample * p.n;
+
+    for (int c = tid; c < kW1Tile; c += kConvThreads) {
+        const int ch = ci_base + c;
+        float scale = 0.f, mean = 0.f, beta = 0.f;
+        if (ch < p.cin) {
+            mean = p.saved[2 * ch];
+            scale = p.gamma[ch] * p.saved[2 * ch + 1];
+            beta = p.beta[ch];
+        }
+        s_cst[c] = scale; s_cst[kW1Tile + c] = mean; s_cst[2 * kW1Tile + c] = beta;
+    }
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int px = tid & 63;            // pixel inside the chunk this thread stages
+    const int row0 = tid >> 6;          // rows row0 + 4k
+    float pre[kW1Pre];
+    bool pix_ok = false;
+
+    auto load_chunk = [&](int chunk) {
+        const int n = chunk / chunks_per_sample;
+        const int pix = (chunk - n * chunks_per_sample) * kW1Chunk + px;
+        pix_ok = pix < plane;
+        int pooled = 0, code = 0;
+        if (pix_ok) {
+            const int y = pix / p.w, x = pix - y * p.w;
+            pooled = (y >> 1) * p.dy_w + (x >> 1);
+            code = ((y & 1) << 1) | (x & 1);
+        }
+        const float* dy_n = p.dy + n * p.dy_ns;
+        const uint8_t* idx_n = p.dy_idx + n * p.idx_ns;
+        const float* in_n = p.in + n * p.in_ns;
+#pragma unroll
+        for (int k = 0; k < kW1Pre / 2; ++k) {          // dY rows
+            const int co = co_base + row0 + 4 * k;
+            float v = 0.f;
+            if (pix_ok && co < p.cout) {
+                const int64_t o = static_cast<int64_t>(co) * p.dy_cs + pooled;
+                v = (idx_n[o] == code) ? dy_n[o] : 0.f;
+            }
+            pre[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < kW1Pre / 2; ++k) {          // activation rows
+            const int ch = ci_base + row0 + 4 * k;
+            pre[kW1Pre / 2 + k] = (pix_ok && ch < p.cin) ? in_n[static_cast<int64_t>(ch) * p.in_cs + pix] : 0.f;
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int k = 0; k < kW1Pre / 2; ++k) s_t[(row0 + 4 * k) * kW1Stride + px] = pre[k];
+#pragma unroll
+        for (int k = 0; k < kW1Pre / 2; ++k) {
+            const int r = row0 + 4 * k;
+            float v = 0.f;
+            if (pix_ok && ci_base + r < p.cin) {
+                v = fmaf(pre[kW1Pre / 2 + k] - s_cst[kW1Tile + r], s_cst[r], s_cst[2 * kW1Tile + r]);
+                v = v > 0.f ? v : 0.f;
+            }
+            s_t[(kW1Tile + r) * kW1Stride + px] = v;
+        }
+    };
+
+    const int wr = wave >> 1, wc = wave & 1;      // wave's 48 x 48 quadrant of the 96 x 96 tile
+    int chunk = blockIdx.x;
+    if (chunk < chunks_total) load_chunk(chunk);
+    __syncthreads();
+    bool first = true;
+    for (; chunk < chunks_total; chunk += gridDim.x) {
+        if (!first) __syncthreads();
+        first = false;
+        store_chunk();
+        __syncthreads();
+        if (chunk + static_cast<int>(gridDim.x) < chunks_total) load_chunk(chunk + gridDim.x);
+        const float* a_base = s_t + (wr * 48 + li) * kW1Stride + lk;
+        const float* b_base = s_t + (kW1Tile + wc * 48 + li) * kW1Stride + lk;
+#pragma unroll 4
+        for (int ks = 0; ks < kW1Chunk / 4; ++ks) {
+            float a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                a[i] = a_base[i * 16 * kW1Stride + ks * 4];
+                b[i] = b_base[i * 16 * kW1Stride + ks * 4];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // lane holds D[co = 4*lk + e][ci = li] of each 16 x 16 sub-tile
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_base + wr * 48 + i * 16 + 4 * lk + e;
+                const int ci = ci_base + wc * 48 + j * 16 + li;
+                if (co < p.cout && ci < p.cin) atomicAdd(p.dw + static_cast<int64_t>(co) * p.cin + ci, acc[i][j][e]);
+            }
+}
+
+inline int launch_wgrad1x1(const WgradParams& p, hipStream_t stream) {
+    const int tiles_co = (p.cout + kW1Tile - 1) / kW1Tile;
+    const int tiles_ci = (p.cin + kW1Tile - 1) / kW1Tile;
+    const int plane = p.h * p.w;
+    const int chunks_total = ((plane + kW1Chunk - 1) / kW1Chunk) * p.n;
+    int splits = 768 / (tiles_co * tiles_ci);
+    if (splits < 1) splits = 1;
+    if (splits > chunks_total) splits = chunks_total;
+    wgrad1x1_mfma_kernel<<<dim3(splits, tiles_co, tiles_ci), kConvThreads, 0, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
