@@ -64,7 +64,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     const int tile = blockIdx.x;
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
-    const int co_base = blockIdx.y * NB;
+    const int co_base = p.ksplit > 0 ? 0 : blockIdx.y * NB;
     const int n = blockIdx.z;
 
     // ---------------- prologue: per-channel constants (identical to conv_mfma_kernel) ----------------
@@ -148,7 +148,15 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     const float* in_n = p.in + n * p.in_ns;
     const float* pad_in = g_pad_consts + (IN == IN_BNRELU ? 0 : 4);
     const float* pad_zero = g_pad_consts + 4;
-    const int nchunks = (p.cin + KC - 1) / KC;
+    const int nchunks_all = (p.cin + KC - 1) / KC;
+    int chunk_begin = 0, nchunks = nchunks_all;
+    ConvParams po = p;
+    if (p.ksplit > 0) {          // this block's slice of the K loop
+        const int per = (nchunks_all + p.ksplit - 1) / p.ksplit;
+        chunk_begin = blockIdx.y * per;
+        nchunks = min(nchunks_all, chunk_begin + per);
+        po.out = p.out + blockIdx.y * p.split_stride;
+    }
 
     auto issue_dma = [&](int chunk, int buf) {
         const int c_base = chunk * KC;
@@ -284,30 +292,32 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
         }
     };
 
-    issue_dma(0, 0);
+    issue_dma(chunk_begin, 0);
     if constexpr (kInPlace) {
         // pipeline: [DMA(c+1) -> other buffer] [MFMAs(c)] [own DMA(c+1) landed -> transform own values] [barrier]
         __syncthreads();                              // s_aux (BN constants) visible
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        transform_own(0, 0);
+        transform_own(chunk_begin, 0);
         __syncthreads();
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            if (chunk + 1 < nchunks) issue_dma(chunk + 1, (chunk + 1) & 1);
-            compute(chunk, chunk & 1);
+        for (int chunk = chunk_begin; chunk < nchunks; ++chunk) {
+            const int b = (chunk - chunk_begin) & 1;
+            if (chunk + 1 < nchunks) issue_dma(chunk + 1, b ^ 1);
+            compute(chunk, b);
             if (chunk + 1 < nchunks) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                transform_own(chunk + 1, (chunk + 1) & 1);
+                transform_own(chunk + 1, b ^ 1);
             }
             __syncthreads();
         }
     } else {
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
+        for (int chunk = chunk_begin; chunk < nchunks; ++chunk) {
+            const int b = (chunk - chunk_begin) % NBUF;
             // own DMA of this chunk has landed; after the barrier everybody's has, and everybody has
             // finished reading the other buffer (chunk - 1), so it can be refilled
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (NBUF == 2 && chunk + 1 < nchunks) issue_dma(chunk + 1, (chunk + 1) & 1);
-            compute(chunk, chunk % NBUF);
+            if (NBUF == 2 && chunk + 1 < nchunks) issue_dma(chunk + 1, b ^ 1);
+            compute(chunk, b);
             if (NBUF == 1 && chunk + 1 < nchunks) {      // single buffer: refill only once everybody is done reading
                 __syncthreads();
                 issue_dma(chunk + 1, 0);
@@ -362,7 +372,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             return;
         }
     }
-    conv_epilogue<Q, EPI, R>(p, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
+    conv_epilogue<Q, EPI, R>(po, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
 }
 
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0>
@@ -373,7 +383,7 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = (IN == IN_BNRELU) ? ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16 : 0;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
-    dim3 grid(p.tiles_x * tiles_y, (p.cout + 16 * Q - 1) / (16 * Q), p.n);
+    dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (p.cout + 16 * Q - 1) / (16 * Q), p.n);
     const size_t smem = S::bytes(p.bn_cap);
     static size_t configured = 0;
     if (smem > 48 * 1024 && smem > configured) {

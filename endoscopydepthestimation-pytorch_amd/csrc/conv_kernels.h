@@ -80,6 +80,10 @@ struct ConvParams {
     double* bn_scratch;      // [cout][2] sum dz, sum dz*xhat
     int acc_from;            // output channels >= acc_from accumulate into `out`, others overwrite
     int bn_cap;              // LDS-DMA kernels: capacity (channels) of the BN constant tables, set by the launcher
+    // split-K (coarse levels): blockIdx.y = slice of the input channels; slice s writes its raw partial sums at
+    // out + s * split_stride (bias / statistics are applied by finalize_partial_kernel)
+    int ksplit;
+    int64_t split_stride;
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

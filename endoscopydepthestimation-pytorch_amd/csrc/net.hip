@@ -95,6 +95,7 @@ struct endo_net {
     int64_t sums_off;      // fp64 per-channel sums (byte offset, 8-aligned)
     int64_t sums_bytes;
     int64_t tape_floats;
+    int64_t partial_off;   // split-K partial sums of the coarse-level dense layers (floats, tape)
     int64_t pq_off;        // floats, gradws: P then Q per level channel
     int64_t pq_floats;
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
@@ -158,6 +159,25 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const
             pq_q[c] += static_cast<float>(-scale * s1 / count + k * mean);
         }
     }
+}
+
+// split-K epilogue of the coarse-level dense layers: out = bias + sum over K slices of the partial sums,
+// plus the per-channel sum / sum^2 that later BN layers need.  grid (x blocks, channel, sample).
+__global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __restrict__ partial, int64_t split_stride, int ksplit,
+                                                               int64_t pns, int plane, const float* __restrict__ bias,
+                                                               float* __restrict__ out, int64_t out_ns, double* out_sums) {
+    __shared__ double scratch[2 * 4];
+    const int c = blockIdx.y, n = blockIdx.z;
+    const float b = bias[c];
+    float part[2] = {0.f, 0.f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        float v = b;
+        for (int s = 0; s < ksplit; ++s) v += partial[s * split_stride + n * pns + static_cast<int64_t>(c) * plane + i];
+        out[n * out_ns + static_cast<int64_t>(c) * plane + i] = v;
+        part[0] += v;
+        part[1] += v * v;
+    }
+    block_sum_atomic<2>(part, out_sums + 2 * c, scratch);
 }
 
 // final 1x1 conv 192 -> 1 and |.| (reference models.py:186).  HBM-bound: reads each plane once.
@@ -302,6 +322,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
+    const auto& lv = c.net->lv[level];
     ConvParams p{};
     fill_grid(c, p, level);
     fill_in(c, p, c.act(level), level, ic0, cv.cin);
@@ -310,7 +331,34 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     fill_out(c, p, c.act(level), level, oc0, cv.cout);
     p.out_sums = c.sums(level) + 2 * oc0;
     ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
-                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout));
+                   4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+    // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over
+    // blockIdx.y, write raw partial sums, and let a small kernel add them up (+ bias, + BN statistics).
+    // Scratch bound: slices * N * plane <= (512 / tiles + 1) * N * plane <= 65536 + 32768 floats per channel.
+    const long tiles_big = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.net->n;
+    const long tiles_mid = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 15) / 16) * c.net->n;
+    const long tiles_small = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 7) / 8) * c.net->n;
+    const int nchunks = (cv.cin + 15) / 16;
+    if (tiles_big < 512 && tiles_mid < 384 && tiles_small < 256 && nchunks >= 4) {
+        int want = static_cast<int>((512 + tiles_small - 1) / tiles_small);
+        if (want > nchunks) want = nchunks;
+        const int per = (nchunks + want - 1) / want;
+        const int ksplit = (nchunks + per - 1) / per;
+        float* partial = c.tape + c.net->partial_off;
+        p.ksplit = ksplit;
+        p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;
+        p.out = partial; p.out_ns = static_cast<int64_t>(cv.cout) * lv.plane;
+        p.bias = nullptr; p.out_sums = nullptr;
+        int rc = launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
+        if (rc) return rc;
+        int bx = static_cast<int>((lv.plane + 255) / 256);
+        bx = bx > 8 ? 8 : bx;
+        finalize_partial_kernel<<<dim3(bx, cv.cout, c.net->n), 256, 0, c.stream>>>(
+            partial, p.split_stride, ksplit, p.out_ns, static_cast<int>(lv.plane), c.params + cv.b, c.act(level) + oc0 * lv.plane,
+            lv.t * lv.plane, c.sums(level) + 2 * oc0);
+        ENDO_LAUNCH_CHECK();
+        return 0;
+    }
     return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
 }
 
@@ -456,7 +504,7 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin / 4.0 + cv.cout));
-        rc = launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
+        rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
     ConvParams p{};
@@ -503,6 +551,8 @@ extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
     net->sums_off = byte_off;
     net->sums_bytes = sums * 8;
     byte_off += align_up(net->sums_bytes, 256);
+    net->partial_off = byte_off / 4;
+    byte_off += static_cast<int64_t>(kGrowth) * 98304 * 4;      // bound: see dense_fwd
     net->tape_floats = byte_off / 4;
     net->pq_off = acts;
     net->pq_floats = 2 * pq;
@@ -640,6 +690,6 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
         p.dw = grads + tb.first.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * lv.plane * (3 + kFirst));
-        return wgrad_taps_ok(p) ? launch_wgrad_taps<48, IN_PLAIN>(p, c.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
+        return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, c.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
     }
 }

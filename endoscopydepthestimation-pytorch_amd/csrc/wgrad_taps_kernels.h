@@ -37,12 +37,13 @@ struct WgradTapsGeom {
     static constexpr size_t kRed = 4 * kMG * 256;             // cross-wave reduction scratch (floats)
     static constexpr size_t kFloats = (2 * kBuf > static_cast<int>(kRed) ? 2 * kBuf : kRed) + 64;
     static constexpr size_t kBytes = sizeof(float) * kFloats;
+    static_assert(kBytes <= 160 * 1024, "two tile buffers must fit the 160 KiB LDS");
 };
 
 template <int COUT, int IN>
 __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradParams p) {
     using G = WgradTapsGeom<COUT>;
-    static_assert(IN == IN_BNRELU || IN == IN_PLAIN, "16-byte DMA needs contiguous sources");
+    static_assert(IN == IN_BNRELU || IN == IN_PLAIN || IN == IN_UPSAMPLE, "supported activation load paths");
     constexpr int MG = G::kMG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_cst = smem + G::kFloats - 64;       // scale, mean, beta of the block's 16 channels
@@ -53,6 +54,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
     const int li = lane & 15;
     const int lk = lane >> 4;
     const int ci_base = blockIdx.x * 16;
+    const int co_base = blockIdx.z * COUT;          // wider convs (48 outputs) run as several COUT-wide slices
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int tiles_total = tiles_per_sample * p.n;
 
@@ -92,7 +94,24 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         const int y0 = (trem / p.tiles_x) * G::kTY;
         float* s_in = smem + buf * G::kBuf;
         float* s_dy = s_in + 16 * G::kCS;
-        {   // activations: 16 channels x 64 float4, thread -> (row, 4-pixel group) of the tile
+        if constexpr (IN == IN_UPSAMPLE) {
+            // nearest x2 gather: one dword per output pixel, 4 issues per channel; wave w moves channels w, w+4, ...
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = wave + 4 * k;
+                const int ch = ci_base + c;
+                const float* plane = p.in + n * p.in_ns + static_cast<int64_t>(ch) * p.in_cs;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = q * 64 + lane;
+                    const int ry = e / G::kTX, rx = e % G::kTX;
+                    const int gy = y0 + ry, gx = x0 + rx;
+                    const bool ok = gy < p.h && gx < p.w && ch < p.cin;
+                    const float* src = ok ? plane + (gy >> 1) * p.in_w + (gx >> 1) : pad_zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + c * G::kCS + q * 64), 4, 0, 0);
+                }
+            }
+        } else {   // activations: 16 channels x 64 float4, thread -> (row, 4-pixel group) of the tile
             const int e = tid & 63;            // unit inside a channel: wave w handles channels w, w+4, ...
             const int ry = e / (G::kTX / 4), rx = (e % (G::kTX / 4)) * 4;
             const int gy = y0 + ry, gx = x0 + rx;
@@ -110,8 +129,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
 #pragma unroll
         for (int k = 0; k < (COUT + 3) / 4; ++k) {
             const int co = wave + 4 * k;
-            if (co < COUT) {
-                const float* map = p.dy + n * p.dy_ns + static_cast<int64_t>(co) * p.dy_cs;
+            if (co < COUT && co_base + co < p.cout) {
+                const float* map = p.dy + n * p.dy_ns + static_cast<int64_t>(co_base + co) * p.dy_cs;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int u = half * 64 + lane;
@@ -182,8 +201,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         const int m = 16 * g + 4 * (ln >> 4) + e;
         const int ci = ci_base + (ln & 15);
         if (m < G::kM && ci < p.cin) {
-            const int co = m / 9, tap = m - co * 9;
-            atomicAdd(p.dw + (static_cast<int64_t>(co) * p.cin + ci) * 9 + tap, v);
+            const int co = co_base + m / 9, tap = m % 9;
+            if (co < p.cout) atomicAdd(p.dw + (static_cast<int64_t>(co) * p.cin + ci) * 9 + tap, v);
         }
     }
 }
@@ -194,9 +213,10 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
     p.tiles_x = (p.w + G::kTX - 1) / G::kTX;
     p.tiles_y = (p.h + G::kTY - 1) / G::kTY;
     const int ci_chunks = (p.cin + 15) / 16;
+    const int co_sets = (p.cout + COUT - 1) / COUT;
     const int tiles_total = p.tiles_x * p.tiles_y * p.n;
     // 2 blocks fit a CU (LDS): aim at exactly one round of 512 equally loaded blocks
-    int groups = 512 / ci_chunks;
+    int groups = 512 / (ci_chunks * co_sets);
     if (groups < 1) groups = 1;
     if (groups > tiles_total) groups = tiles_total;
     static bool configured = false;
@@ -205,14 +225,17 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
-    wgrad_taps_kernel<COUT, IN><<<dim3(ci_chunks, groups, 1), kConvThreads, G::kBytes, stream>>>(p);
+    wgrad_taps_kernel<COUT, IN><<<dim3(ci_chunks, groups, co_sets), kConvThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
-inline bool wgrad_taps_ok(const WgradParams& p) {
-    return (p.w % 4 == 0) && (p.in_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) &&
-           (p.dy_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.in) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0);
+// upsampled = the activation operand is gathered (dword DMA), only dY needs float4 alignment
+inline bool wgrad_taps_ok(const WgradParams& p, bool upsampled = false) {
+    const bool dy_ok = (p.w % 4 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) &&
+                       (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0);
+    const bool in_ok = upsampled || ((p.in_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.in) % 16 == 0));
+    return dy_ok && in_ok;
 }
 
 }  // namespace endo
