@@ -51,6 +51,16 @@ __device__ __forceinline__ void block_sum_atomic(const float (&part)[K], double*
     __syncthreads();
 }
 
+// XCD-aware block -> work-item remap.  Workgroup b is observed to run on XCD b % 8 (8 XCDs, each with a
+// private 4 MiB L2; MI355X_MICROARCH.md).  Giving XCD k the contiguous range [k*T/8, (k+1)*T/8) of a
+// row-major tile grid puts horizontally / vertically adjacent tiles -- which share halo cache lines --
+// behind the same L2.  Purely a locality hint: the map is a bijection on [0, T) for any T.
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+    const int xcd = b & 7, idx = b >> 3;
+    const int q = total >> 3, r = total & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
 // live profiling hooks (prof.hip)
 struct ProfScope {
     int family;

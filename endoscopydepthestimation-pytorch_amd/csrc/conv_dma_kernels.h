@@ -61,7 +61,9 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile = blockIdx.x;
+    // blockIdx.x is the fastest-varying dispatch index; when the tile count is a multiple of 8 the XCD of a
+    // block is blockIdx.x % 8 for every (y, z) slice, and the remap keeps neighbouring tiles on one XCD
+    const int tile = (gridDim.x & 7) == 0 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
     const int co_base = p.ksplit > 0 ? 0 : blockIdx.y * NB;

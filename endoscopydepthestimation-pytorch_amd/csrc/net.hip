@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "dgrad_kernels.h"
+#include "dgrad_block_kernels.h"
 #include "wgrad_taps_kernels.h"
 
 namespace endo {
@@ -232,22 +233,35 @@ __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __rest
     }
 }
 
-// dw[c] += sum g * u[c]; channel index cin is the bias (sum g)
+// dw[c] += sum g * u[c]; channel index cin is the bias (sum g).  grid (cin + 1, slices, n): float4 streaming,
+// two independent accumulators; g = gout * sign(pre) is recomputed from two L2-resident planes.
 __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                                const float* __restrict__ u, int64_t ns, int plane, int cin,
                                                                int nsamples, float* __restrict__ gw, float* __restrict__ gb) {
     __shared__ double scratch[4];
     const int c = blockIdx.x;
-    const int64_t total = static_cast<int64_t>(nsamples) * plane;
-    float part[1] = {0.f};
-    for (int64_t e = static_cast<int64_t>(blockIdx.y) * blockDim.x + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.y) * blockDim.x) {
-        const int n = static_cast<int>(e / plane);
-        const int i = static_cast<int>(e - static_cast<int64_t>(n) * plane);
-        const float g = gout[e] * sign_of(pre[e]);
-        part[0] += (c < cin) ? g * u[n * ns + static_cast<int64_t>(c) * plane + i] : g;
+    const int n = blockIdx.z;
+    (void)nsamples;
+    const float* gp = gout + static_cast<int64_t>(n) * plane;
+    const float* pp = pre + static_cast<int64_t>(n) * plane;
+    const float* up = u + n * ns + static_cast<int64_t>(c < cin ? c : 0) * plane;
+    float part = 0.f, part2 = 0.f;
+    if ((plane & 3) == 0) {
+        const int stride = gridDim.y * blockDim.x * 4;
+        for (int i = (blockIdx.y * blockDim.x + threadIdx.x) * 4; i < plane; i += stride) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + i);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pp + i);
+            f32x4 uv = {1.f, 1.f, 1.f, 1.f};
+            if (c < cin) uv = *reinterpret_cast<const f32x4*>(up + i);
+            part += gv[0] * sign_of(pv[0]) * uv[0] + gv[1] * sign_of(pv[1]) * uv[1];
+            part2 += gv[2] * sign_of(pv[2]) * uv[2] + gv[3] * sign_of(pv[3]) * uv[3];
+        }
+    } else {
+        for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < plane; i += gridDim.y * blockDim.x)
+            part += gp[i] * sign_of(pp[i]) * (c < cin ? up[i] : 1.f);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double v = wave_sum(static_cast<double>(part[0]));
+    double v = wave_sum(static_cast<double>(part + part2));
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -405,12 +419,17 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad)
     return 0;
 }
 
-static int bn_finalize(const Ctx& c, const BnP& b, int level, int ic0) {
+// BN parameter gradients + deferred dx terms for channels [first, first + count) of the layer's input
+// (ic0 = level-buffer channel of the layer's first input channel)
+static int bn_finalize(const Ctx& c, const BnP& b, int level, int ic0, int first = 0, int count = -1) {
     const auto& lv = c.net->lv[level];
+    if (count < 0) count = b.c - first;
+    if (count <= 0) return 0;
     ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
-    bn_bwd_finalize_kernel<<<(b.c + 127) / 128, 128, 0, c.stream>>>(c.scratch(b), c.saved(b), c.params + b.g, c.grads + b.g,
-                                                                     c.grads + b.b, c.pq_p(level) + ic0, c.pq_q(level) + ic0, b.c,
-                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+    bn_bwd_finalize_kernel<<<(count + 127) / 128, 128, 0, c.stream>>>(c.scratch(b) + 2 * first, c.saved(b) + 2 * first, c.params + b.g + first,
+                                                                       c.grads + b.g + first, c.grads + b.b + first,
+                                                                       c.pq_p(level) + ic0 + first, c.pq_q(level) + ic0 + first, count,
+                                                                       static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -422,22 +441,25 @@ static void fill_wgrad_grid(const Ctx& c, WgradParams& p, int level) {
     p.tiles_y = (lv.h + kWgTileY - 1) / kWgTileY;
 }
 
+static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
+    const auto& lv = c.net->lv[level];
+    WgradParams p{};
+    fill_wgrad_grid(c, p, level);
+    p.in = c.act(level) + ic0 * lv.plane; p.in_ns = lv.t * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = cv.cin;
+    p.saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b;
+    p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
+    p.dw = c.grads + cv.w;
+    ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+    return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
+}
+
 // dense layer backward: bias grad + deferred-term fold, wgrad, dgrad fused with ReLU/BN backward
 static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv, int acc_from) {
     const auto& lv = c.net->lv[level];
     int rc = prep_dy(c, level, oc0, cv.cout, c.grads + cv.b);
     if (rc) return rc;
-    {
-        WgradParams p{};
-        fill_wgrad_grid(c, p, level);
-        p.in = c.act(level) + ic0 * lv.plane; p.in_ns = lv.t * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = cv.cin;
-        p.saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b;
-        p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
-        p.dw = c.grads + cv.w;
-        ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
-        rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
-        if (rc) return rc;
-    }
+    rc = dense_wgrad(c, level, ic0, oc0, b, cv);
+    if (rc) return rc;
     {
         ConvParams p{};
         fill_grid(c, p, level);
@@ -453,6 +475,84 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         if (rc) return rc;
     }
     return bn_finalize(c, b, level, ic0);
+}
+
+// Backward of a whole dense block (4 layers) whose input ("base") is level-buffer channels [ic0, ic0 + c0)
+// and whose 4 x 12 new maps follow at [ic0 + c0, ic0 + c0 + 48).  base_overwrite: the base channels have
+// no gradient yet (first writer) instead of accumulating.
+//   fine levels : per layer (last to first) prep + wgrad + a dgrad restricted to the NEW channels the layer
+//                 reads (they carry the layer-to-layer dependency); then ONE fused dgrad for the base channels
+//                 of all four layers (dgrad_block_kernels.h) -- 3x less HBM traffic than four full dgrads
+//   coarse levels: the per-layer path (few tiles: parallelism comes from splitting channels over blocks)
+static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* bn, const ConvP* cv, bool base_overwrite) {
+    const auto& lv = c.net->lv[level];
+    const int new0 = ic0 + c0;
+    DgradBlockParams probe{};
+    probe.w = lv.w; probe.cs = static_cast<int>(lv.plane); probe.ns = lv.t * lv.plane;
+    probe.x = c.act(level) + ic0 * lv.plane; probe.out = c.gbuf(level) + ic0 * lv.plane;
+    const long tiles = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 5) / 6) * c.net->n;
+    if (!dgrad_block_ok(probe) || tiles < 256) {
+        for (int j = kLayers - 1; j >= 0; --j) {
+            const int acc_from = (j == kLayers - 1 && base_overwrite) ? new0 : 0;
+            int rc = dense_bwd(c, level, ic0, new0 + kGrowth * j, bn[j], cv[j], acc_from < ic0 ? ic0 : acc_from);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    auto fill_common = [&](DgradBlockParams& p) {
+        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+        p.g_ns = lv.t * lv.plane; p.g_cs = static_cast<int>(lv.plane); p.g_w = lv.w;
+        p.ns = lv.t * lv.plane; p.cs = static_cast<int>(lv.plane);
+    };
+    for (int j = kLayers - 1; j >= 0; --j) {
+        int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b);
+        if (rc) return rc;
+        rc = dense_wgrad(c, level, ic0, new0 + kGrowth * j, bn[j], cv[j]);
+        if (rc) return rc;
+        if (j > 0) {   // gradient into the new maps of layers 0..j-1 (always accumulates: a later consumer wrote them first)
+            DgradBlockParams p{};
+            fill_common(p);
+            p.g = c.gbuf(level) + (new0 + kGrowth * j) * lv.plane;
+            p.x = c.act(level) + new0 * lv.plane;
+            p.out = c.gbuf(level) + new0 * lv.plane;
+            p.count = kGrowth * j;
+            p.acc_from = 0;
+            p.w_ci_off = c0;
+            p.wgt[0] = c.params + cv[j].w; p.w_cin[0] = cv[j].cin;
+            p.saved[0] = c.saved(bn[j]) + 2 * c0; p.gamma[0] = c.params + bn[j].g + c0; p.beta[0] = c.params + bn[j].b + c0;
+            p.scratch[0] = c.scratch(bn[j]) + 2 * c0;
+            ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.net->n * lv.plane * p.count * kGrowth * 9,
+                           4.0 * c.net->n * lv.plane * (3.0 * p.count + kGrowth));
+            rc = launch_dgrad_block<1, 2, 3>(p, c.stream);
+            if (rc) return rc;
+            rc = bn_finalize(c, bn[j], level, ic0, c0, kGrowth * j);
+            if (rc) return rc;
+        }
+    }
+    {   // base channels, all four layers in one pass
+        DgradBlockParams p{};
+        fill_common(p);
+        p.g = c.gbuf(level) + new0 * lv.plane;
+        p.x = c.act(level) + ic0 * lv.plane;
+        p.out = c.gbuf(level) + ic0 * lv.plane;
+        p.count = c0;
+        p.acc_from = base_overwrite ? c0 : 0;
+        p.w_ci_off = 0;
+        for (int j = 0; j < kLayers; ++j) {
+            p.wgt[j] = c.params + cv[j].w; p.w_cin[j] = cv[j].cin;
+            p.saved[j] = c.saved(bn[j]); p.gamma[j] = c.params + bn[j].g; p.beta[j] = c.params + bn[j].b;
+            p.scratch[j] = c.scratch(bn[j]);
+        }
+        ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.net->n * lv.plane * c0 * kGrowth * 9 * kLayers,
+                       4.0 * c.net->n * lv.plane * (3.0 * c0 + kGrowth * kLayers));
+        int rc = launch_dgrad_block<4, 2, 3>(p, c.stream);
+        if (rc) return rc;
+    }
+    for (int j = 0; j < kLayers; ++j) {
+        int rc = bn_finalize(c, bn[j], level, ic0, 0, c0);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
@@ -649,36 +749,29 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         int bx = static_cast<int>((lv.plane + 255) / 256);
         final_bwd_data_kernel<<<dim3(bx, net->n), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
                                                                       lv.t * lv.plane, static_cast<int>(lv.plane), 192);
-        int by = static_cast<int>((static_cast<int64_t>(net->n) * lv.plane + 256 * 64 - 1) / (256 * 64));
-        by = by < 1 ? 1 : (by > 64 ? 64 : by);
-        final_bwd_weight_kernel<<<dim3(193, by), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
+        int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
+        by = by < 1 ? 1 : (by > 16 ? 16 : by);
+        final_bwd_weight_kernel<<<dim3(193, by, net->n), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
                                                                      static_cast<int>(lv.plane), 192, net->n, grads + tb.final_.w,
                                                                      grads + tb.final_.b);
         ENDO_LAUNCH_CHECK();
     }
     for (int i = kLevels - 1; i >= 0; --i) {
         const int l = kLevels - 1 - i;
-        for (int j = kLayers - 1; j >= 0; --j) {
-            const int acc_from = (j == kLayers - 1 && l > 0) ? 96 + down_in(l) : 0;
-            rc = dense_bwd(c, l, 0, 96 + down_in(l) + kGrowth * j, tb.up_bn[i][j], tb.up_conv[i][j], acc_from);
-            if (rc) return rc;
-        }
+        rc = dense_block_bwd(c, l, 0, 96 + down_in(l), tb.up_bn[i], tb.up_conv[i], l > 0);
+        if (rc) return rc;
         const int src = l + 1;
         const int src_c0 = (i == 0) ? 288 : 96 + down_in(src);
         rc = tu_bwd(c, l, src, src_c0, tb.tu_conv[i]);
         if (rc) return rc;
     }
-    for (int j = kLayers - 1; j >= 0; --j) {
-        rc = dense_bwd(c, kLevels, 0, 288 + kGrowth * j, tb.bott_bn[j], tb.bott_conv[j], j == kLayers - 1 ? 288 : 0);
-        if (rc) return rc;
-    }
+    rc = dense_block_bwd(c, kLevels, 0, 288, tb.bott_bn, tb.bott_conv, true);
+    if (rc) return rc;
     for (int l = kLevels - 1; l >= 0; --l) {
         rc = td_bwd(c, l, tb.td_bn[l], tb.td_conv[l]);
         if (rc) return rc;
-        for (int j = kLayers - 1; j >= 0; --j) {
-            rc = dense_bwd(c, l, 48, 48 + down_in(l) + kGrowth * j, tb.down_bn[l][j], tb.down_conv[l][j], 48);
-            if (rc) return rc;
-        }
+        rc = dense_block_bwd(c, l, 48, down_in(l), tb.down_bn[l], tb.down_conv[l], false);
+        if (rc) return rc;
     }
     {   // first conv: bias grad + weight grad (the image needs no gradient)
         rc = prep_dy(c, 0, 48, kFirst, grads + tb.first.b);

@@ -53,7 +53,17 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15;
     const int lk = lane >> 4;
-    const int ci_base = blockIdx.x * 16;
+    // Blocks that work on the same tiles (all input-channel slices of one tile group) re-read the same dY
+    // tiles: keep them on one XCD so the re-reads hit its L2.  Flattened id b = x + gridDim.x * y runs on
+    // XCD b % 8; slices of tile group (b % 8 + 8 * k) are laid out along b / 8.
+    int slice = blockIdx.x, group = blockIdx.y;
+    if ((gridDim.y & 7) == 0) {
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, idx = b >> 3;
+        slice = idx % gridDim.x;
+        group = xcd + 8 * (idx / gridDim.x);
+    }
+    const int ci_base = slice * 16;
     const int co_base = blockIdx.z * COUT;          // wider convs (48 outputs) run as several COUT-wide slices
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int tiles_total = tiles_per_sample * p.n;
@@ -154,7 +164,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
 
     const int rows_per_wave = G::kTY / 4;      // 2
 
-    int tile = blockIdx.y;
+    int tile = group;
     if (tile < tiles_total) issue_dma(tile, 0);
     int it = 0;
     for (; tile < tiles_total; tile += gridDim.y, ++it) {
@@ -219,6 +229,7 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
     int groups = 512 / (ci_chunks * co_sets);
     if (groups < 1) groups = 1;
     if (groups > tiles_total) groups = tiles_total;
+    if (groups >= 16) groups &= ~7;            // multiple of 8: enables the XCD-local block order
     static bool configured = false;
     if (!configured && G::kBytes > 48 * 1024) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<COUT, IN>), hipFuncAttributeMaxDynamicSharedMemorySize,
