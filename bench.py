@@ -73,6 +73,23 @@ def cpu_baseline(seconds_budget=25.0):
             "ms_per_step": median * 1e3}
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
+    serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
+    bench.py command).  None when there is no such file."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as fh:
+                entry = json.load(fh)["families"].get(family)
+        except (OSError, ValueError, KeyError):
+            continue
+        if entry:
+            return entry["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +194,8 @@ def main():
     dominant = max(MFMA_FAMILIES, key=lambda f: fam[f][0])
     ms, cnt, fl, by = fam[dominant]
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
+    dom_name = lib.endo_prof_family_name(dominant).decode()
+    traffic, traffic_src = pmc_traffic(dom_name)
     result = {
         "metric": "train frame-pairs/sec at 256x320 bs=8",
         "value": pairs / elapsed,
@@ -196,9 +215,11 @@ def main():
         "skipped_steps": skipped,
         "conv_roofline_frac_whole_step": (pairs / elapsed) * PAIR_GFLOP / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world),
         "depth_warp_fwd_bwd_ms_per_pair": warp_ms_per_pair,
-        "roofline": {"kernel": lib.endo_prof_family_name(dominant).decode(), "bound": "mfma", "achieved": achieved,
+        "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "launches": cnt, "avg_launch_ms": ms / cnt if cnt else None,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC 2*FETCH_SIZE+WRITE_SIZE)",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by / cnt if cnt else None,
+                     "launches": cnt, "avg_launch_ms": ms / cnt if cnt else None,
                      "algorithmic_gbs": by / ms / 1e6 if ms > 0 else None,
                      "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam[f][0] / args.steps for f in MFMA_FAMILIES}},
     }

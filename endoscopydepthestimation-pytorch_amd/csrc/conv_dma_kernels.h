@@ -25,11 +25,18 @@ __device__ __attribute__((aligned(16))) float g_pad_consts[8] = {__builtin_nanf(
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int KS, int KC, int Q, int WX, int R, int NBUF, int VEC>
+template <int KS, int KC, int Q, int WX, int R, int NBUF, int VEC, int IN = IN_PLAIN>
 struct ConvDmaSmem {
     using G = ConvGeom<KS, KC, WX, R, VEC>;
     static constexpr int kW = KS * KS * KC * 16 * Q;
-    static constexpr int kBuf = KC * G::kCS + kW;                 // floats per buffer
+    // IN_UNPOOL stages the POOLED gradient tile plus its argmax codes (4 one-byte codes per dword) and expands
+    // them when the A fragment is read; channel stride == 8 (mod 32): the 4 k-groups x 8 pooled columns of a
+    // fragment read hit 32 different banks
+    static constexpr int kUG = (G::kTileX / 2) * (G::kTileY / 2);
+    static constexpr int kUI = kUG / 4;
+    static constexpr int kUStride = ((kUG + kUI - 8 + 31) / 32) * 32 + 8;
+    static constexpr int kChan = (IN == IN_UNPOOL) ? kUStride : G::kCS;
+    static constexpr int kBuf = KC * kChan + kW;                  // floats per buffer
     static constexpr int kTail = 4 * 16 * Q + 8 * 16 * Q;       // dgrad constants + reduction scratch
     static size_t bytes(int bn_cap) { return sizeof(float) * (NBUF * kBuf + 3 * bn_cap + kTail); }
 };
@@ -43,11 +50,11 @@ struct ConvDmaSmem {
 // its own vmcnt(0) and before the barrier that publishes the chunk (no extra synchronisation).
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF>
 __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p) {
-    static_assert(IN != IN_UNPOOL, "UNPOOL needs a compare on load: use the register-staged kernel");
+    static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
-    static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE), "16-byte DMA needs contiguous sources");
+    static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL), "16-byte DMA needs contiguous sources");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
-    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC>;
+    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC, IN>;
     constexpr int KK = KS * KS;
     constexpr int NB = 16 * Q;
     constexpr int kWElems = S::kW;
@@ -147,6 +154,31 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             }
         }
     }
+    // IN_UNPOOL: this thread's slots of the [KC][kUStride] staging layout: pooled-plane offset (floats for the
+    // gradient, bytes for the codes; -1 = padding / out of image) and which array it comes from
+    constexpr int kUSlots = (IN == IN_UNPOOL) ? (KC * S::kUStride + kConvThreads - 1) / kConvThreads : 1;
+    int uoff[kUSlots];
+    if constexpr (IN == IN_UNPOOL) {
+        constexpr int PC = G::kTileX / 2;
+        const int ph = p.h >> 1, pw = p.w >> 1;
+#pragma unroll
+        for (int k = 0; k < kUSlots; ++k) {
+            const int e = tid + k * kConvThreads;
+            const int u = e % S::kUStride;
+            int off = -1;
+            if (e < KC * S::kUStride) {
+                if (u < S::kUG) {
+                    const int gy = (y0 >> 1) + u / PC, gx = (x0 >> 1) + u % PC;
+                    if (gy < ph && gx < pw) off = gy * p.in_w + gx;
+                } else if (u < S::kUG + S::kUI) {
+                    const int q = u - S::kUG;
+                    const int gy = (y0 >> 1) + q / (PC / 4), gx = (x0 >> 1) + 4 * (q % (PC / 4));
+                    if (gy < ph && gx < pw) off = gy * p.in_w + gx;       // pooled width % 4 == 0: a code dword is all in or all out
+                }
+            }
+            uoff[k] = off;
+        }
+    }
     const float* in_n = p.in + n * p.in_ns;
     const float* pad_in = g_pad_consts + (IN == IN_BNRELU ? 0 : 4);
     const float* pad_zero = g_pad_consts + 4;
@@ -163,9 +195,27 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     auto issue_dma = [&](int chunk, int buf) {
         const int c_base = chunk * KC;
         float* s_in = smem + buf * S::kBuf;
-        float* s_w = s_in + KC * G::kCS;
+        float* s_w = s_in + KC * S::kChan;
+        if constexpr (IN == IN_UNPOOL) {
+            const uint8_t* idx_n = p.in_idx + n * p.idx_ns;
 #pragma unroll
-        for (int c = 0; c < KC; ++c) {
+            for (int k = 0; k < kUSlots; ++k) {
+                const int e0 = k * kConvThreads + wave * 64;
+                if (e0 < KC * S::kUStride) {
+                    const int e = e0 + lane;
+                    const int ch = c_base + e / S::kUStride;
+                    const bool is_code = (e % S::kUStride) >= S::kUG;
+                    const void* src = pad_zero;
+                    if (uoff[k] >= 0 && ch < p.cin) {
+                        const int64_t o = static_cast<int64_t>(ch) * p.in_cs + uoff[k];
+                        src = is_code ? static_cast<const void*>(idx_n + o) : static_cast<const void*>(in_n + o);
+                    }
+                    if (e < KC * S::kUStride) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + e0), 4, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < (IN == IN_UNPOOL ? 0 : KC); ++c) {
             const int ch = c_base + c;
             const float* plane = in_n + static_cast<int64_t>(ch) * p.in_cs;
 #pragma unroll
@@ -261,7 +311,35 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
 
     auto compute = [&](int chunk, int buf) {
         const float* s_in = smem + buf * S::kBuf;
-        const float* s_w = s_in + KC * G::kCS;
+        const float* s_w = s_in + KC * S::kChan;
+        if constexpr (IN == IN_UNPOOL) {
+            // a[row][x] = g[row/2][x/2] if code[row/2][x/2] == 2*(row&1) + (x&1) else 0 (y0, wy and wx are even)
+            constexpr int PC = G::kTileX / 2;
+            const int pcol = (wx + li) >> 1;
+            const unsigned sh = 8u * (pcol & 3);
+            const unsigned want = li & 1;
+#pragma unroll
+            for (int quad = 0; quad < KC / 4; ++quad) {
+                const float* g_base = s_in + (quad * 4 + lk) * S::kUStride + (wy >> 1) * PC + pcol;
+                const unsigned* i_base = reinterpret_cast<const unsigned*>(s_in + (quad * 4 + lk) * S::kUStride + S::kUG);
+                const float* b_base = s_w + (quad * 4 + lk) * NB + li;
+                float a[R];
+#pragma unroll
+                for (int rr = 0; rr < R / 2; ++rr) {
+                    const float g = g_base[rr * PC];
+                    const unsigned code = (i_base[(((wy >> 1) + rr) * PC + pcol) >> 2] >> sh) & 0xffu;
+                    a[2 * rr] = code == want ? g : 0.f;
+                    a[2 * rr + 1] = code == want + 2u ? g : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const float b = b_base[q * 16];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b, acc[r][q], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int quad = 0; quad < KC / 4; ++quad) {
             const float* a_base = s_in + (quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li + G::kColOff;
@@ -381,7 +459,7 @@ template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int M
 inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     static_assert(XF == 0 || NBUF == 2 || IN != IN_BNRELU, "the in-place transform pipeline is written for two buffers");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
-    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC>;
+    using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC, IN>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = (IN == IN_BNRELU) ? ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16 : 0;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
@@ -401,7 +479,7 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
 // 16-byte DMA whenever the input rows are float4-aligned, dword DMA otherwise
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW = 1>
 inline int launch_conv_dma(const ConvParams& p, hipStream_t stream) {
-    if constexpr (IN != IN_UPSAMPLE) {
+    if constexpr (IN != IN_UPSAMPLE && IN != IN_UNPOOL) {
         const bool aligned = (p.w % 4 == 0) && (p.in_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
         if (aligned) return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 4>(p, stream);

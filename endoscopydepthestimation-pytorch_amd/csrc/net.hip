@@ -20,6 +20,7 @@
 #include "dgrad_kernels.h"
 #include "dgrad_block_kernels.h"
 #include "wgrad_taps_kernels.h"
+#include "wgrad1x1_kernels.h"
 
 namespace endo {
 
@@ -158,6 +159,40 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const
             const double k = scale * rstd * s2 / count;
             pq_p[c] += static_cast<float>(-k);
             pq_q[c] += static_cast<float>(-scale * s1 / count + k * mean);
+        }
+    }
+}
+
+// the same for the four BN layers of a dense block over the channels they share (the block's input): one launch,
+// one read-modify-write of P and Q
+struct BnFin4 {
+    const double* scratch[4];
+    const float* saved[4];
+    const float* gamma[4];
+    float* ggamma[4];
+    float* gbeta[4];
+};
+__global__ void bn_bwd_finalize4_kernel(const BnFin4 a, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
+                                        int training) {
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
+        double dp = 0.0, dq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double s1 = a.scratch[j][2 * c], s2 = a.scratch[j][2 * c + 1];
+            a.ggamma[j][c] += static_cast<float>(s2);
+            a.gbeta[j][c] += static_cast<float>(s1);
+            if (training) {
+                const double mean = a.saved[j][2 * c], rstd = a.saved[j][2 * c + 1];
+                const double scale = a.gamma[j][c] * rstd;
+                const double k = scale * rstd * s2 / count;
+                // same rounding sequence as four single-layer finalizes: each term is rounded to fp32 before it is added
+                dp += static_cast<double>(static_cast<float>(-k));
+                dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
+            }
+        }
+        if (training) {
+            pq_p[c] += static_cast<float>(dp);
+            pq_q[c] += static_cast<float>(dq);
         }
     }
 }
@@ -348,13 +383,13 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
                    4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
     // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over
     // blockIdx.y, write raw partial sums, and let a small kernel add them up (+ bias, + BN statistics).
-    // Scratch bound: slices * N * plane <= (512 / tiles + 1) * N * plane <= 65536 + 32768 floats per channel.
+    // Scratch bound: slices * N * plane <= (768 / tiles + 1) * 128 * tiles <= 98304 + 65536 floats per channel.
     const long tiles_big = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.net->n;
     const long tiles_mid = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 15) / 16) * c.net->n;
     const long tiles_small = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 7) / 8) * c.net->n;
     const int nchunks = (cv.cin + 15) / 16;
-    if (tiles_big < 512 && tiles_mid < 384 && tiles_small < 256 && nchunks >= 4) {
-        int want = static_cast<int>((512 + tiles_small - 1) / tiles_small);
+    if (tiles_big < 512 && tiles_mid < 384 && tiles_small < 512 && nchunks >= 4) {
+        int want = static_cast<int>(((tiles_small < 256 ? 512 : 768) + tiles_small - 1) / tiles_small);
         if (want > nchunks) want = nchunks;
         const int per = (nchunks + want - 1) / want;
         const int ksplit = (nchunks + per - 1) / per;
@@ -548,9 +583,16 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         int rc = launch_dgrad_block<4, 2, 3>(p, c.stream);
         if (rc) return rc;
     }
-    for (int j = 0; j < kLayers; ++j) {
-        int rc = bn_finalize(c, bn[j], level, ic0, 0, c0);
-        if (rc) return rc;
+    {
+        BnFin4 a;
+        for (int j = 0; j < kLayers; ++j) {
+            a.scratch[j] = c.scratch(bn[j]); a.saved[j] = c.saved(bn[j]); a.gamma[j] = c.params + bn[j].g;
+            a.ggamma[j] = c.grads + bn[j].g; a.gbeta[j] = c.grads + bn[j].b;
+        }
+        ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
+        bn_bwd_finalize4_kernel<<<(c0 + 127) / 128, 128, 0, c.stream>>>(a, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
+                                                                         static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+        ENDO_LAUNCH_CHECK();
     }
     return 0;
 }
@@ -571,7 +613,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.dy_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * cv.cin);
-        rc = launch_wgrad1x1(p, c.stream);
+        rc = wgrad1x1_dma_ok(p) ? launch_wgrad1x1_dma(p, c.stream) : launch_wgrad1x1(p, c.stream);
         if (rc) return rc;
     }
     {
@@ -586,7 +628,9 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.bn_scratch = c.scratch(b);
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * 3.0 * cv.cin);
-        rc = launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
+        // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
+        rc = (nx.w % 4 == 0) ? launch_conv_dma_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream)
+                             : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
         if (rc) return rc;
     }
     return bn_finalize(c, b, level, 48);
@@ -652,7 +696,7 @@ extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
     net->sums_bytes = sums * 8;
     byte_off += align_up(net->sums_bytes, 256);
     net->partial_off = byte_off / 4;
-    byte_off += static_cast<int64_t>(kGrowth) * 98304 * 4;      // bound: see dense_fwd
+    byte_off += static_cast<int64_t>(kGrowth) * 163840 * 4;     // bound: see dense_fwd
     net->tape_floats = byte_off / 4;
     net->pq_off = acts;
     net->pq_floats = 2 * pq;

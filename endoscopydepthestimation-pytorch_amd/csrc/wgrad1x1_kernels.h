@@ -1,0 +1,178 @@
+// Weight gradient of the transition-down 1x1 convolution (reference models.py:56-67: BN -> ReLU -> conv1x1 ->
+// [dropout] -> maxpool2) on the fp32 matrix cores, LDS-DMA staged:
+//
+//   dW[co][ci] += sum over full-resolution pixels  Gfull[co][p] * relu(bn(x[ci][p]))
+//
+// where Gfull is the max-pool un-routing of the pooled gradient G (non-zero only at the argmax position of each
+// 2x2 window).  Neither Gfull nor the activation is materialised: a chunk is one pooled row segment = 2 rows x 32
+// pixels, staged as raw x rows (64 dwords each), pooled G rows (16 dwords) and their argmax codes (4 dwords, one
+// byte per pooled pixel); un-routing (byte extract, compare, select) and BN+ReLU happen on the fragment read.
+// GEMM view: M = 96 cout, N = 96 cin per block (3 x 3 MFMA tiles per wave), K = pixels; a block walks a strided
+// subset of the chunks with two LDS buffers (one barrier per chunk) and ends with one fp32 atomic per dW element.
+// LDS rows: x stride 66 (== 2 mod 32) and G stride 21 (odd): both fragment reads are bank-conflict free.
+#pragma once
+
+#include "conv_dma_kernels.h"
+#include "wgrad_kernels.h"
+
+namespace endo {
+
+constexpr int kP1Tile = 96;
+constexpr int kP1Seg = 32;                       // pixels per row of a chunk
+constexpr int kP1ActStride = 2 * kP1Seg + 2;
+constexpr int kP1DyStride = kP1Seg / 2 + kP1Seg / 8 + 1;
+constexpr int kP1Buf = kP1Tile * (kP1ActStride + kP1DyStride);     // floats per buffer
+constexpr size_t kP1Bytes = 2 * kP1Buf * sizeof(float);
+
+__global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int co_base = blockIdx.y * kP1Tile;
+    const int ci_base = blockIdx.z * kP1Tile;
+    const int segs = (p.w + kP1Seg - 1) / kP1Seg;
+    const int chunks_per_sample = segs * (p.h >> 1);
+    const int chunks_total = chunks_per_sample * p.n;
+    const int wr = wave >> 1, wc = wave & 1;      // wave's 48 x 48 quadrant of the 96 x 96 tile
+
+    float sc[3], mn[3], bt[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int ch = ci_base + wc * 48 + j * 16 + li;
+        sc[j] = 0.f; mn[j] = 0.f; bt[j] = 0.f;       // rows past cin hold the NaN pad: max(fma(NaN, 0, 0), 0) = 0
+        if (ch < p.cin) {
+            mn[j] = p.saved[2 * ch];
+            sc[j] = p.gamma[ch] * p.saved[2 * ch + 1];
+            bt[j] = p.beta[ch];
+        }
+    }
+
+    f32x4 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane parts of the DMA sources
+    const int arow = lane >> 5, ax = lane & 31;
+    const bool dy_is_code = lane >= 16;
+    const int dcol = dy_is_code ? 4 * (lane - 16) : lane;              // pooled column inside the segment
+    const int64_t dstride = dy_is_code ? static_cast<int64_t>(p.dy_cs) : 4 * static_cast<int64_t>(p.dy_cs);   // bytes per channel
+    const char* pad_nan = reinterpret_cast<const char*>(g_pad_consts);
+    const char* pad_zero = reinterpret_cast<const char*>(g_pad_consts + 4);
+
+    auto issue = [&](int chunk, int buf) {
+        const int n = chunk / chunks_per_sample;
+        const int rem = chunk - n * chunks_per_sample;
+        const int y2 = rem / segs;
+        const int xs = (rem - y2 * segs) * kP1Seg;
+        float* s_act = smem + buf * kP1Buf;
+        float* s_dy = s_act + kP1Tile * kP1ActStride;
+        const bool a_ok = xs + ax < p.w;
+        const float* abase = p.in + n * p.in_ns + static_cast<int64_t>(2 * y2 + arow) * p.in_w + xs + ax;
+#pragma unroll 4
+        for (int t = 0; t < kP1Tile / 4; ++t) {
+            const int r = wave * (kP1Tile / 4) + t;
+            const int ch = ci_base + r;
+            const void* src = (a_ok && ch < p.cin) ? static_cast<const void*>(abase + static_cast<int64_t>(ch) * p.in_cs)
+                                                   : static_cast<const void*>(pad_nan);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_act + r * kP1ActStride), 4, 0, 0);
+        }
+        const int pxs = xs >> 1;
+        const bool d_ok = pxs + dcol < (p.w >> 1);
+        const int64_t poff = static_cast<int64_t>(y2) * p.dy_w + pxs + dcol;
+        const char* dbase = dy_is_code ? reinterpret_cast<const char*>(p.dy_idx + n * p.idx_ns + poff)
+                                       : reinterpret_cast<const char*>(p.dy + n * p.dy_ns + poff);
+#pragma unroll 4
+        for (int t = 0; t < kP1Tile / 4; ++t) {
+            const int r = wave * (kP1Tile / 4) + t;
+            const int co = co_base + r;
+            const char* src = (d_ok && co < p.cout) ? dbase + co * dstride : pad_zero;
+            if (lane < kP1Seg / 2 + kP1Seg / 8)
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + r * kP1DyStride), 4, 0, 0);
+        }
+    };
+
+    const unsigned lane_shift = 8u * (lk >> 1);
+    const unsigned lane_want = lk & 1;
+    auto compute = [&](int buf) {
+        const float* s_act = smem + buf * kP1Buf;
+        const float* s_dy = s_act + kP1Tile * kP1ActStride;
+        const float* g_base = s_dy + (wr * 48 + li) * kP1DyStride;
+        const float* b_base = s_act + (wc * 48 + li) * kP1ActStride + lk;
+        unsigned cw[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int d = 0; d < 4; ++d) cw[i][d] = __float_as_uint(g_base[i * 16 * kP1DyStride + kP1Seg / 2 + d]);
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+            // k = pixel 4*ks + lk of the chunk: row ks>>3, x = 4*(ks&7) + lk; pooled column x>>1, code 2*row + (x&1)
+            const int pc = 2 * (ks & 7) + (lk >> 1);
+            const unsigned want = 2u * (ks >> 3) + lane_want;
+            float a[3], b[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const float g = g_base[i * 16 * kP1DyStride + pc];
+                const unsigned code = (cw[i][(ks & 7) >> 1] >> (16u * (ks & 1) + lane_shift)) & 0xffu;
+                a[i] = code == want ? g : 0.f;
+                const float v = b_base[i * 16 * kP1ActStride + 4 * ks];
+                b[i] = __builtin_fmaxf(fmaf(v - mn[i], sc[i], bt[i]), 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int chunk = blockIdx.x;
+    if (chunk < chunks_total) issue(chunk, 0);
+    int b = 0;
+    for (; chunk < chunks_total; chunk += gridDim.x, b ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (chunk + static_cast<int>(gridDim.x) < chunks_total) issue(chunk + gridDim.x, b ^ 1);
+        compute(b);
+    }
+    // lane holds D[co = 4*lk + e][ci = li] of each 16 x 16 sub-tile
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_base + wr * 48 + i * 16 + 4 * lk + e;
+                const int ci = ci_base + wc * 48 + j * 16 + li;
+                if (co < p.cout && ci < p.cin) atomicAdd(p.dw + static_cast<int64_t>(co) * p.cin + ci, acc[i][j][e]);
+            }
+}
+
+// needs whole code dwords per pooled row segment (pooled width % 4 == 0) and even H, W
+inline bool wgrad1x1_dma_ok(const WgradParams& p) {
+    return (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.idx_ns % 4 == 0) && (p.h % 2 == 0) && (p.w % 2 == 0) &&
+           (reinterpret_cast<uintptr_t>(p.dy_idx) % 4 == 0);
+}
+
+inline int launch_wgrad1x1_dma(const WgradParams& p, hipStream_t stream) {
+    const int tiles_co = (p.cout + kP1Tile - 1) / kP1Tile;
+    const int tiles_ci = (p.cin + kP1Tile - 1) / kP1Tile;
+    const int chunks_total = ((p.w + kP1Seg - 1) / kP1Seg) * (p.h / 2) * p.n;
+    int splits = 512 / (tiles_co * tiles_ci);          // 2 blocks per CU (LDS)
+    if (splits < 1) splits = 1;
+    if (splits > chunks_total) splits = chunks_total;
+    static bool configured = false;
+    if (!configured) {
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(kP1Bytes)));
+        configured = true;
+    }
+    wgrad1x1_dma_kernel<<<dim3(splits, tiles_co, tiles_ci), kConvThreads, kP1Bytes, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace endo

@@ -23,5 +23,30 @@ def main():
                 r[0][:100], r[1], r[2] / 1e6, 100.0 * r[2] / total, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, r[6] or 0, r[7] or 0, r[8] or 0))
 
 
+def by_grid():
+    """usage: summarize_rocprof.py --by-grid <results.db> <out.txt>: one row per (kernel, grid) so that each
+    resolution level of the network shows up separately."""
+    db_path, out_path = sys.argv[2], sys.argv[3]
+    cur = sqlite3.connect(db_path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    gx = [c for c in ("grid_x", "grid_size_x") if c in cols]
+    gy = [c for c in ("grid_y", "grid_size_y") if c in cols]
+    gz = [c for c in ("grid_z", "grid_size_z") if c in cols]
+    wx = [c for c in ("workgroup_x", "workgroup_size_x") if c in cols]
+    if not gx:
+        raise SystemExit("no grid columns in %s" % cols)
+    key = "%s, %s, %s, %s" % (gx[0], gy[0], gz[0], wx[0])
+    rows = cur.execute("select name, %s, count(*), sum(end-start), avg(end-start) from kernels group by name, %s order by 7 desc" % (key, key)).fetchall()
+    total = sum(r[6] for r in rows)
+    with open(out_path, "w") as f:
+        f.write("# per (kernel, grid) summary; grid in work-items; total %.3f ms\n" % (total / 1e6))
+        f.write("%-90s %22s %6s %10s %6s %10s\n" % ("kernel", "grid(x,y,z)/wg", "calls", "total_ms", "pct", "avg_us"))
+        for r in rows:
+            f.write("%-90s %22s %6d %10.3f %6.2f %10.1f\n" % (r[0][:90], "%d,%d,%d/%d" % (r[1], r[2], r[3], r[4]), r[5], r[6] / 1e6, 100.0 * r[6] / total, r[7] / 1e3))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--by-grid":
+        by_grid()
+    else:
+        main()
