@@ -21,6 +21,7 @@
 #include "dgrad_block_kernels.h"
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
+#include "wgrad_nsplit_kernels.h"
 
 namespace endo {
 
@@ -102,6 +103,7 @@ struct endo_net {
     int64_t pq_floats;
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
     int64_t scratch_bytes;
+    int64_t wg_scratch_off;   // float offset in gradws of the weight-gradient partial sums (wgrad_nsplit_kernels.h)
     int64_t gradws_floats;
 };
 
@@ -485,6 +487,7 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream);
     return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }
 
@@ -702,7 +705,8 @@ extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
     net->pq_floats = 2 * pq;
     net->scratch_off = align_up((acts + net->pq_floats) * 4, 256);
     net->scratch_bytes = tb.bn_width_total * 2 * 8;
-    net->gradws_floats = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
+    net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
+    net->gradws_floats = net->wg_scratch_off + kNsScratchFloats;
     *out = net;
     return 0;
 }

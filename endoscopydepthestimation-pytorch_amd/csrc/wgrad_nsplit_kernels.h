@@ -1,0 +1,228 @@
+// 3x3 weight gradient of the growth-12 dense layers, input channels split over WAVES (full-resolution levels).
+//
+//   dW[co][ci][ky][kx] = sum_p a[ci][p] * dY[co][p - (ky-1, kx-1)]          (a = relu(bn(x)), zero outside)
+//
+// Same GEMM as wgrad_taps_kernels.h (M = (co, tap) = 108 rows -> 7 MFMA row groups, N = input channels,
+// K = pixels) but a block owns ALL input channels of a pass (4 waves x NG groups of 16) for its pixels:
+//   * every activation value is used by exactly one lane (B[k = pixel][j = ci]), so x never touches LDS: each
+//     lane loads its own 2 x 16 bytes per channel group straight into registers, one chunk ahead, and applies
+//     BN+ReLU there;
+//   * only the small operand -- 12 dY maps of a 3-row x 40-column window, 5.6 KiB -- is staged (LDS-DMA, two
+//     buffers, one barrier per chunk) and shared by the 4 waves: 7 LDS reads feed 7*NG MFMAs;
+//   * x and dY are read from HBM once per pass (the taps kernel re-reads the dY tile for every 16-channel slice);
+//   * no cross-wave reduction: a wave owns its (row group, channel group) accumulators.  Blocks own contiguous
+//     chunk ranges and write their partial sums to scratch (coalesced 256-byte rows); a small second kernel adds
+//     the partials and accumulates into the flat gradient -- no same-address atomic storm, and the sum over
+//     pixels is evaluated in a fixed order.
+// k <-> pixel mapping inside a 32-pixel chunk row: k-step ks, lane group lk -> pixel 16*(ks>>2) + 4*lk + (ks&3),
+// i.e. each lane's 8 pixels are two aligned float4s.
+#pragma once
+
+#include "conv_dma_kernels.h"
+#include "wgrad_kernels.h"
+
+namespace endo {
+
+constexpr int kNsSeg = 32;                         // pixels per chunk (one row segment)
+constexpr int kNsCols = kNsSeg + 8;                // dY window: 4-pixel aligned halo on both sides
+constexpr int kNsMap = 3 * kNsCols;                // floats per dY map window
+constexpr int kNsBuf = 12 * kNsMap + 64;           // + zero rows read by the unused M rows of the last group
+constexpr int kNsMG = 7;
+constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
+
+template <int NG>
+__global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradParams p, float* __restrict__ partial,
+                                                                    int chunks_per_block) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * kNsBuf];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int group0 = NG * (4 * blockIdx.y + wave);          // first 16-channel group of this wave
+    const int groups_total = NG * 4 * gridDim.y;
+    const int segs = (p.w + kNsSeg - 1) / kNsSeg;
+    const int chunks_total = segs * p.h * p.n;
+    const int c_begin = blockIdx.x * chunks_per_block;
+    const int c_end = min(c_begin + chunks_per_block, chunks_total);
+
+    float sc[NG], mn[NG], bt[NG];
+    bool ch_ok[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int ch = 16 * (group0 + g) + li;
+        ch_ok[g] = ch < p.cin;
+        sc[g] = 0.f; mn[g] = 0.f; bt[g] = 0.f;
+        if (ch_ok[g]) {
+            mn[g] = p.saved[2 * ch];
+            sc[g] = p.gamma[ch] * p.saved[2 * ch + 1];
+            bt[g] = p.beta[ch];
+        }
+    }
+
+    // per-lane gather offsets into the dY window: row m = 16 g + li = co * 9 + ky * 3 + kx reads
+    // dY[co][y + 1 - ky][x + 1 - kx]  ->  window row 2 - ky, window col x + 5 - kx
+    int aoff[kNsMG];
+#pragma unroll
+    for (int g = 0; g < kNsMG; ++g) {
+        const int m = 16 * g + li;
+        const int co = m / 9, tap = m - co * 9;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        aoff[g] = (m < 108) ? co * kNsMap + (2 - ky) * kNsCols + (5 - kx) + 4 * lk : 12 * kNsMap + 4 * lk;
+    }
+    for (int i = tid; i < 64; i += kConvThreads) {
+        smem[12 * kNsMap + i] = 0.f;
+        smem[kNsBuf + 12 * kNsMap + i] = 0.f;
+    }
+
+    f32x4 acc[NG][kNsMG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int m = 0; m < kNsMG; ++m) acc[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* pad_zero = g_pad_consts + 4;
+    f32x4 xr[NG][2];          // raw x of the chunk in flight
+    unsigned xr_ok = 0;       // bit q: this lane's float4 q is inside the image
+
+    auto issue = [&](int chunk, int buf) {
+        const int n = chunk / (segs * p.h);
+        const int rem = chunk - n * segs * p.h;
+        const int y = rem / segs;
+        const int x0 = (rem - y * segs) * kNsSeg;
+        float* s_dy = smem + buf * kNsBuf;
+        const float* dy_n = p.dy + n * p.dy_ns;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int e0 = k * kConvThreads + wave * 64;
+            if (e0 < kNsUnits) {
+                const int e = e0 + lane;
+                const int map = e / (kNsMap / 4);
+                const int r = e - map * (kNsMap / 4);
+                const int row = r / (kNsCols / 4), c4 = r - row * (kNsCols / 4);
+                const int gy = y - 1 + row, gx = x0 - 4 + 4 * c4;
+                const bool ok = e < kNsUnits && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+                const float* src = ok ? dy_n + static_cast<int64_t>(map) * p.dy_cs + gy * p.dy_w + gx : pad_zero;
+                if (e < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
+            }
+        }
+        const float* in_n = p.in + n * p.in_ns + static_cast<int64_t>(y) * p.in_w + x0 + 4 * lk;
+        xr_ok = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (x0 + 16 * q + 4 * lk < p.w) xr_ok |= 1u << q;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float* row = in_n + static_cast<int64_t>(16 * (group0 + g) + li) * p.in_cs;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                xr[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (ch_ok[g] && (xr_ok & (1u << q))) xr[g][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
+            }
+        }
+    };
+
+    if (c_begin < c_end) issue(c_begin, 0);
+    int buf = 0;
+    for (int chunk = c_begin; chunk < c_end; ++chunk, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // BN + ReLU of this chunk's activations (registers), then start the next chunk's loads
+        f32x4 bv[NG][2];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool ok = ch_ok[g] && (xr_ok & (1u << q));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[g][q][e] = ok ? __builtin_fmaxf(fmaf(xr[g][q][e] - mn[g], sc[g], bt[g]), 0.f) : 0.f;
+            }
+        if (chunk + 1 < c_end) issue(chunk + 1, buf ^ 1);
+
+        const float* s_dy = smem + buf * kNsBuf;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a[kNsMG];
+#pragma unroll
+                for (int m = 0; m < kNsMG; ++m) a[m] = s_dy[aoff[m] + 16 * q + e];
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int m = 0; m < kNsMG; ++m)
+                        acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[g][q][e], acc[g][m], 0, 0, 0);
+            }
+    }
+
+    // partial[((block * groups_total + group) * 7 + m) * 4 + r][lane] = D[row 16 m + 4 lk + r][ci = 16 group + li]
+    float* out = partial + (static_cast<int64_t>(blockIdx.x) * groups_total + group0) * (kNsMG * 256);
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int m = 0; m < kNsMG; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[((g * kNsMG + m) * 4 + r) * 64 + lane] = acc[g][m][r];
+}
+
+// grid (groups_total * 7, slices): thread (r, lane) of row block (group, m) adds the partials of its slice of blocks
+__global__ void __launch_bounds__(256) wgrad_nsplit_reduce_kernel(const float* __restrict__ partial, int blocks, int groups_total, int cin,
+                                                                  float* __restrict__ dw) {
+    const int gm = blockIdx.x;
+    const int group = gm / kNsMG, m7 = gm - group * kNsMG;
+    const int per = (blocks + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
+    const float* src = partial + (static_cast<int64_t>(group) * kNsMG + m7) * 256 + threadIdx.x;
+    const int64_t stride = static_cast<int64_t>(groups_total) * kNsMG * 256;
+    float s0 = 0.f, s1 = 0.f;
+    int b = b0;
+    for (; b + 1 < b1; b += 2) {
+        s0 += src[b * stride];
+        s1 += src[(b + 1) * stride];
+    }
+    if (b < b1) s0 += src[b * stride];
+    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int m = 16 * m7 + 4 * (lane >> 4) + r;
+    const int ci = 16 * group + (lane & 15);
+    if (m < 108 && ci < cin && b0 < b1) {
+        const int co = m / 9, tap = m - co * 9;
+        atomicAdd(dw + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, s0 + s1);
+    }
+}
+
+constexpr int kNsMaxBlocks = 512;            // 2 blocks per CU (registers)
+constexpr int64_t kNsScratchFloats = static_cast<int64_t>(kNsMaxBlocks) * 12 * kNsMG * 256;   // blocks * groups_total <= 512 * 12
+
+inline bool wgrad_nsplit_ok(const WgradParams& p) {
+    const bool aligned = (p.w % 4 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
+                         (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0) &&
+                         (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
+    const long chunks = static_cast<long>((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
+    return aligned && p.cout == 12 && chunks >= 4 * kNsMaxBlocks;
+}
+
+template <int NG>
+inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int passes, hipStream_t stream) {
+    const int chunks_total = ((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
+    int blocks = kNsMaxBlocks / passes;
+    const int per = (chunks_total + blocks - 1) / blocks;
+    blocks = (chunks_total + per - 1) / per;
+    const int groups_total = NG * 4 * passes;
+    wgrad_nsplit_kernel<NG><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
+    ENDO_LAUNCH_CHECK();
+    wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 8), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// scratch: kNsScratchFloats floats
+inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream) {
+    const int groups = (p.cin + 15) / 16;
+    const int passes = (groups + 11) / 12;                       // at most 3 groups per wave
+    const int ng = (groups + 4 * passes - 1) / (4 * passes);
+    if (ng <= 1) return launch_wgrad_nsplit_ng<1>(p, scratch, passes, stream);
+    if (ng == 2) return launch_wgrad_nsplit_ng<2>(p, scratch, passes, stream);
+    return launch_wgrad_nsplit_ng<3>(p, scratch, passes, stream);
+}
+
+}  // namespace endo
