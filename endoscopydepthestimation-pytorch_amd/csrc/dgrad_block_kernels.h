@@ -15,8 +15,9 @@
 // Structure (as dgrad_kernels.h): block = one 32 x 6 pixel tile; the NL*12 G maps (+halo) are DMA'd to
 // LDS once; then steps s = (16-channel group, layer): 9x12x16 weight slice by LDS-DMA into a double
 // buffer, 27 * 3 MFMAs per wave, masked accumulate into `total`; after the last layer of a group the
-// float4 epilogue stores.  x / dbuf of the next group and the BN constants of the next step are loaded
-// one step ahead.  One barrier per step.
+// float4 epilogue results are parked in registers and stored at the start of the NEXT step (so that no store is
+// in flight at the vmcnt(0) that publishes the next weight slice).  x / dbuf of a group set are loaded at its first
+// layer's step, the BN constants one step ahead.  One barrier per step.
 #pragma once
 
 #include "conv_dma_kernels.h"
@@ -48,7 +49,7 @@ struct DgradBlockParams {
     double* scratch[kMaxFusedLayers];
 };
 
-template <int NL, int WX, int R>
+template <int NL, int WX, int R, int GP>
 struct DgradBlockGeom {
     static constexpr int kTileX = 16 * WX;
     static constexpr int kTileY = R * (4 / WX);
@@ -57,19 +58,26 @@ struct DgradBlockGeom {
     static constexpr int kPlane = kRows * kCols;
     static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;
     static constexpr int kPos = (kPlane + kConvThreads - 1) / kConvThreads;
-    static constexpr int kWG = 9 * 12 * 16;
+    static constexpr int kNB = 16 * GP;                 // output channels per step
+    static constexpr int kWG = 9 * 12 * kNB;
     static constexpr int kWPre = (kWG + kConvThreads - 1) / kConvThreads;
-    static constexpr size_t kBytes = sizeof(float) * (NL * 12 * kCS + 2 * kWG + 2 * 4 * 16 * 2);
+    static constexpr int kRed = GP * 4 * 16 * 2;        // per buffer: [GP][4 waves][16][2]
+    static constexpr size_t kBytes = sizeof(float) * (NL * 12 * kCS + 2 * kWG + 2 * kRed);
     static_assert(kBytes <= 80 * 1024, "two blocks per CU");
 };
 
-template <int NL, int WX, int R>
+// GP: 16-channel groups per step.  Two groups share every A (dY) fragment read and halve the barriers per MFMA, but
+// measured (tools/conv_bench, level 0 / 1 / 2 shapes) GP = 2 is within +-3 % of GP = 1 and costs 80 more VGPRs;
+// the library instantiates GP = 1.
+// EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x / dbuf loads, 2 = no stores,
+// 4 = weight slice loaded once, 8 = no BN-sum reduction, 16 = no dY tile load, 32 = epilogue reduced to an add
+template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1>
 __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBlockParams p) {
-    using G = DgradBlockGeom<NL, WX, R>;
+    using G = DgradBlockGeom<NL, WX, R, GP>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_g = smem;                               // [NL*12][kCS]
-    float* s_w = s_g + NL * 12 * G::kCS;             // [2][9][12][16]
-    float* s_red = s_w + 2 * G::kWG;                 // [2][4 waves][16][2]
+    float* s_w = s_g + NL * 12 * G::kCS;             // [2][9][12][16 GP]
+    float* s_red = s_w + 2 * G::kWG;                 // [2][GP][4 waves][16][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,8 +91,14 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
     const int wx = (wave % WX) * 16;
     const int wy = (wave / WX) * R;
     const int px = x0 + wx + 4 * lk;
+    // blockIdx.y: slice of the group sets (coarse levels have few tiles; the dY tile is re-read per slice, from L2)
     const int ngroups = (p.count + 15) / 16;
-    const int nsteps = ngroups * NL;
+    const int gsets = (ngroups + GP - 1) / GP;
+    const int gs_per = (gsets + gridDim.y - 1) / gridDim.y;
+    const int gs_begin = blockIdx.y * gs_per;
+    const int gs_end = min(gsets, gs_begin + gs_per);
+    if (gs_begin >= gs_end) return;
+    const int nsteps = (gs_end - gs_begin) * NL;
 
     // ---- G tiles: NL*12 maps with a 1-pixel halo, dword DMA (once per block) ----
     {
@@ -101,7 +115,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
             }
         }
         const float* g_n = p.g + n * p.g_ns;
-        for (int c = 0; c < NL * 12; ++c) {
+        for (int c = 0; c < ((EXP & 16) ? 0 : NL * 12); ++c) {
             const float* plane = g_n + static_cast<int64_t>(c) * p.g_cs;
 #pragma unroll
             for (int k = 0; k < G::kPos; ++k) {
@@ -115,13 +129,13 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
         }
     }
 
-    // ---- weight slice of step (group, layer): element (tap, c, j) <- W_l[c][w_ci_off + 16 group + j][8 - tap] ----
+    // ---- weight slice of step (group set, layer): element (tap, c, j) <- W_l[c][w_ci_off + 16 GP gs + j][8 - tap] ----
     int wc[G::kWPre], wrest[G::kWPre], wj[G::kWPre];
 #pragma unroll
     for (int k = 0; k < G::kWPre; ++k) {
         const int e = tid + k * kConvThreads;
-        const int j = e % 16;
-        const int rest = e / 16;
+        const int j = e % G::kNB;
+        const int rest = e / G::kNB;
         const int c = rest % 12;
         const int tap = rest / 12;
         wc[k] = c * 9;
@@ -129,8 +143,8 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
         wj[k] = j;
     }
     auto issue_weights = [&](int step, int buf) {
-        const int grp = step / NL, l = step - grp * NL;
-        const int co_base = grp * 16;
+        const int gs = gs_begin + step / NL, l = step % NL;
+        const int co_base = gs * G::kNB;
         const float* wl = p.wgt[l] + static_cast<int64_t>(p.w_ci_off + co_base) * 9;
         const int wcin = p.w_cin[l];
 #pragma unroll
@@ -145,145 +159,224 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
         }
     };
 
-    // ---- per-lane BN constants of a step: channel co = 16 group + li of layer l ----
-    auto load_consts = [&](int step, float (&cst)[4]) {
-        const int grp = step / NL, l = step - grp * NL;
-        const int co = grp * 16 + li;
-        cst[0] = cst[1] = cst[2] = cst[3] = 0.f;
-        if (co < p.count) {
-            const float mean = p.saved[l][2 * co], rstd = p.saved[l][2 * co + 1];
-            cst[0] = p.gamma[l][co] * rstd;     // scale
-            cst[1] = p.beta[l][co];
-            cst[2] = mean;
-            cst[3] = rstd;
-        }
-    };
-
-    // ---- epilogue operands of a group ----
-    const float* x_n = p.x + n * p.ns;
-    float* out_n = p.out + n * p.ns;
-    auto load_operands = [&](int grp, f32x4 (&xv)[R], f32x4 (&dv)[R]) {
-        const int co = grp * 16 + li;
+    // ---- per-lane BN constants of a step: channel co = 16 (GP gs + a) + li of layer l ----
+    auto load_consts = [&](int step, float (&cst)[GP][4]) {
+        const int gs = gs_begin + step / NL, l = step % NL;
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const int y = y0 + wy + r;
-            xv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dv[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (co < p.count && y < p.h && px + 3 < p.w) {
-                xv[r] = *reinterpret_cast<const f32x4*>(x_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
-                if (co >= p.acc_from) dv[r] = *reinterpret_cast<const f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+        for (int a = 0; a < GP; ++a) {
+            const int co = (gs * GP + a) * 16 + li;
+            cst[a][0] = cst[a][1] = cst[a][2] = cst[a][3] = 0.f;
+            if (co < p.count) {
+                const float mean = p.saved[l][2 * co], rstd = p.saved[l][2 * co + 1];
+                cst[a][0] = p.gamma[l][co] * rstd;     // scale
+                cst[a][1] = p.beta[l][co];
+                cst[a][2] = mean;
+                cst[a][3] = rstd;
             }
         }
     };
 
-    f32x4 xc[R], dc[R], xn[R], dn[R], total[R];
-    float cc[4], cn[4];
+    const float* x_n = p.x + n * p.ns;
+    float* out_n = p.out + n * p.ns;
+    f32x4 xc[GP][R], dc[GP][R], total[GP][R], po[GP][R];
+    float cc[GP][4], cn[GP][4];
+    int po_gs = -1;                                   // group set whose results wait in `po` (stored one step late)
+    // epilogue operands of a group set; issued at its first layer's step and consumed at the end of that step
+    auto load_operands = [&](int gs) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) total[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < GP; ++a) {
+            const int co = (gs * GP + a) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                xc[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                dc[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(EXP & 1) && co < p.count && y < p.h && px + 3 < p.w) {
+                    xc[a][r] = *reinterpret_cast<const f32x4*>(x_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+                    if (co >= p.acc_from) dc[a][r] = *reinterpret_cast<const f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+                }
+            }
+        }
+    };
+    auto store_pending = [&]() {
+#pragma unroll
+        for (int a = 0; a < GP; ++a) {
+            const int co = (po_gs * GP + a) * 16 + li;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                if (!(EXP & 2) && co < p.count && y < p.h && px + 3 < p.w)
+                    *reinterpret_cast<f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px) = po[a][r];
+            }
+        }
+    };
+
+#pragma unroll
+    for (int a = 0; a < GP; ++a)
+#pragma unroll
+        for (int r = 0; r < R; ++r) total[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
     issue_weights(0, 0);
     load_consts(0, cc);
-    load_operands(0, xc, dc);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int step = 0; step < nsteps; ++step) {
         const int buf = step & 1;
-        const int grp = step / NL, l = step - grp * NL;
+        const int gs = gs_begin + step / NL, l = step % NL;
         const bool last_layer = (l == NL - 1);
+        // results of the previous group set go out now: their write latency hides under this step's MFMAs instead
+        // of stalling the vmcnt(0) that publishes the next weight slice
+        if (po_gs >= 0) { store_pending(); po_gs = -1; }
+        if (l == 0) load_operands(gs);
         if (step + 1 < nsteps) {
-            if (last_layer) load_operands(grp + 1, xn, dn);
             load_consts(step + 1, cn);
-            issue_weights(step + 1, buf ^ 1);
+            if (!(EXP & 4) || step == 0) issue_weights(step + 1, buf ^ 1);
         }
-        // ---- convT_l(G_l) for 16 channels: K = 3 map quads x 9 taps ----
-        f32x4 acc[R];
+        const bool second = (gs * GP + 1) * 16 < p.count;      // the second group of the set exists (block-uniform)
+        // ---- convT_l(G_l) for 16 GP channels: K = 3 map quads x 9 taps ----
+        f32x4 acc[GP][R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int a = 0; a < GP; ++a)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float* wb = s_w + buf * G::kWG;
+        if constexpr (PIPE) {
+            // fragments of map quad q+1 are requested before the 27 GP R MFMAs of quad q are issued, so the LDS
+            // latency hides under this wave's own MFMAs (left to itself the compiler reads each B value right
+            // before the 3 MFMAs that use it and stalls on lgkmcnt(0) every ~100 cycles)
+            float av[2][3][R + 2], bw[2][9][GP];
+            auto load_quad = [&](int quad, int set) {
+                const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
+                const float* b_base = wb + (quad * 4 + lk) * G::kNB + li;
+#pragma unroll
+                for (int r = 0; r < R + 2; ++r)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) av[set][dx][r] = a_base[r * G::kCols + dx];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int a = 0; a < GP; ++a) bw[set][tap][a] = b_base[tap * 12 * G::kNB + a * 16];
+            };
+            load_quad(0, 0);
+#pragma unroll
+            for (int quad = 0; quad < 3; ++quad) {
+                const int set = quad & 1;
+                if (quad + 1 < 3) load_quad(quad + 1, set ^ 1);
+                __builtin_amdgcn_sched_barrier(0);        // keep the reads above, the MFMAs below
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                        for (int a = 0; a < GP; ++a)
+                            if (a == 0 || second) {
+#pragma unroll
+                                for (int r = 0; r < R; ++r)
+                                    acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][dx][r + dy], bw[set][dy * 3 + dx][a], acc[a][r], 0, 0, 0);
+                            }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int quad = 0; quad < 3; ++quad) {
             const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
-            const float* b_base = wb + (quad * 4 + lk) * 16 + li;
+            const float* b_base = wb + (quad * 4 + lk) * G::kNB + li;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                float a[R + 2];
+                float av[R + 2];
 #pragma unroll
-                for (int r = 0; r < R + 2; ++r) a[r] = a_base[r * G::kCols + dx];
+                for (int r = 0; r < R + 2; ++r) av[r] = a_base[r * G::kCols + dx];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) {
-                    const float b = b_base[(dy * 3 + dx) * 12 * 16];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], b, acc[r], 0, 0, 0);
+                    for (int a = 0; a < GP; ++a) {
+                        if (a == 0 || second) {
+                            const float b = b_base[(dy * 3 + dx) * 12 * G::kNB + a * 16];
+#pragma unroll
+                            for (int r = 0; r < R; ++r)
+                                acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + dy], b, acc[a][r], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
+        }
         // ---- layer l's ReLU mask + BN backward, accumulated over the layers of the block ----
-        {
-            const int co = grp * 16 + li;
-            const float scale = cc[0], beta = cc[1], mean = cc[2], rstd = cc[3];
+#pragma unroll
+        for (int a = 0; a < GP; ++a) {
+            const int co = (gs * GP + a) * 16 + li;
+            const float scale = cc[a][0], beta = cc[a][1], mean = cc[a][2], rstd = cc[a][3];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int y = y0 + wy + r;
-                if (co < p.count && y < p.h && px + 3 < p.w) {
+                if constexpr ((EXP & 32) != 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) total[a][r][e] += acc[a][r][e];
+                } else if (co < p.count && y < p.h && px + 3 < p.w) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xcen = xc[r][e] - mean;
+                        const float xcen = xc[a][r][e] - mean;
                         const float z = fmaf(xcen, scale, beta);
-                        const float dz = z > 0.f ? acc[r][e] : 0.f;
+                        const float dz = z > 0.f ? acc[a][r][e] : 0.f;
                         s1 += dz;
                         s2 += dz * (xcen * rstd);
-                        total[r][e] += scale * dz;
+                        total[a][r][e] += scale * dz;
                     }
-                    if (last_layer) {
-                        f32x4 o = dc[r];
+                }
+                if (last_layer) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += total[r][e];
-                        *reinterpret_cast<f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px) = o;
-                    }
+                    for (int e = 0; e < 4; ++e) po[a][r][e] = dc[a][r][e] + total[a][r][e];
+                    total[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lk == 0) {
-                float* red = s_red + buf * (4 * 16 * 2);
+            if (!(EXP & 8) && lk == 0) {
+                float* red = s_red + buf * G::kRed + a * (4 * 16 * 2);
                 red[(wave * 16 + li) * 2] = s1;
                 red[(wave * 16 + li) * 2 + 1] = s2;
             }
         }
-        if (last_layer) {
+        if (last_layer) po_gs = gs;
 #pragma unroll
-            for (int r = 0; r < R; ++r) { total[r] = f32x4{0.f, 0.f, 0.f, 0.f}; xc[r] = xn[r]; dc[r] = dn[r]; }
-        }
+        for (int a = 0; a < GP; ++a)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cc[i] = cn[i];
+            for (int i = 0; i < 4; ++i) cc[a][i] = cn[a][i];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < 32) {
-            const int j = tid >> 1, which = tid & 1;
-            const int co = grp * 16 + j;
+        if (!(EXP & 8) && tid < 32 * GP) {
+            const int a = tid >> 5, j = (tid >> 1) & 15, which = tid & 1;
+            const int co = (gs * GP + a) * 16 + j;
             if (co < p.count) {
-                const float* red = s_red + buf * (4 * 16 * 2);
+                const float* red = s_red + buf * G::kRed + a * (4 * 16 * 2);
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
                 atomicAdd(p.scratch[l] + 2 * co + which, t);
             }
         }
     }
+    if (po_gs >= 0) store_pending();
 }
 
-template <int NL, int WX, int R>
+template <int NL, int WX, int R, int GP = 1, int EXP = 0, int PIPE = 1>
 inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
-    using G = DgradBlockGeom<NL, WX, R>;
+    using G = DgradBlockGeom<NL, WX, R, GP>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     static bool configured = false;
     if (!configured && G::kBytes > 48 * 1024) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
-    dgrad_block_kernel<NL, WX, R><<<dim3(p.tiles_x * tiles_y, 1, p.n), kConvThreads, G::kBytes, stream>>>(p);
+    // enough blocks for ~3 per CU: slice the channel group sets when the level has few tiles
+    const int tiles = p.tiles_x * tiles_y * p.n;
+    const int gsets = ((p.count + 15) / 16 + GP - 1) / GP;
+    int ysplit = (768 + tiles - 1) / tiles;
+    if (ysplit > gsets) ysplit = gsets;
+    if (ysplit < 1) ysplit = 1;
+    dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), kConvThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

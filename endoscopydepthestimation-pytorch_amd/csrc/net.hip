@@ -410,6 +410,8 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         ENDO_LAUNCH_CHECK();
         return 0;
     }
+    // 128x160-class levels: 16x8 tiles (1280 blocks) beat 16x16 (640 blocks, under 2 waves per SIMD) by 13 % (tools/conv_bench)
+    if (tiles_big < 512 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
     return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
 }
 
@@ -529,7 +531,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     probe.w = lv.w; probe.cs = static_cast<int>(lv.plane); probe.ns = lv.t * lv.plane;
     probe.x = c.act(level) + ic0 * lv.plane; probe.out = c.gbuf(level) + ic0 * lv.plane;
     const long tiles = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 5) / 6) * c.net->n;
-    if (!dgrad_block_ok(probe) || tiles < 256) {
+    (void)tiles;          // few tiles: the fused kernel slices the channel groups over blockIdx.y
+    if (!dgrad_block_ok(probe)) {
         for (int j = kLayers - 1; j >= 0; --j) {
             const int acc_from = (j == kLayers - 1 && base_overwrite) ? new0 : 0;
             int rc = dense_bwd(c, level, ic0, new0 + kGrowth * j, bn[j], cv[j], acc_from < ic0 ? ic0 : acc_from);
@@ -632,7 +635,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
-        rc = (nx.w % 4 == 0) ? launch_conv_dma_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream)
+        rc = (nx.w % 4 == 0) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream)
                              : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
         if (rc) return rc;
     }

@@ -3,7 +3,9 @@
 //   dW[co][ci][ky][kx] = sum_p a[ci][p] * dY[co][p - (ky-1, kx-1)]          (a = relu(bn(x)), zero outside)
 //
 // Same GEMM as wgrad_taps_kernels.h (M = (co, tap) = 108 rows -> 7 MFMA row groups, N = input channels,
-// K = pixels) but a block owns ALL input channels of a pass (4 waves x NG groups of 16) for its pixels:
+// K = pixels) but a block owns ALL input channels of a pass (its 16-channel groups dealt out to the 4 waves, at most
+// NG each; when the count is not a multiple of 4 the waves holding one group more rotate with the block index so
+// that the SIMDs of a CU, which run wave i of every resident block, stay evenly loaded) for its pixels:
 //   * every activation value is used by exactly one lane (B[k = pixel][j = ci]), so x never touches LDS: each
 //     lane loads its own 2 x 16 bytes per channel group straight into registers, one chunk ahead, and applies
 //     BN+ReLU there;
@@ -30,7 +32,8 @@ constexpr int kNsBuf = 12 * kNsMap + 64;           // + zero rows read by the un
 constexpr int kNsMG = 7;
 constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
 
-template <int NG>
+// EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x loads, 2 = no dY DMA, 4 = no barrier
+template <int NG, int EXP = 0>
 __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradParams p, float* __restrict__ partial,
                                                                     int chunks_per_block) {
     __shared__ __attribute__((aligned(16))) float smem[2 * kNsBuf];
@@ -39,8 +42,15 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15;
     const int lk = lane >> 4;
-    const int group0 = NG * (4 * blockIdx.y + wave);          // first 16-channel group of this wave
-    const int groups_total = NG * 4 * gridDim.y;
+    // this pass's groups [pass_g0, pass_g0 + pass_n) dealt to the waves: rotated wave r owns q (+1 if r < rem) groups
+    const int groups_total = (p.cin + 15) / 16;
+    const int per_pass = (groups_total + gridDim.y - 1) / gridDim.y;
+    const int pass_g0 = blockIdx.y * per_pass;
+    const int pass_n = min(per_pass, groups_total - pass_g0);
+    const int rw = (wave + blockIdx.x) & 3;
+    const int gq = pass_n >> 2, grem = pass_n & 3;
+    const int ngw = gq + (rw < grem ? 1 : 0);                 // groups of this wave (<= NG)
+    const int group0 = pass_g0 + rw * gq + min(rw, grem);
     const int segs = (p.w + kNsSeg - 1) / kNsSeg;
     const int chunks_total = segs * p.h * p.n;
     const int c_begin = blockIdx.x * chunks_per_block;
@@ -51,7 +61,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int ch = 16 * (group0 + g) + li;
-        ch_ok[g] = ch < p.cin;
+        ch_ok[g] = g < ngw && ch < p.cin;
         sc[g] = 0.f; mn[g] = 0.f; bt[g] = 0.f;
         if (ch_ok[g]) {
             mn[g] = p.saved[2 * ch];
@@ -103,7 +113,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
                 const int gy = y - 1 + row, gx = x0 - 4 + 4 * c4;
                 const bool ok = e < kNsUnits && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
                 const float* src = ok ? dy_n + static_cast<int64_t>(map) * p.dy_cs + gy * p.dy_w + gx : pad_zero;
-                if (e < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
+                if (!(EXP & 2) && e < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
             }
         }
         const float* in_n = p.in + n * p.in_ns + static_cast<int64_t>(y) * p.in_w + x0 + 4 * lk;
@@ -117,7 +127,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 xr[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (ch_ok[g] && (xr_ok & (1u << q))) xr[g][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
+                if (!(EXP & 1) && ch_ok[g] && (xr_ok & (1u << q))) xr[g][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
             }
         }
     };
@@ -126,7 +136,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     int buf = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (!(EXP & 4)) __syncthreads();
         // BN + ReLU of this chunk's activations (registers), then start the next chunk's loads
         f32x4 bv[NG][2];
 #pragma unroll
@@ -149,9 +159,11 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
                 for (int m = 0; m < kNsMG; ++m) a[m] = s_dy[aoff[m] + 16 * q + e];
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
+                    if (g < ngw) {          // wave-uniform
 #pragma unroll
-                    for (int m = 0; m < kNsMG; ++m)
-                        acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[g][q][e], acc[g][m], 0, 0, 0);
+                        for (int m = 0; m < kNsMG; ++m)
+                            acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[g][q][e], acc[g][m], 0, 0, 0);
+                    }
             }
     }
 
@@ -159,10 +171,12 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     float* out = partial + (static_cast<int64_t>(blockIdx.x) * groups_total + group0) * (kNsMG * 256);
 #pragma unroll
     for (int g = 0; g < NG; ++g)
+        if (g < ngw) {
 #pragma unroll
-        for (int m = 0; m < kNsMG; ++m)
+            for (int m = 0; m < kNsMG; ++m)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[((g * kNsMG + m) * 4 + r) * 64 + lane] = acc[g][m][r];
+                for (int r = 0; r < 4; ++r) out[((g * kNsMG + m) * 4 + r) * 64 + lane] = acc[g][m][r];
+        }
 }
 
 // grid (groups_total * 7, slices): thread (r, lane) of row block (group, m) adds the partials of its slice of blocks
@@ -190,8 +204,8 @@ __global__ void __launch_bounds__(256) wgrad_nsplit_reduce_kernel(const float* _
     }
 }
 
-constexpr int kNsMaxBlocks = 512;            // 2 blocks per CU (registers)
-constexpr int64_t kNsScratchFloats = static_cast<int64_t>(kNsMaxBlocks) * 12 * kNsMG * 256;   // blocks * groups_total <= 512 * 12
+constexpr int kNsMaxBlocks = 512;            // at NG = 3 (2 blocks per CU)
+constexpr int64_t kNsScratchFloats = static_cast<int64_t>(kNsMaxBlocks) * 12 * kNsMG * 256;   // blocks * groups <= 512 * 12
 
 inline bool wgrad_nsplit_ok(const WgradParams& p) {
     const bool aligned = (p.w % 4 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
@@ -201,14 +215,14 @@ inline bool wgrad_nsplit_ok(const WgradParams& p) {
     return aligned && p.cout == 12 && chunks >= 4 * kNsMaxBlocks;
 }
 
-template <int NG>
+template <int NG, int EXP = 0>
 inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int passes, hipStream_t stream) {
     const int chunks_total = ((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
-    int blocks = kNsMaxBlocks / passes;
+    int blocks = (NG == 3 ? 512 : NG == 2 ? 768 : 1024) / passes;   // resident blocks per CU by register count: 2 / 3 / 4
     const int per = (chunks_total + blocks - 1) / blocks;
     blocks = (chunks_total + per - 1) / per;
-    const int groups_total = NG * 4 * passes;
-    wgrad_nsplit_kernel<NG><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
+    const int groups_total = (p.cin + 15) / 16;
+    wgrad_nsplit_kernel<NG, EXP><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
     ENDO_LAUNCH_CHECK();
     wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 8), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();
@@ -219,7 +233,8 @@ inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int pass
 inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream) {
     const int groups = (p.cin + 15) / 16;
     const int passes = (groups + 11) / 12;                       // at most 3 groups per wave
-    const int ng = (groups + 4 * passes - 1) / (4 * passes);
+    const int per_pass = (groups + passes - 1) / passes;
+    const int ng = (per_pass + 3) / 4;
     if (ng <= 1) return launch_wgrad_nsplit_ng<1>(p, scratch, passes, stream);
     if (ng == 2) return launch_wgrad_nsplit_ng<2>(p, scratch, passes, stream);
     return launch_wgrad_nsplit_ng<3>(p, scratch, passes, stream);

@@ -1,7 +1,7 @@
 // Kernel-variant microbenchmark (development tool, not part of the product): times alternative
 // instantiations of the dense-layer kernels on one layer shape and cross-checks their outputs.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/conv_bench.hip -o gpurun_out/conv_bench
-//   gpurun_out/conv_bench [cin] [n] [h] [w]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/conv_bench.hip -o tools/bin/conv_bench
+//   tools/bin/conv_bench [cin] [n] [h] [w]     (cin = channels entering the LAST layer of a dense block: c0 = cin - 36)
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -11,6 +11,8 @@
 
 #include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_taps_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_nsplit_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_block_kernels.h"
 
 using namespace endo;
 
@@ -81,6 +83,7 @@ int main(int argc, char** argv) {
     double* scratch; CK(hipMalloc(&scratch, 2 * t * sizeof(double))); CK(hipMemset(scratch, 0, 2 * t * sizeof(double)));
     double* osums; CK(hipMalloc(&osums, 2 * 16 * sizeof(double))); CK(hipMemset(osums, 0, 32 * sizeof(double)));
     float* dw; CK(hipMalloc(&dw, (size_t)12 * cin * 9 * sizeof(float)));
+    float* wscratch; CK(hipMalloc(&wscratch, kNsScratchFloats * sizeof(float)));
 
     const double flops = 2.0 * n * plane * cin * 12 * 9;
 
@@ -94,60 +97,40 @@ int main(int argc, char** argv) {
     f.out = buf + cin * plane; f.out_ns = t * plane; f.out_cs = (int)plane; f.out_w = w; f.cout = 12; f.out_sums = osums;
     {
         std::vector<Variant> vs;
-        vs.push_back({"fwd reg-staged KC8 32x16", [&](hipStream_t s) { return launch_conv<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 8>(f, s); }});
-        vs.push_back({"fwd reg-staged KC8 16x16", [&](hipStream_t s) { return launch_conv<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 4>(f, s); }});
-        vs.push_back({"fwd reg-staged KC8 32x8", [&](hipStream_t s) { return launch_conv<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 4>(f, s); }});
-        vs.push_back({"fwd dma KC4 2buf 32x16 minw5", [&](hipStream_t s) { return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 5>(f, s); }});
-        vs.push_back({"fwd dma KC4 2buf 32x16 minw1", [&](hipStream_t s) { return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1>(f, s); }});
-        vs.push_back({"fwd dma KC8 2buf 32x16", [&](hipStream_t s) { return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1>(f, s); }});
-        vs.push_back({"fwd dma KC4 2buf 32x8", [&](hipStream_t s) { return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1>(f, s); }});
-        vs.push_back({"fwd dma KC8 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 32x16 xf0 (bn at frag read)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 32x16 xf1 (bn in place)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 1>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 32x16 xf1 minw5", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 5, 4, 1>(f, s); }});
-        vs.push_back({"fwd dma4 KC8 32x16 xf1", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 1>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 32x8 xf1", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 1>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 16x16 xf1", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 1>(f, s); }});
-        vs.push_back({"fwd dma1 KC4 32x16 xf1 (dword)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 1, 1>(f, s); }});
-        vs.push_back({"fwd dma1 KC4 2buf 32x16 (dword)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 1, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 2buf 32x16 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC8 2buf 32x16 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 2buf 32x8 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC8 2buf 32x8 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 0>(f, s); }});
-        vs.push_back({"fwd dma4 KC4 2buf 16x16 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC4 2buf 32x16 (library)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC4 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC8 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC4 2buf 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC8 2buf 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC4 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC8 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC16 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
         bench(vs, f.out, (size_t)12 * plane, flops);      // compares sample 0's 12 planes
     }
 
-    // ---------------- dgrad: dY (12 planes) -> gradient of the cin input planes, BN/ReLU backward fused ----------------
-    ConvParams d{};
-    d.n = n; d.h = h; d.w = w;
-    d.in = gbuf + cin * plane; d.in_ns = t * plane; d.in_cs = (int)plane; d.in_w = w; d.cin = 12;
-    d.wgt = wgt; d.w_cout = 12; d.w_cin = cin;
-    d.out = gbuf; d.out_ns = t * plane; d.out_cs = (int)plane; d.out_w = w; d.cout = cin;
-    d.x = buf; d.x_ns = t * plane; d.x_cs = (int)plane;
-    d.bn_saved = saved; d.bn_gamma = gamma; d.bn_beta = beta; d.bn_scratch = scratch; d.acc_from = 1 << 30;   // overwrite: repeatable
+    // ---------------- block-fused dgrad: the 4 layers of a block into its c0 = cin - 36 base channels ----------------
     {
+        const int c0 = cin - 36;
+        DgradBlockParams p{};
+        p.n = n; p.h = h; p.w = w;
+        // reuse gbuf: maps [0, c0) = gradient buffer of the base, take the 48 dY maps from buf's first planes (values only matter for timing)
+        p.g = buf; p.g_ns = t * plane; p.g_cs = (int)plane; p.g_w = w;
+        p.x = buf; p.out = gbuf; p.ns = t * plane; p.cs = (int)plane; p.count = c0; p.acc_from = 1 << 30; p.w_ci_off = 0;
+        for (int j = 0; j < 4; ++j) {
+            p.wgt[j] = wgt; p.w_cin[j] = cin; p.saved[j] = saved; p.gamma[j] = gamma; p.beta[j] = beta; p.scratch[j] = scratch;
+        }
+        const double bflops = 2.0 * n * plane * c0 * 12 * 9 * 4;
         std::vector<Variant> vs;
-        vs.push_back({"dgrad reg-staged KC12 Q3 32x8", [&](hipStream_t s) { return launch_conv<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4>(d, s); }});
-        vs.push_back({"dgrad reg-staged KC12 Q3 32x16", [&](hipStream_t s) { return launch_conv<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 8>(d, s); }});
-        vs.push_back({"dgrad dma KC12 Q3 32x8 1buf", [&](hipStream_t s) { return launch_conv_dma<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1>(d, s); }});
-        vs.push_back({"dgrad dma KC12 Q3 16x16 1buf", [&](hipStream_t s) { return launch_conv_dma<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 1, 4, 1, 1>(d, s); }});
-        vs.push_back({"dgrad dma KC12 Q2 32x8 1buf", [&](hipStream_t s) { return launch_conv_dma<3, 12, 2, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1>(d, s); }});
-        vs.push_back({"dgrad dma KC12 Q2 32x16 1buf", [&](hipStream_t s) { return launch_conv_dma<3, 12, 2, IN_PLAIN, EPI_DGRAD_BN, 2, 8, 1, 1>(d, s); }});
-        vs.push_back({"dgrad dma KC12 Q1 32x16 1buf", [&](hipStream_t s) { return launch_conv_dma<3, 12, 1, IN_PLAIN, EPI_DGRAD_BN, 2, 8, 1, 1>(d, s); }});
-        vs.push_back({"dgrad persistent 32x8", [&](hipStream_t s) { return launch_dgrad_dense<2, 4>(d, s); }});
-        vs.push_back({"dgrad persistent 32x16", [&](hipStream_t s) { return launch_dgrad_dense<2, 8>(d, s); }});
-        vs.push_back({"dgrad persistent 16x16", [&](hipStream_t s) { return launch_dgrad_dense<1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 Q1 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 1, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 Q1 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 1, IN_PLAIN, EPI_DGRAD_BN, 1, 4, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 Q2 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 2, IN_PLAIN, EPI_DGRAD_BN, 1, 4, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 Q2 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 2, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 Q3 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 1, 2, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma1 KC12 Q3 32x8 (dword)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1, 1>(d, s); }});
-        vs.push_back({"dgrad dma4 KC12 Q3 32x8 (16B)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 1, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 KC12 Q3 32x8 minw2", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 2, 4>(d, s); }});
-        vs.push_back({"dgrad dma4 KC12 Q3 32x8 minw3", [&](hipStream_t s) { return launch_conv_dma_vec<3, 12, 3, IN_PLAIN, EPI_DGRAD_BN, 2, 4, 1, 3, 4>(d, s); }});
-        bench(vs, d.out, (size_t)cin * plane, flops);
+        vs.push_back({"dgrad_block<4> GP1 pipelined (library)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 0, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP1 unpipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 0, 0>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP2 pipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 2, 0, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP2 unpipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 2, 0, 0>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP1 pipelined no loads/stores", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 3, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP1 trivial epilogue (32+8)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 40, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP1 trivial epi, no ld/st (43)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 43, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP1 + weights once (47)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 47, 1>(p, s); }});
+        vs.push_back({"dgrad_block<4> GP2 + weights once (47)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 2, 47, 0>(p, s); }});
+        bench(vs, p.out, (size_t)c0 * plane, bflops);
     }
 
     // ---------------- wgrad ----------------
@@ -158,9 +141,15 @@ int main(int argc, char** argv) {
     g.dy = gbuf + cin * plane; g.dy_ns = t * plane; g.dy_cs = (int)plane; g.dy_w = w; g.cout = 12;
     g.dw = dw;
     {
+        const int groups = (cin + 15) / 16, passes = (groups + 11) / 12;
         std::vector<Variant> vs;
-        vs.push_back({"wgrad KC16 32x8 reg-staged", [&](hipStream_t s) { CK(hipMemsetAsync(dw, 0, (size_t)12 * cin * 9 * 4, s)); return launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(g, s); }});
-        vs.push_back({"wgrad taps-in-M dma 32x8", [&](hipStream_t s) { CK(hipMemsetAsync(dw, 0, (size_t)12 * cin * 9 * 4, s)); return launch_wgrad_taps<12, IN_BNRELU>(g, s); }});
+        auto zero = [&](hipStream_t s) { CK(hipMemsetAsync(dw, 0, (size_t)12 * cin * 9 * 4, s)); };
+        vs.push_back({"wgrad taps-in-M dma 32x8", [&](hipStream_t s) { zero(s); return launch_wgrad_taps<12, IN_BNRELU>(g, s); }});
+        vs.push_back({"wgrad nsplit (library)", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit(g, wscratch, s); }});
+        vs.push_back({"wgrad nsplit<3> no x loads", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 1>(g, wscratch, passes, s); }});
+        vs.push_back({"wgrad nsplit<3> no dY DMA", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 2>(g, wscratch, passes, s); }});
+        vs.push_back({"wgrad nsplit<3> no loads at all", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 3>(g, wscratch, passes, s); }});
+        vs.push_back({"wgrad nsplit<3> no loads, no barrier", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 7>(g, wscratch, passes, s); }});
         bench(vs, dw, (size_t)12 * cin * 9, flops);
     }
     return 0;
