@@ -74,7 +74,7 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
+    """HBM bytes per step of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
     serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
     bench.py command).  None when there is no such file."""
     import glob
@@ -86,7 +86,7 @@ def pmc_traffic(family):
         except (OSError, ValueError, KeyError):
             continue
         if entry:
-            return entry["traffic_bytes_per_launch"], "profiles/" + os.path.basename(path)
+            return entry["traffic_bytes_per_step"], "profiles/" + os.path.basename(path)
     return None, None
 
 
@@ -195,7 +195,9 @@ def main():
     ms, cnt, fl, by = fam[dominant]
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
-    traffic, traffic_src = pmc_traffic(dom_name)
+    traffic, traffic_src = pmc_traffic(dom_name)          # bytes per step -> per launch with the launches counted here
+    if traffic is not None and cnt:
+        traffic = traffic / (cnt / args.steps)
     result = {
         "metric": "train frame-pairs/sec at 256x320 bs=8",
         "value": pairs / elapsed,

@@ -166,6 +166,22 @@ int endo_sgd_clip_step(float* params, float* grads, float* momentum, double* nor
                        int64_t count, float lr, float mu, float max_norm, float grad_scale,
                        int first_step, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Sparse SfM scatter -- reference utils.py:460-612 (get_torch_training_data) for a batch of pairs of ONE
+ * sequence, on the device.  points [P][4] fp64 (homogeneous), projections [B][2][3][4] fp64,
+ * extrinsics [B][2][4][4] fp64, visibility [B][P][2] (> 0.5 = the point is seen in that frame of the pair),
+ * clean [P] or NULL (utils.py:496-497), mask [H][W] uint8 (255 = inside the endoscope boundary).
+ * Outputs, zero-filled by the call, NCHW with the frame index outermost: depth_masks / depths / flow_masks
+ * [2][B][1][H][W], flows [2][B][2][H][W] (u then v, divided by W and H; entries with |flow| > 5 zeroed,
+ * utils.py:566-569,603-606).  depths are multiplied by depth_multiplier (1 = the reference function;
+ * 1 / global_scale folds in dataset.py:391-392).  Pixel collisions: the highest point index wins (numpy
+ * fancy-index assignment).  winner_scratch: 2*B*H*W int32 of workspace.
+ * ------------------------------------------------------------------------------------------- */
+int endo_sparse_scatter(const double* points, int n_points, const double* projections, const double* extrinsics,
+                        const float* visibility, const float* clean, const uint8_t* mask, int batch, int height, int width,
+                        float depth_multiplier, int32_t* winner_scratch, float* depth_masks, float* depths, float* flow_masks,
+                        float* flows, void* stream);
+
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f
  * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read
