@@ -35,6 +35,9 @@ SIGNATURES = {
     "endo_scale_inv_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "endo_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "endo_net_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
+    "endo_net_create_grouped": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "endo_net_groups": (_I, [_P]),
+    "endo_net_group_stride": (_L, [_P]),
     "endo_net_destroy": (None, [_P]),
     "endo_net_param_floats": (_L, []),
     "endo_net_bn_floats": (_L, []),

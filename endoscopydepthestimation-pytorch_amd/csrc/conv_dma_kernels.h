@@ -49,7 +49,7 @@ struct ConvDmaSmem {
 // read by 3 taps); 1 = once, in place in LDS, by the thread whose DMA wrote the value, right after
 // its own vmcnt(0) and before the barrier that publishes the chunk (no extra synchronisation).
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF>
-__global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p0) {
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
     static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL), "16-byte DMA needs contiguous sources");
@@ -63,6 +63,12 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_aux = smem + NBUF * S::kBuf;
+    int grp, n;
+    group_of(p0, blockIdx.z, grp, n);
+    const ConvParams p = group_view(p0, grp);
+    const int groups = p0.group_n > 0 ? gridDim.z / p0.group_n : 1;
+    const bool first_of_group = blockIdx.x == 0 && blockIdx.y == 0 && n == 0;
+    (void)groups; (void)first_of_group;
     const int cap = p.bn_cap;      // BN tables: scale [0,cap) mean [cap,2cap) beta [2cap,3cap); then dgrad constants, reductions
 
     const int tid = threadIdx.x;
@@ -74,35 +80,15 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
     const int co_base = p.ksplit > 0 ? 0 : blockIdx.y * NB;
-    const int n = blockIdx.z;
 
     // ---------------- prologue: per-channel constants (identical to conv_mfma_kernel) ----------------
     if constexpr (IN == IN_BNRELU) {
         for (int c = tid; c < p.cin; c += kConvThreads) {
-            double mean, var;
-            if (p.training) {
-                mean = p.in_sums[2 * c] / p.count;
-                var = p.in_sums[2 * c + 1] / p.count - mean * mean;
-                if (var < 0.0) var = 0.0;
-            } else {
-                mean = p.running_mean[c];
-                var = p.running_var[c];
-            }
-            const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
-            s_aux[c] = p.gamma[c] * static_cast<float>(rstd);
-            s_aux[cap + c] = static_cast<float>(mean);
-            s_aux[2 * cap + c] = p.beta[c];
-            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-                if (p.saved) {
-                    p.saved[2 * c] = static_cast<float>(mean);
-                    p.saved[2 * c + 1] = static_cast<float>(rstd);
-                }
-                if (p.training) {
-                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * static_cast<float>(mean);
-                    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
-                }
-            }
+            float scale, mean, beta;
+            bn_input_constants(p, p0, grp, groups, first_of_group, c, scale, mean, beta);
+            s_aux[c] = scale;
+            s_aux[cap + c] = mean;
+            s_aux[2 * cap + c] = beta;
         }
         // channels past cin (last chunk): any finite constants; their raw values are the NaN pad
         for (int c = p.cin + tid; c < ((p.cin + KC - 1) / KC) * KC; c += kConvThreads) {

@@ -84,7 +84,76 @@ struct ConvParams {
     // out + s * split_stride (bias / statistics are applied by finalize_partial_kernel)
     int ksplit;
     int64_t split_stride;
+    // ---- grouped batch (endo_net_create_grouped): blockIdx.z runs over groups * group_n samples.  Group g is an
+    // independent forward / backward (its own BatchNorm statistics, tape and gradient workspace) that shares the
+    // parameters: tape / workspace pointers move by g * gs floats, `in` and `out` by their own strides (they may be
+    // caller tensors), parameter pointers do not move.  group_n == 0 means "not grouped" (one group of n samples).
+    int group_n;
+    int64_t gs, in_gs, out_gs;
 };
+
+// this block's group and sample inside it
+__device__ __forceinline__ void group_of(const ConvParams& p, int z, int& grp, int& n) {
+    grp = p.group_n > 0 ? z / p.group_n : 0;
+    n = z - grp * p.group_n;
+}
+
+__device__ __forceinline__ ConvParams group_view(const ConvParams& p, int grp) {
+    ConvParams q = p;
+    const int64_t o = grp * p.gs;
+    q.in += grp * p.in_gs;
+    q.out += grp * p.out_gs;
+    if (q.x) q.x += o;
+    if (q.in_idx) q.in_idx += 4 * o;
+    if (q.out_idx) q.out_idx += 4 * o;
+    if (q.in_sums) q.in_sums += o / 2;
+    if (q.out_sums) q.out_sums += o / 2;
+    if (q.bn_scratch) q.bn_scratch += o / 2;
+    if (q.saved) q.saved += o;
+    if (q.bn_saved) q.bn_saved += o;
+    return q;
+}
+
+// BN constants of input channel c for this block's group (p = the group view, p0 = the launch parameters).  The first
+// block of each group records (mean, rstd) for its backward pass; the very first block of the launch applies the
+// running-statistics updates of ALL groups, in group order -- the sequence the reference's separate forward calls
+// (one per group) would produce.
+__device__ __forceinline__ void bn_input_constants(const ConvParams& p, const ConvParams& p0, int grp, int groups, bool first_of_group,
+                                                   int c, float& scale, float& mean_f, float& beta) {
+    double mean, var;
+    if (p.training) {
+        mean = p.in_sums[2 * c] / p.count;
+        var = p.in_sums[2 * c + 1] / p.count - mean * mean;
+        if (var < 0.0) var = 0.0;
+    } else {
+        mean = p.running_mean[c];
+        var = p.running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
+    scale = p.gamma[c] * static_cast<float>(rstd);
+    mean_f = static_cast<float>(mean);
+    beta = p.beta[c];
+    if (first_of_group) {
+        if (p.saved) {
+            p.saved[2 * c] = static_cast<float>(mean);
+            p.saved[2 * c + 1] = static_cast<float>(rstd);
+        }
+        if (p.training && grp == 0) {
+            float rm = p.running_mean[c], rv = p.running_var[c];
+            for (int g = 0; g < groups; ++g) {
+                const double* sums = p0.in_sums + g * (p0.gs / 2);
+                const double m = sums[2 * c] / p.count;
+                double v = sums[2 * c + 1] / p.count - m * m;
+                if (v < 0.0) v = 0.0;
+                const double unbiased = p.count > 1.0 ? v * p.count / (p.count - 1.0) : v;
+                rm = (1.0f - p.momentum) * rm + p.momentum * static_cast<float>(m);
+                rv = (1.0f - p.momentum) * rv + p.momentum * static_cast<float>(unbiased);
+            }
+            p.running_mean[c] = rm;
+            p.running_var[c] = rv;
+        }
+    }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -301,7 +370,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
 }
 
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R>
-__global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParams p0) {
     using G = ConvGeom<KS, KC, WX, R>;
     constexpr int kTileX = G::kTileX;
     constexpr int kTileY = G::kTileY;
@@ -320,10 +389,15 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int tile = blockIdx.x;
-    const int x0 = (tile % p.tiles_x) * kTileX;
-    const int y0 = (tile / p.tiles_x) * kTileY;
+    const int x0 = (tile % p0.tiles_x) * kTileX;
+    const int y0 = (tile / p0.tiles_x) * kTileY;
     const int co_base = blockIdx.y * NB;
-    const int n = blockIdx.z;
+    int grp, n;
+    group_of(p0, blockIdx.z, grp, n);
+    const ConvParams p = group_view(p0, grp);
+    const int groups = p0.group_n > 0 ? gridDim.z / p0.group_n : 1;
+    const bool first_of_group = blockIdx.x == 0 && blockIdx.y == 0 && n == 0;
+    (void)groups; (void)first_of_group;
 
     // ---------------- prologue: per-channel constants ----------------
     if constexpr (IN == IN_BNRELU) {
@@ -331,31 +405,11 @@ __global__ void __launch_bounds__(kConvThreads) conv_mfma_kernel(const ConvParam
         // z = (x - mean) * scale + beta: subtracting the mean FIRST keeps z accurate near zero, so the
         // ReLU mask (and hence every gradient) flips no more often than in the reference's fp32 path.
         for (int c = tid; c < p.cin; c += kConvThreads) {
-            double mean, var;
-            if (p.training) {
-                mean = p.in_sums[2 * c] / p.count;
-                var = p.in_sums[2 * c + 1] / p.count - mean * mean;
-                if (var < 0.0) var = 0.0;
-            } else {
-                mean = p.running_mean[c];
-                var = p.running_var[c];
-            }
-            const double rstd = 1.0 / sqrt(var + static_cast<double>(p.eps));
-            const float scale = p.gamma[c] * static_cast<float>(rstd);
+            float scale, mean, beta;
+            bn_input_constants(p, p0, grp, groups, first_of_group, c, scale, mean, beta);
             s_aux[c] = scale;
-            s_aux[kMaxBnChannels + c] = static_cast<float>(mean);
-            s_aux[2 * kMaxBnChannels + c] = p.beta[c];
-            if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0) {
-                if (p.saved) {
-                    p.saved[2 * c] = static_cast<float>(mean);
-                    p.saved[2 * c + 1] = static_cast<float>(rstd);
-                }
-                if (p.training) {
-                    const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                    p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * static_cast<float>(mean);
-                    p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
-                }
-            }
+            s_aux[kMaxBnChannels + c] = mean;
+            s_aux[2 * kMaxBnChannels + c] = beta;
         }
     }
     if constexpr (EPI == EPI_DGRAD_BN) {

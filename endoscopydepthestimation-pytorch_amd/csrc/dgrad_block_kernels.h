@@ -47,6 +47,9 @@ struct DgradBlockParams {
     const float* gamma[kMaxFusedLayers];
     const float* beta[kMaxFusedLayers];
     double* scratch[kMaxFusedLayers];
+    // grouped batch (see ConvParams): blockIdx.z = group * group_n + sample; g, x, out, saved, scratch move by group * gs floats
+    int group_n;
+    int64_t gs;
 };
 
 template <int NL, int WX, int R, int GP>
@@ -72,8 +75,12 @@ struct DgradBlockGeom {
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x / dbuf loads, 2 = no stores,
 // 4 = weight slice loaded once, 8 = no BN-sum reduction, 16 = no dY tile load, 32 = epilogue reduced to an add
 template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1>
-__global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBlockParams p) {
+__global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBlockParams p0) {
     using G = DgradBlockGeom<NL, WX, R, GP>;
+    const int grp = p0.group_n > 0 ? blockIdx.z / p0.group_n : 0;
+    const int n = blockIdx.z - grp * p0.group_n;
+    const DgradBlockParams& p = p0;
+    const int64_t grp_off = grp * p0.gs;            // this group's tape / workspace offset (floats)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_g = smem;                               // [NL*12][kCS]
     float* s_w = s_g + NL * 12 * G::kCS;             // [2][9][12][16 GP]
@@ -87,7 +94,6 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
     const int tile = (gridDim.x & 7) == 0 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
-    const int n = blockIdx.z;
     const int wx = (wave % WX) * 16;
     const int wy = (wave / WX) * R;
     const int px = x0 + wx + 4 * lk;
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
                 if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) { ok |= 1u << k; goff[k] = gy * p.g_w + gx; }
             }
         }
-        const float* g_n = p.g + n * p.g_ns;
+        const float* g_n = p.g + grp_off + n * p.g_ns;
         for (int c = 0; c < ((EXP & 16) ? 0 : NL * 12); ++c) {
             const float* plane = g_n + static_cast<int64_t>(c) * p.g_cs;
 #pragma unroll
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
             const int co = (gs * GP + a) * 16 + li;
             cst[a][0] = cst[a][1] = cst[a][2] = cst[a][3] = 0.f;
             if (co < p.count) {
-                const float mean = p.saved[l][2 * co], rstd = p.saved[l][2 * co + 1];
+                const float mean = p.saved[l][grp_off + 2 * co], rstd = p.saved[l][grp_off + 2 * co + 1];
                 cst[a][0] = p.gamma[l][co] * rstd;     // scale
                 cst[a][1] = p.beta[l][co];
                 cst[a][2] = mean;
@@ -176,8 +182,8 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
         }
     };
 
-    const float* x_n = p.x + n * p.ns;
-    float* out_n = p.out + n * p.ns;
+    const float* x_n = p.x + grp_off + n * p.ns;
+    float* out_n = p.out + grp_off + n * p.ns;
     f32x4 xc[GP][R], dc[GP][R], total[GP][R], po[GP][R];
     float cc[GP][4], cn[GP][4];
     int po_gs = -1;                                   // group set whose results wait in `po` (stored one step late)
@@ -352,7 +358,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
                 const float* red = s_red + buf * G::kRed + a * (4 * 16 * 2);
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
-                atomicAdd(p.scratch[l] + 2 * co + which, t);
+                atomicAdd(p.scratch[l] + grp_off / 2 + 2 * co + which, t);
             }
         }
     }

@@ -29,7 +29,10 @@ struct DgradGeom {
 };
 
 template <int WX, int R>
-__global__ void __launch_bounds__(kConvThreads) dgrad_dense_kernel(const ConvParams p) {
+__global__ void __launch_bounds__(kConvThreads) dgrad_dense_kernel(const ConvParams p0) {
+    int grp, n;
+    group_of(p0, blockIdx.z, grp, n);
+    const ConvParams p = group_view(p0, grp);
     using D = DgradGeom<WX, R>;
     using G = typename D::G;
     static_assert(G::kPos == 1, "one 16-byte unit per thread per channel");
@@ -48,7 +51,6 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_dense_kernel(const ConvPar
     const int tile = blockIdx.x;
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
-    const int n = blockIdx.z;
     const int wx = (wave % WX) * 16;
     const int wy = (wave / WX) * R;
     const int px = x0 + wx + 4 * lk;

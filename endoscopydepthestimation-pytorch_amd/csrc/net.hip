@@ -90,7 +90,9 @@ static const Table& table() {
 using namespace endo;
 
 struct endo_net {
-    int n, h, w;
+    int n, h, w;           // n = samples per group
+    int groups;            // independent forward / backward passes batched into every launch (each with its own BN statistics)
+    int64_t gs;            // floats between two groups' tapes and between their gradient workspaces
     struct Level { int h, w, t; int64_t plane; int64_t act, grad; int64_t sums; int64_t pq; } lv[kLevels + 1];
     int64_t pre_off;       // final conv pre-activation (floats, tape)
     int64_t saved_off;     // BN saved mean/rstd (floats, tape), 2 per BN channel
@@ -117,11 +119,12 @@ namespace endo {
 // the channel), and bias gradient += sum G.
 __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, const float* __restrict__ x, int64_t ns, int plane,
                                                       const float* __restrict__ pq_p, const float* __restrict__ pq_q,
-                                                      float* bias_grad) {
+                                                      float* bias_grad, int group_n, int64_t gs) {
     __shared__ double scratch[4];
-    const int c = blockIdx.y, n = blockIdx.z;
-    const float pc = pq_p[c], qc = pq_q[c];
-    const int64_t base = n * ns + static_cast<int64_t>(c) * plane;
+    const int c = blockIdx.y;
+    const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
+    const float pc = pq_p[grp * gs + c], qc = pq_q[grp * gs + c];
+    const int64_t base = grp * gs + n * ns + static_cast<int64_t>(c) * plane;
     float part = 0.f;
     if ((plane & 3) == 0) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
@@ -150,11 +153,14 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
 //   Q += -scale*S1/M + scale*rstd*S2/M*mean          (S1 = sum dz, S2 = sum dz*xhat)
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const float* __restrict__ saved,
                                        const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                       float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count, int training) {
+                                       float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count, int training,
+                                       int64_t gs) {
+    // blockIdx.y = sample group: its own sums, statistics and deferred terms; the parameter gradients add up over groups
+    scratch += blockIdx.y * (gs / 2); saved += blockIdx.y * gs; pq_p += blockIdx.y * gs; pq_q += blockIdx.y * gs;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
         const double s1 = scratch[2 * c], s2 = scratch[2 * c + 1];
-        ggamma[c] += static_cast<float>(s2);
-        gbeta[c] += static_cast<float>(s1);
+        atomicAdd(ggamma + c, static_cast<float>(s2));
+        atomicAdd(gbeta + c, static_cast<float>(s1));
         if (training) {
             const double mean = saved[2 * c], rstd = saved[2 * c + 1];
             const double scale = gamma[c] * rstd;
@@ -175,16 +181,18 @@ struct BnFin4 {
     float* gbeta[4];
 };
 __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
-                                        int training) {
+                                        int training, int64_t gs) {
+    const int64_t go = blockIdx.y * gs;          // sample group offset (floats)
+    pq_p += go; pq_q += go;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
         double dp = 0.0, dq = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double s1 = a.scratch[j][2 * c], s2 = a.scratch[j][2 * c + 1];
-            a.ggamma[j][c] += static_cast<float>(s2);
-            a.gbeta[j][c] += static_cast<float>(s1);
+            const double s1 = a.scratch[j][go / 2 + 2 * c], s2 = a.scratch[j][go / 2 + 2 * c + 1];
+            atomicAdd(a.ggamma[j] + c, static_cast<float>(s2));
+            atomicAdd(a.gbeta[j] + c, static_cast<float>(s1));
             if (training) {
-                const double mean = a.saved[j][2 * c], rstd = a.saved[j][2 * c + 1];
+                const double mean = a.saved[j][go + 2 * c], rstd = a.saved[j][go + 2 * c + 1];
                 const double scale = a.gamma[j][c] * rstd;
                 const double k = scale * rstd * s2 / count;
                 // same rounding sequence as four single-layer finalizes: each term is rounded to fp32 before it is added
@@ -203,9 +211,12 @@ __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, float* __restrict__ pq_p
 // plus the per-channel sum / sum^2 that later BN layers need.  grid (x blocks, channel, sample).
 __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __restrict__ partial, int64_t split_stride, int ksplit,
                                                                int64_t pns, int plane, const float* __restrict__ bias,
-                                                               float* __restrict__ out, int64_t out_ns, double* out_sums) {
+                                                               float* __restrict__ out, int64_t out_ns, double* out_sums,
+                                                               int group_n, int64_t gs) {
     __shared__ double scratch[2 * 4];
-    const int c = blockIdx.y, n = blockIdx.z;
+    const int c = blockIdx.y;
+    const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;
+    partial += grp * gs; out += grp * gs; out_sums += grp * (gs / 2);
     const float b = bias[c];
     float part[2] = {0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
@@ -221,11 +232,15 @@ __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __re
 // final 1x1 conv 192 -> 1 and |.| (reference models.py:186).  HBM-bound: reads each plane once.
 __global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict__ u, int64_t ns, int plane, int cin,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                        float* __restrict__ pre, float* __restrict__ out) {
+                                                        float* __restrict__ pre, float* __restrict__ out, int group_n, int64_t gs) {
     __shared__ float s_w[192];
     for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
     __syncthreads();
-    const int n = blockIdx.y;
+    // u and pre live in the sample group's tape, out is the caller's [groups * group_n] tensor
+    const int grp = blockIdx.y / group_n, n = blockIdx.y - grp * group_n;
+    u += grp * gs;
+    if (pre) pre += grp * gs;
+    out += static_cast<int64_t>(grp) * group_n * plane;
     const bool vec = (plane & 3) == 0;
     if (vec) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
@@ -259,11 +274,12 @@ __device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 
 // dbuf[c] = (gout * sign(pre)) * w[c] for all 192 planes (first writer of the level-0 gradient buffer)
 __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                              const float* __restrict__ wgt, float* __restrict__ dbuf,
-                                                             int64_t ns, int plane, int cin) {
+                                                             int64_t ns, int plane, int cin, int group_n, int64_t gs) {
     __shared__ float s_w[192];
     for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
     __syncthreads();
-    const int n = blockIdx.y;
+    const int grp = blockIdx.y / group_n, n = blockIdx.y - grp * group_n;
+    gout += static_cast<int64_t>(grp) * group_n * plane; pre += grp * gs; dbuf += grp * gs;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
         const float g = gout[static_cast<int64_t>(n) * plane + i] * sign_of(pre[static_cast<int64_t>(n) * plane + i]);
         for (int c = 0; c < cin; ++c) dbuf[n * ns + static_cast<int64_t>(c) * plane + i] = g * s_w[c];
@@ -274,14 +290,13 @@ __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __rest
 // two independent accumulators; g = gout * sign(pre) is recomputed from two L2-resident planes.
 __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                                const float* __restrict__ u, int64_t ns, int plane, int cin,
-                                                               int nsamples, float* __restrict__ gw, float* __restrict__ gb) {
+                                                               int group_n, int64_t gs, float* __restrict__ gw, float* __restrict__ gb) {
     __shared__ double scratch[4];
     const int c = blockIdx.x;
-    const int n = blockIdx.z;
-    (void)nsamples;
-    const float* gp = gout + static_cast<int64_t>(n) * plane;
-    const float* pp = pre + static_cast<int64_t>(n) * plane;
-    const float* up = u + n * ns + static_cast<int64_t>(c < cin ? c : 0) * plane;
+    const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;
+    const float* gp = gout + static_cast<int64_t>(blockIdx.z) * plane;
+    const float* pp = pre + grp * gs + static_cast<int64_t>(n) * plane;
+    const float* up = u + grp * gs + n * ns + static_cast<int64_t>(c < cin ? c : 0) * plane;
     float part = 0.f, part2 = 0.f;
     if ((plane & 3) == 0) {
         const int stride = gridDim.y * blockDim.x * 4;
@@ -320,6 +335,7 @@ struct Ctx {
     int training;
     hipStream_t stream;
 
+    int nt() const { return net->n * net->groups; }      // samples of all groups
     float* act(int level) const { return tape + net->lv[level].act; }
     float* gbuf(int level) const { return gradws + net->lv[level].grad; }
     double* sums(int level) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(tape) + net->sums_off) + net->lv[level].sums; }
@@ -338,7 +354,7 @@ static void fill_bn_in(const Ctx& c, ConvParams& p, const BnP& b, int level, int
     p.running_mean = c.bn_running + b.run;
     p.running_var = c.bn_running + b.run + b.c;
     p.saved = c.tape ? c.saved(b) : nullptr;
-    p.count = static_cast<double>(c.net->n) * lv.h * lv.w;
+    p.count = static_cast<double>(c.net->n) * lv.h * lv.w;      // per sample group
     p.eps = kBnEps;
     p.momentum = kBnMomentum;
     p.training = c.training;
@@ -364,11 +380,12 @@ static void fill_out(const Ctx& c, ConvParams& p, float* base, int level, int oc
 
 static void fill_grid(const Ctx& c, ConvParams& p, int level) {
     const auto& lv = c.net->lv[level];
-    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.n = c.nt(); p.h = lv.h; p.w = lv.w;
+    p.group_n = c.net->n; p.gs = c.net->gs; p.in_gs = c.net->gs; p.out_gs = c.net->gs;      // tape / workspace pointers by default
 }
 
 static double conv_flops(const endo_net* net, int level, int cin, int cout, int ks) {
-    return 2.0 * net->n * net->lv[level].plane * cin * cout * ks * ks;
+    return 2.0 * net->n * net->groups * net->lv[level].plane * cin * cout * ks * ks;
 }
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
@@ -382,13 +399,13 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     fill_out(c, p, c.act(level), level, oc0, cv.cout);
     p.out_sums = c.sums(level) + 2 * oc0;
     ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
-                   4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+                   4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over
     // blockIdx.y, write raw partial sums, and let a small kernel add them up (+ bias, + BN statistics).
     // Scratch bound: slices * N * plane <= (768 / tiles + 1) * 128 * tiles <= 98304 + 65536 floats per channel.
-    const long tiles_big = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.net->n;
-    const long tiles_mid = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 15) / 16) * c.net->n;
-    const long tiles_small = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 7) / 8) * c.net->n;
+    const long tiles_big = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
+    const long tiles_mid = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 15) / 16) * c.nt();
+    const long tiles_small = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 7) / 8) * c.nt();
     const int nchunks = (cv.cin + 15) / 16;
     if (tiles_big < 512 && tiles_mid < 384 && tiles_small < 512 && nchunks >= 4) {
         int want = static_cast<int>(((tiles_small < 256 ? 512 : 768) + tiles_small - 1) / tiles_small);
@@ -397,16 +414,16 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         const int ksplit = (nchunks + per - 1) / per;
         float* partial = c.tape + c.net->partial_off;
         p.ksplit = ksplit;
-        p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;
+        p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;      // inside one group's tape
         p.out = partial; p.out_ns = static_cast<int64_t>(cv.cout) * lv.plane;
         p.bias = nullptr; p.out_sums = nullptr;
         int rc = launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
         if (rc) return rc;
         int bx = static_cast<int>((lv.plane + 255) / 256);
         bx = bx > 8 ? 8 : bx;
-        finalize_partial_kernel<<<dim3(bx, cv.cout, c.net->n), 256, 0, c.stream>>>(
+        finalize_partial_kernel<<<dim3(bx, cv.cout, c.nt()), 256, 0, c.stream>>>(
             partial, p.split_stride, ksplit, p.out_ns, static_cast<int>(lv.plane), c.params + cv.b, c.act(level) + oc0 * lv.plane,
-            lv.t * lv.plane, c.sums(level) + 2 * oc0);
+            lv.t * lv.plane, c.sums(level) + 2 * oc0, c.net->n, c.net->gs);
         ENDO_LAUNCH_CHECK();
         return 0;
     }
@@ -429,7 +446,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.idx_ns = static_cast<int64_t>(cv.cout) * c.net->lv[next].plane;
     p.out_sums = c.sums(next) + 2 * oc0;
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
-                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
+                   4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
     return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL>(p, c.stream);
 }
 
@@ -442,7 +459,7 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     fill_out(c, p, c.act(level), level, 0, cv.cout);
     p.out_sums = c.sums(level);
     ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
-                   4.0 * c.net->n * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
+                   4.0 * c.nt() * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
     return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
@@ -450,10 +467,10 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad)
     const auto& lv = c.net->lv[level];
     int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
     bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
-    ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.net->n * lv.plane * count);
-    prep_dy_kernel<<<dim3(bx, count, c.net->n), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
+    ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.nt() * lv.plane * count);
+    prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
-                                                                     c.pq_q(level) + c0, bias_grad);
+                                                                     c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -465,17 +482,18 @@ static int bn_finalize(const Ctx& c, const BnP& b, int level, int ic0, int first
     if (count < 0) count = b.c - first;
     if (count <= 0) return 0;
     ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
-    bn_bwd_finalize_kernel<<<(count + 127) / 128, 128, 0, c.stream>>>(c.scratch(b) + 2 * first, c.saved(b) + 2 * first, c.params + b.g + first,
+    bn_bwd_finalize_kernel<<<dim3((count + 127) / 128, c.net->groups), 128, 0, c.stream>>>(c.scratch(b) + 2 * first, c.saved(b) + 2 * first, c.params + b.g + first,
                                                                        c.grads + b.g + first, c.grads + b.b + first,
                                                                        c.pq_p(level) + ic0 + first, c.pq_q(level) + ic0 + first, count,
-                                                                       static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+                                                                       static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
 static void fill_wgrad_grid(const Ctx& c, WgradParams& p, int level) {
     const auto& lv = c.net->lv[level];
-    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.n = c.nt(); p.h = lv.h; p.w = lv.w;
+    p.group_n = c.net->n; p.gs = c.net->gs; p.in_gs = c.net->gs;
     p.tiles_x = (lv.w + kWgTileX - 1) / kWgTileX;
     p.tiles_y = (lv.h + kWgTileY - 1) / kWgTileY;
 }
@@ -488,7 +506,7 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b;
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
-    ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin + cv.cout));
+    ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream);
     return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }
@@ -510,7 +528,7 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
         p.bn_scratch = c.scratch(b);
         p.acc_from = acc_from - ic0;
-        ProfScope prof(kProfDgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (3.0 * cv.cin + cv.cout));
+        ProfScope prof(kProfDgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (3.0 * cv.cin + cv.cout));
         rc = launch_dgrad_dense_auto(p, c.stream);
         if (rc) return rc;
     }
@@ -530,7 +548,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     DgradBlockParams probe{};
     probe.w = lv.w; probe.cs = static_cast<int>(lv.plane); probe.ns = lv.t * lv.plane;
     probe.x = c.act(level) + ic0 * lv.plane; probe.out = c.gbuf(level) + ic0 * lv.plane;
-    const long tiles = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 5) / 6) * c.net->n;
+    const long tiles = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 5) / 6) * c.nt();
     (void)tiles;          // few tiles: the fused kernel slices the channel groups over blockIdx.y
     if (!dgrad_block_ok(probe)) {
         for (int j = kLayers - 1; j >= 0; --j) {
@@ -541,7 +559,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         return 0;
     }
     auto fill_common = [&](DgradBlockParams& p) {
-        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+        p.n = c.nt(); p.h = lv.h; p.w = lv.w;
+        p.group_n = c.net->n; p.gs = c.net->gs;
         p.g_ns = lv.t * lv.plane; p.g_cs = static_cast<int>(lv.plane); p.g_w = lv.w;
         p.ns = lv.t * lv.plane; p.cs = static_cast<int>(lv.plane);
     };
@@ -562,8 +581,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             p.wgt[0] = c.params + cv[j].w; p.w_cin[0] = cv[j].cin;
             p.saved[0] = c.saved(bn[j]) + 2 * c0; p.gamma[0] = c.params + bn[j].g + c0; p.beta[0] = c.params + bn[j].b + c0;
             p.scratch[0] = c.scratch(bn[j]) + 2 * c0;
-            ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.net->n * lv.plane * p.count * kGrowth * 9,
-                           4.0 * c.net->n * lv.plane * (3.0 * p.count + kGrowth));
+            ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * p.count * kGrowth * 9,
+                           4.0 * c.nt() * lv.plane * (3.0 * p.count + kGrowth));
             rc = launch_dgrad_block<1, 2, 3>(p, c.stream);
             if (rc) return rc;
             rc = bn_finalize(c, bn[j], level, ic0, c0, kGrowth * j);
@@ -584,8 +603,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             p.saved[j] = c.saved(bn[j]); p.gamma[j] = c.params + bn[j].g; p.beta[j] = c.params + bn[j].b;
             p.scratch[j] = c.scratch(bn[j]);
         }
-        ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.net->n * lv.plane * c0 * kGrowth * 9 * kLayers,
-                       4.0 * c.net->n * lv.plane * (3.0 * c0 + kGrowth * kLayers));
+        ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * c0 * kGrowth * 9 * kLayers,
+                       4.0 * c.nt() * lv.plane * (3.0 * c0 + kGrowth * kLayers));
         int rc = launch_dgrad_block<4, 2, 3>(p, c.stream);
         if (rc) return rc;
     }
@@ -596,8 +615,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             a.ggamma[j] = c.grads + bn[j].g; a.gbeta[j] = c.grads + bn[j].b;
         }
         ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
-        bn_bwd_finalize4_kernel<<<(c0 + 127) / 128, 128, 0, c.stream>>>(a, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
-                                                                         static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+        bn_bwd_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(a, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
+                                                                         static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
         ENDO_LAUNCH_CHECK();
     }
     return 0;
@@ -618,7 +637,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.dy = c.gbuf(next) + oc0 * nx.plane; p.dy_ns = nx.t * nx.plane; p.dy_cs = static_cast<int>(nx.plane); p.dy_w = nx.w; p.cout = cv.cout;
         p.dy_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;
         p.dw = c.grads + cv.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * cv.cin);
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * cv.cin);
         rc = wgrad1x1_dma_ok(p) ? launch_wgrad1x1_dma(p, c.stream) : launch_wgrad1x1(p, c.stream);
         if (rc) return rc;
     }
@@ -633,7 +652,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
         p.bn_scratch = c.scratch(b);
         p.acc_from = 0;
-        ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.net->n * lv.plane * 3.0 * cv.cin);
+        ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
         rc = (nx.w % 4 == 0) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream)
                              : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
@@ -653,7 +672,7 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.in = c.act(src_level) + src_c0 * sv.plane; p.in_ns = sv.t * sv.plane; p.in_cs = static_cast<int>(sv.plane); p.in_w = sv.w; p.cin = cv.cin;
         p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cin / 4.0 + cv.cout));
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin / 4.0 + cv.cout));
         rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
@@ -662,7 +681,7 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     fill_in(c, p, c.gbuf(level), level, 0, cv.cout);
     p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
-    ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.net->n * lv.plane * (cv.cout + cv.cin / 4.0));
+    ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cout + cv.cin / 4.0));
     return launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_DGRAD_SUMPOOL, 4>(p, c.stream);
 }
 
@@ -673,13 +692,14 @@ static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // ---------------------------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------------------------
-extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
-    if (!out || n <= 0 || h <= 0 || w <= 0) return ENDO_E_BADARG;
+extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int groups) {
+    if (!out || n <= 0 || h <= 0 || w <= 0 || groups <= 0) return ENDO_E_BADARG;
+    if (groups > kMaxGroups) return ENDO_E_UNSUPPORTED;
     if ((h % 32) != 0 || (w % 32) != 0) return ENDO_E_UNSUPPORTED;   // 5 poolings + exact centre crop (models.py:93-97)
     const Table& tb = table();
     endo_net* net = new (std::nothrow) endo_net();
     if (!net) return ENDO_E_BADARG;
-    net->n = n; net->h = h; net->w = w;
+    net->n = n; net->h = h; net->w = w; net->groups = groups;
     int64_t off = 0, sums = 0, pq = 0;
     for (int l = 0; l <= kLevels; ++l) {
         auto& lv = net->lv[l];
@@ -710,15 +730,22 @@ extern "C" int endo_net_create(endo_net** out, int n, int h, int w) {
     net->scratch_bytes = tb.bn_width_total * 2 * 8;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
     net->gradws_floats = net->wg_scratch_off + kNsScratchFloats;
+    // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
+    // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
+    net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
     *out = net;
     return 0;
 }
 
+extern "C" int endo_net_create(endo_net** out, int n, int h, int w) { return endo_net_create_grouped(out, n, h, w, 1); }
+
 extern "C" void endo_net_destroy(endo_net* net) { delete net; }
 extern "C" int64_t endo_net_param_floats(void) { return table().param_floats; }
 extern "C" int64_t endo_net_bn_floats(void) { return table().bn_floats; }
-extern "C" int64_t endo_net_tape_floats(const endo_net* net) { return net ? net->tape_floats : 0; }
-extern "C" int64_t endo_net_gradws_floats(const endo_net* net) { return net ? net->gradws_floats : 0; }
+extern "C" int64_t endo_net_tape_floats(const endo_net* net) { return !net ? 0 : (net->groups > 1 ? net->groups * net->gs : net->tape_floats); }
+extern "C" int64_t endo_net_gradws_floats(const endo_net* net) { return !net ? 0 : (net->groups > 1 ? net->groups * net->gs : net->gradws_floats); }
+extern "C" int endo_net_groups(const endo_net* net) { return net ? net->groups : 0; }
+extern "C" int64_t endo_net_group_stride(const endo_net* net) { return net ? net->gs : 0; }
 extern "C" int64_t endo_net_param_offset(int index) {
     const Table& tb = table();
     if (index < 0 || index >= static_cast<int>(tb.param_offsets.size())) return -1;
@@ -737,16 +764,18 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     if (!net || !params || !bn_running || !x || !out || !tape) return ENDO_E_BADARG;
     const Table& tb = table();
     Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
-    ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape) + net->sums_off, 0, net->sums_bytes, c.stream));
+    for (int g = 0; g < net->groups; ++g)
+        ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape + g * net->gs) + net->sums_off, 0, net->sums_bytes, c.stream));
     int rc;
     {   // first conv 3 -> 48 into level-0 channels [48, 96)
         ConvParams p{};
         fill_grid(c, p, 0);
         p.in = x; p.in_ns = 3 * net->lv[0].plane; p.in_cs = static_cast<int>(net->lv[0].plane); p.in_w = net->w; p.cin = 3;
+        p.in_gs = net->n * p.in_ns;                 // x is the caller's [groups * n][3][H][W] tensor
         p.wgt = params + tb.first.w; p.bias = params + tb.first.b; p.w_cout = kFirst; p.w_cin = 3;
         fill_out(c, p, c.act(0), 0, 48, kFirst);
         p.out_sums = c.sums(0) + 2 * 48;
-        ProfScope prof(kProfConvFirst, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * net->lv[0].plane * (3 + kFirst));
+        ProfScope prof(kProfConvFirst, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * net->lv[0].plane * (3 + kFirst));
         rc = launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_FWD>(p, c.stream);
         if (rc) return rc;
     }
@@ -775,11 +804,12 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     }
     {
         const auto& lv = net->lv[0];
-        ProfScope prof(kProfConvFinal, c.stream, 2.0 * net->n * lv.plane * 192, 4.0 * net->n * lv.plane * 194);
+        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * 194);
         int bx = static_cast<int>((lv.plane / 4 + 255) / 256);
         bx = bx < 1 ? 1 : bx;
-        final_fwd_kernel<<<dim3(bx, net->n), 256, 0, c.stream>>>(c.act(0), lv.t * lv.plane, static_cast<int>(lv.plane), 192,
-                                                                 params + tb.final_.w, params + tb.final_.b, tape + net->pre_off, out);
+        final_fwd_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(c.act(0), lv.t * lv.plane, static_cast<int>(lv.plane), 192,
+                                                                 params + tb.final_.w, params + tb.final_.b, tape + net->pre_off, out,
+                                                                 net->n, net->gs);
         ENDO_LAUNCH_CHECK();
     }
     return 0;
@@ -791,19 +821,20 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     const Table& tb = table();
     Ctx c{net, params, nullptr, const_cast<float*>(tape), grads, gradws, training, static_cast<hipStream_t>(stream_)};
     // zero the deferred-term tables and the BN reduction scratch
-    ENDO_CHECK(hipMemsetAsync(gradws + net->pq_off, 0,
-                              static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
+    for (int g = 0; g < net->groups; ++g)
+        ENDO_CHECK(hipMemsetAsync(gradws + g * net->gs + net->pq_off, 0,
+                                  static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
     int rc;
     {
         const auto& lv = net->lv[0];
-        ProfScope prof(kProfConvFinal, c.stream, 4.0 * net->n * lv.plane * 192, 4.0 * net->n * lv.plane * (2 * 192 + 4));
+        ProfScope prof(kProfConvFinal, c.stream, 4.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (2 * 192 + 4));
         int bx = static_cast<int>((lv.plane + 255) / 256);
-        final_bwd_data_kernel<<<dim3(bx, net->n), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
-                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), 192);
+        final_bwd_data_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
+                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), 192, net->n, net->gs);
         int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
         by = by < 1 ? 1 : (by > 16 ? 16 : by);
-        final_bwd_weight_kernel<<<dim3(193, by, net->n), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
-                                                                     static_cast<int>(lv.plane), 192, net->n, grads + tb.final_.w,
+        final_bwd_weight_kernel<<<dim3(193, by, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
+                                                                     static_cast<int>(lv.plane), 192, net->n, net->gs, grads + tb.final_.w,
                                                                      grads + tb.final_.b);
         ENDO_LAUNCH_CHECK();
     }
@@ -831,9 +862,10 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         WgradParams p{};
         fill_wgrad_grid(c, p, 0);
         p.in = x; p.in_ns = 3 * lv.plane; p.in_cs = static_cast<int>(lv.plane); p.in_w = lv.w; p.cin = 3;
+        p.in_gs = net->n * p.in_ns;                 // the caller's image tensor
         p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
         p.dw = grads + tb.first.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * net->n * lv.plane * (3 + kFirst));
+        ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * lv.plane * (3 + kFirst));
         return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, c.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
     }
 }

@@ -98,9 +98,9 @@ extern "C" int endo_sparse_scatter(const double* points, int n_points, const dou
                                    float* flows, void* stream_) {
     using namespace endo;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (!points || !projections || !extrinsics || !visibility || !mask || !winner_scratch || !depth_masks || !depths || !flow_masks || !flows)
-        return ENDO_E_BADARG;
     if (n_points < 0 || batch <= 0 || height <= 0 || width <= 0) return ENDO_E_BADARG;
+    if (!projections || !extrinsics || !mask || !winner_scratch || !depth_masks || !depths || !flow_masks || !flows) return ENDO_E_BADARG;
+    if (n_points > 0 && (!points || !visibility)) return ENDO_E_BADARG;      // an empty cloud has no point / visibility storage
     const size_t planes = static_cast<size_t>(2) * batch * height * width;
     ENDO_CHECK(hipMemsetAsync(winner_scratch, 0xFF, planes * sizeof(int32_t), stream));       // -1
     ENDO_CHECK(hipMemsetAsync(depth_masks, 0, planes * sizeof(float), stream));

@@ -39,16 +39,21 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
     const int wr = wave >> 1, wc = wave & 1;      // wave's 48 x 48 quadrant of the 96 x 96 tile
 
     float sc[3], mn[3], bt[3];
+    int cur_grp = -1;
+    auto load_consts = [&](int g) {           // BN constants of this lane's 3 input channels for sample group g
+        const float* saved = p.saved + g * p.gs;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int ch = ci_base + wc * 48 + j * 16 + li;
-        sc[j] = 0.f; mn[j] = 0.f; bt[j] = 0.f;       // rows past cin hold the NaN pad: max(fma(NaN, 0, 0), 0) = 0
-        if (ch < p.cin) {
-            mn[j] = p.saved[2 * ch];
-            sc[j] = p.gamma[ch] * p.saved[2 * ch + 1];
-            bt[j] = p.beta[ch];
+        for (int j = 0; j < 3; ++j) {
+            const int ch = ci_base + wc * 48 + j * 16 + li;
+            sc[j] = 0.f; mn[j] = 0.f; bt[j] = 0.f;       // rows past cin hold the NaN pad: max(fma(NaN, 0, 0), 0) = 0
+            if (ch < p.cin) {
+                mn[j] = saved[2 * ch];
+                sc[j] = p.gamma[ch] * saved[2 * ch + 1];
+                bt[j] = p.beta[ch];
+            }
         }
-    }
+        cur_grp = g;
+    };
 
     f32x4 acc[3][3];
 #pragma unroll
@@ -69,10 +74,11 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
         const int rem = chunk - n * chunks_per_sample;
         const int y2 = rem / segs;
         const int xs = (rem - y2 * segs) * kP1Seg;
+        const WgSample sm(p, n);
         float* s_act = smem + buf * kP1Buf;
         float* s_dy = s_act + kP1Tile * kP1ActStride;
         const bool a_ok = xs + ax < p.w;
-        const float* abase = p.in + n * p.in_ns + static_cast<int64_t>(2 * y2 + arow) * p.in_w + xs + ax;
+        const float* abase = p.in + sm.in_off(p) + static_cast<int64_t>(2 * y2 + arow) * p.in_w + xs + ax;
 #pragma unroll 4
         for (int t = 0; t < kP1Tile / 4; ++t) {
             const int r = wave * (kP1Tile / 4) + t;
@@ -84,8 +90,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
         const int pxs = xs >> 1;
         const bool d_ok = pxs + dcol < (p.w >> 1);
         const int64_t poff = static_cast<int64_t>(y2) * p.dy_w + pxs + dcol;
-        const char* dbase = dy_is_code ? reinterpret_cast<const char*>(p.dy_idx + n * p.idx_ns + poff)
-                                       : reinterpret_cast<const char*>(p.dy + n * p.dy_ns + poff);
+        const char* dbase = dy_is_code ? reinterpret_cast<const char*>(p.dy_idx + sm.idx_off(p) + poff)
+                                       : reinterpret_cast<const char*>(p.dy + sm.dy_off(p) + poff);
 #pragma unroll 4
         for (int t = 0; t < kP1Tile / 4; ++t) {
             const int r = wave * (kP1Tile / 4) + t;
@@ -136,6 +142,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (chunk + static_cast<int>(gridDim.x) < chunks_total) issue(chunk + gridDim.x, b ^ 1);
+        const int g = WgSample(p, chunk / chunks_per_sample).grp;
+        if (g != cur_grp) load_consts(g);
         compute(b);
     }
     // lane holds D[co = 4*lk + e][ci = li] of each 16 x 16 sub-tile

@@ -41,7 +41,26 @@ struct WgradParams {
     int64_t idx_ns;
     int cout;
     float* dw;               // [cout][cin][KS*KS], accumulated
+    // grouped batch (see ConvParams): n counts groups * group_n samples; sample s belongs to group s / group_n, whose
+    // dy / dy_idx / saved live gs floats further on and whose activations in_gs floats further on.  dw sums over all groups.
+    int group_n;
+    int64_t gs, in_gs;
 };
+
+constexpr int kMaxGroups = 4;
+
+// group and in-group index of global sample s; offsets of its planes
+struct WgSample {
+    int grp, nl;
+    __device__ __forceinline__ WgSample(const WgradParams& p, int s) {
+        grp = p.group_n > 0 ? s / p.group_n : 0;
+        nl = s - grp * p.group_n;
+    }
+    __device__ __forceinline__ int64_t in_off(const WgradParams& p) const { return grp * p.in_gs + nl * p.in_ns; }
+    __device__ __forceinline__ int64_t dy_off(const WgradParams& p) const { return grp * p.gs + nl * p.dy_ns; }
+    __device__ __forceinline__ int64_t idx_off(const WgradParams& p) const { return 4 * grp * p.gs + nl * p.idx_ns; }
+};
+__device__ __forceinline__ int wg_groups(const WgradParams& p) { return p.group_n > 0 ? p.n / p.group_n : 1; }
 
 template <int KS>
 struct WgradGeom {
@@ -68,7 +87,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_in = smem;                        // [16][kCS]
     float* s_dy = s_in + kWgKC * G::kCS;       // [NB][kDS]
-    __shared__ float s_cst[4 * kWgKC];   // scale, mean, beta per input channel
+    __shared__ float s_cst[kMaxGroups * 4 * kWgKC];   // per group: scale, mean, beta per input channel
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -81,17 +100,19 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     const int tiles_total = tiles_per_sample * p.n;
 
     if constexpr (IN == IN_BNRELU) {
-        if (tid < kWgKC) {
-            const int c = ci_base + tid;
+        if (tid < kWgKC * wg_groups(p)) {
+            const int g = tid / kWgKC, t = tid - g * kWgKC;
+            const int c = ci_base + t;
             float scale = 0.f, mean = 0.f, beta = 0.f;
             if (c < p.cin) {
-                mean = p.saved[2 * c];
-                scale = p.gamma[c] * p.saved[2 * c + 1];
+                const float* saved = p.saved + g * p.gs;
+                mean = saved[2 * c];
+                scale = p.gamma[c] * saved[2 * c + 1];
                 beta = p.beta[c];
             }
-            s_cst[tid] = scale;
-            s_cst[kWgKC + tid] = mean;
-            s_cst[2 * kWgKC + tid] = beta;
+            s_cst[g * 4 * kWgKC + t] = scale;
+            s_cst[g * 4 * kWgKC + kWgKC + t] = mean;
+            s_cst[g * 4 * kWgKC + 2 * kWgKC + t] = beta;
         }
     }
 
@@ -117,12 +138,15 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     static_assert(kWgTileX * kWgTileY == kConvThreads, "one dY pixel per thread");
     static_assert(kDyPre == NB, "dY staging is one value per thread per output channel");
 
+    int pre_grp = 0;         // group of the tile held in `pre`
     auto load_tile = [&](int tile) {
         const int n = tile / tiles_per_sample;
         const int trem = tile - n * tiles_per_sample;
         const int x0 = (trem % p.tiles_x) * kWgTileX;
         const int y0 = (trem / p.tiles_x) * kWgTileY;
-        const float* in_n = p.in + n * p.in_ns;
+        const WgSample sm(p, n);
+        pre_grp = sm.grp;
+        const float* in_n = p.in + sm.in_off(p);
         pos_ok = 0;
         int goff[G::kPos];
 #pragma unroll
@@ -146,7 +170,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
         }
         const int gy = y0 + dy_ry, gx = x0 + dy_rx;
         const bool ok = gy < p.h && gx < p.w;
-        const float* dy_n = p.dy + n * p.dy_ns;
+        const float* dy_n = p.dy + sm.dy_off(p);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int co = co_base + j;
@@ -155,7 +179,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
                 if constexpr (DY == DY_UNPOOL) {
                     const int64_t o = static_cast<int64_t>(co) * p.dy_cs + (gy >> 1) * p.dy_w + (gx >> 1);
                     const int code = ((gy & 1) << 1) | (gx & 1);
-                    v = (p.dy_idx[n * p.idx_ns + o] == code) ? dy_n[o] : 0.f;
+                    v = (p.dy_idx[sm.idx_off(p) + o] == code) ? dy_n[o] : 0.f;
                 } else {
                     v = dy_n[static_cast<int64_t>(co) * p.dy_cs + gy * p.dy_w + gx];
                 }
@@ -165,6 +189,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
     };
 
     auto store_tile = [&]() {
+        const float* cst = s_cst + pre_grp * 4 * kWgKC;
 #pragma unroll
         for (int c = 0; c < kWgKC; ++c) {
 #pragma unroll
@@ -174,7 +199,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_mfma_kernel(const WgradPar
                     float v = pre[c * G::kPos + k];
                     if constexpr (IN == IN_BNRELU) {
                         if (ci_base + c < p.cin && (pos_ok & (1u << k))) {
-                            v = fmaf(v - s_cst[kWgKC + c], s_cst[c], s_cst[2 * kWgKC + c]);
+                            v = fmaf(v - cst[kWgKC + c], cst[c], cst[2 * kWgKC + c]);
                             v = v > 0.f ? v : 0.f;
                         } else {
                             v = 0.f;
@@ -289,7 +314,7 @@ constexpr int kW1Pre = kW1Rows * kW1Chunk / kConvThreads;   // 48 staged values 
 
 __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const WgradParams p) {
     __shared__ float s_t[kW1Rows * kW1Stride];
-    __shared__ float s_cst[3 * kW1Tile];
+    __shared__ float s_cst[kMaxGroups * 3 * kW1Tile];       // per group: scale, mean, beta
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -301,15 +326,18 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const Wgrad
     const int chunks_per_sample = (plane + kW1Chunk - 1) / kW1Chunk;
     const int chunks_total = chunks_per_sample * p.n;
 
-    for (int c = tid; c < kW1Tile; c += kConvThreads) {
+    for (int e = tid; e < kW1Tile * wg_groups(p); e += kConvThreads) {
+        const int g = e / kW1Tile, c = e - g * kW1Tile;
         const int ch = ci_base + c;
         float scale = 0.f, mean = 0.f, beta = 0.f;
         if (ch < p.cin) {
-            mean = p.saved[2 * ch];
-            scale = p.gamma[ch] * p.saved[2 * ch + 1];
+            const float* saved = p.saved + g * p.gs;
+            mean = saved[2 * ch];
+            scale = p.gamma[ch] * saved[2 * ch + 1];
             beta = p.beta[ch];
         }
-        s_cst[c] = scale; s_cst[kW1Tile + c] = mean; s_cst[2 * kW1Tile + c] = beta;
+        float* cst = s_cst + g * 3 * kW1Tile;
+        cst[c] = scale; cst[kW1Tile + c] = mean; cst[2 * kW1Tile + c] = beta;
     }
 
     f32x4 acc[3][3];
@@ -322,9 +350,12 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const Wgrad
     const int row0 = tid >> 6;          // rows row0 + 4k
     float pre[kW1Pre];
     bool pix_ok = false;
+    int pre_grp = 0;
 
     auto load_chunk = [&](int chunk) {
         const int n = chunk / chunks_per_sample;
+        const WgSample sm(p, n);
+        pre_grp = sm.grp;
         const int pix = (chunk - n * chunks_per_sample) * kW1Chunk + px;
         pix_ok = pix < plane;
         int pooled = 0, code = 0;
@@ -333,9 +364,9 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const Wgrad
             pooled = (y >> 1) * p.dy_w + (x >> 1);
             code = ((y & 1) << 1) | (x & 1);
         }
-        const float* dy_n = p.dy + n * p.dy_ns;
-        const uint8_t* idx_n = p.dy_idx + n * p.idx_ns;
-        const float* in_n = p.in + n * p.in_ns;
+        const float* dy_n = p.dy + sm.dy_off(p);
+        const uint8_t* idx_n = p.dy_idx + sm.idx_off(p);
+        const float* in_n = p.in + sm.in_off(p);
 #pragma unroll
         for (int k = 0; k < kW1Pre / 2; ++k) {          // dY rows
             const int co = co_base + row0 + 4 * k;
@@ -353,6 +384,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const Wgrad
         }
     };
     auto store_chunk = [&]() {
+        const float* cst = s_cst + pre_grp * 3 * kW1Tile;
 #pragma unroll
         for (int k = 0; k < kW1Pre / 2; ++k) s_t[(row0 + 4 * k) * kW1Stride + px] = pre[k];
 #pragma unroll
@@ -360,7 +392,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_mfma_kernel(const Wgrad
             const int r = row0 + 4 * k;
             float v = 0.f;
             if (pix_ok && ci_base + r < p.cin) {
-                v = fmaf(pre[kW1Pre / 2 + k] - s_cst[kW1Tile + r], s_cst[r], s_cst[2 * kW1Tile + r]);
+                v = fmaf(pre[kW1Pre / 2 + k] - cst[kW1Tile + r], cst[r], cst[2 * kW1Tile + r]);
                 v = v > 0.f ? v : 0.f;
             }
             s_t[(kW1Tile + r) * kW1Stride + px] = v;

@@ -59,16 +59,22 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     float sc[NG], mn[NG], bt[NG];
     bool ch_ok[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const int ch = 16 * (group0 + g) + li;
-        ch_ok[g] = g < ngw && ch < p.cin;
-        sc[g] = 0.f; mn[g] = 0.f; bt[g] = 0.f;
-        if (ch_ok[g]) {
-            mn[g] = p.saved[2 * ch];
-            sc[g] = p.gamma[ch] * p.saved[2 * ch + 1];
-            bt[g] = p.beta[ch];
+    for (int g = 0; g < NG; ++g) ch_ok[g] = g < ngw && 16 * (group0 + g) + li < p.cin;
+    int cst_grp = -1;                          // sample group whose BN constants sit in sc / mn / bt
+    auto load_consts = [&](int sg) {
+        const float* saved = p.saved + sg * p.gs;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int ch = 16 * (group0 + g) + li;
+            sc[g] = 0.f; mn[g] = 0.f; bt[g] = 0.f;
+            if (ch_ok[g]) {
+                mn[g] = saved[2 * ch];
+                sc[g] = p.gamma[ch] * saved[2 * ch + 1];
+                bt[g] = p.beta[ch];
+            }
         }
-    }
+        cst_grp = sg;
+    };
 
     // per-lane gather offsets into the dY window: row m = 16 g + li = co * 9 + ky * 3 + kx reads
     // dY[co][y + 1 - ky][x + 1 - kx]  ->  window row 2 - ky, window col x + 5 - kx
@@ -100,8 +106,9 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         const int rem = chunk - n * segs * p.h;
         const int y = rem / segs;
         const int x0 = (rem - y * segs) * kNsSeg;
+        const WgSample sm(p, n);
         float* s_dy = smem + buf * kNsBuf;
-        const float* dy_n = p.dy + n * p.dy_ns;
+        const float* dy_n = p.dy + sm.dy_off(p);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e0 = k * kConvThreads + wave * 64;
@@ -116,7 +123,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
                 if (!(EXP & 2) && e < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
             }
         }
-        const float* in_n = p.in + n * p.in_ns + static_cast<int64_t>(y) * p.in_w + x0 + 4 * lk;
+        const float* in_n = p.in + sm.in_off(p) + static_cast<int64_t>(y) * p.in_w + x0 + 4 * lk;
         xr_ok = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -138,6 +145,10 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(EXP & 4)) __syncthreads();
         // BN + ReLU of this chunk's activations (registers), then start the next chunk's loads
+        {
+            const int sg = WgSample(p, chunk / (segs * p.h)).grp;
+            if (sg != cst_grp) load_consts(sg);
+        }
         f32x4 bv[NG][2];
 #pragma unroll
         for (int g = 0; g < NG; ++g)

@@ -35,7 +35,7 @@ struct WgradTapsGeom {
     static constexpr int kInUnits = kInPlane / 4;             // 64 float4 per channel
     static constexpr int kDyUnits = kDyPlane / 4;             // 100 float4 per map
     static constexpr size_t kRed = 4 * kMG * 256;             // cross-wave reduction scratch (floats)
-    static constexpr size_t kFloats = (2 * kBuf > static_cast<int>(kRed) ? 2 * kBuf : kRed) + 64;
+    static constexpr size_t kFloats = (2 * kBuf > static_cast<int>(kRed) ? 2 * kBuf : kRed) + 64 * kMaxGroups;
     static constexpr size_t kBytes = sizeof(float) * kFloats;
     static_assert(kBytes <= 160 * 1024, "two tile buffers must fit the 160 KiB LDS");
 };
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
     static_assert(IN == IN_BNRELU || IN == IN_PLAIN || IN == IN_UPSAMPLE, "supported activation load paths");
     constexpr int MG = G::kMG;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_cst = smem + G::kFloats - 64;       // scale, mean, beta of the block's 16 channels
+    float* s_cst = smem + G::kFloats - 64 * kMaxGroups;       // per group: scale, mean, beta of the block's 16 channels
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,15 +68,17 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int tiles_total = tiles_per_sample * p.n;
 
-    if (tid < 16) {
-        const int c = ci_base + tid;
+    if (tid < 16 * wg_groups(p)) {
+        const int g = tid >> 4, t = tid & 15;
+        const int c = ci_base + t;
         float scale = 1.f, mean = 0.f, beta = 0.f;
         if (IN == IN_BNRELU && c < p.cin) {
-            mean = p.saved[2 * c];
-            scale = p.gamma[c] * p.saved[2 * c + 1];
+            const float* saved = p.saved + g * p.gs;
+            mean = saved[2 * c];
+            scale = p.gamma[c] * saved[2 * c + 1];
             beta = p.beta[c];
         }
-        s_cst[tid] = scale; s_cst[16 + tid] = mean; s_cst[32 + tid] = beta;
+        s_cst[64 * g + t] = scale; s_cst[64 * g + 16 + t] = mean; s_cst[64 * g + 32 + t] = beta;
     }
 
     // per-lane gather offsets into the dY tile: row m = 16 g + li = co * 9 + ky * 3 + kx reads
@@ -102,6 +104,9 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         const int trem = tile - n * tiles_per_sample;
         const int x0 = (trem % p.tiles_x) * G::kTX;
         const int y0 = (trem / p.tiles_x) * G::kTY;
+        const WgSample sm(p, n);
+        const float* in_s = p.in + sm.in_off(p);
+        const float* dy_s = p.dy + sm.dy_off(p);
         float* s_in = smem + buf * G::kBuf;
         float* s_dy = s_in + 16 * G::kCS;
         if constexpr (IN == IN_UPSAMPLE) {
@@ -110,7 +115,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
             for (int k = 0; k < 4; ++k) {
                 const int c = wave + 4 * k;
                 const int ch = ci_base + c;
-                const float* plane = p.in + n * p.in_ns + static_cast<int64_t>(ch) * p.in_cs;
+                const float* plane = in_s + static_cast<int64_t>(ch) * p.in_cs;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int e = q * 64 + lane;
@@ -126,7 +131,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
             const int ry = e / (G::kTX / 4), rx = (e % (G::kTX / 4)) * 4;
             const int gy = y0 + ry, gx = x0 + rx;
             const bool ok = gy < p.h && gx < p.w;
-            const float* base = p.in + n * p.in_ns + gy * p.in_w + gx;
+            const float* base = in_s + gy * p.in_w + gx;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = wave + 4 * k;
@@ -140,7 +145,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         for (int k = 0; k < (COUT + 3) / 4; ++k) {
             const int co = wave + 4 * k;
             if (co < COUT && co_base + co < p.cout) {
-                const float* map = p.dy + n * p.dy_ns + static_cast<int64_t>(co_base + co) * p.dy_cs;
+                const float* map = dy_s + static_cast<int64_t>(co_base + co) * p.dy_cs;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const int u = half * 64 + lane;
@@ -175,7 +180,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
 
         const float* s_in = smem + (it & 1) * G::kBuf;
         const float* s_dy = s_in + 16 * G::kCS;
-        const float bsc = s_cst[li], bmn = s_cst[16 + li], bbt = s_cst[32 + li];
+        const float* cst = s_cst + 64 * WgSample(p, tile / tiles_per_sample).grp;
+        const float bsc = cst[li], bmn = cst[16 + li], bbt = cst[32 + li];
 #pragma unroll
         for (int rr = 0; rr < rows_per_wave; ++rr) {
             const int row = wave * rows_per_wave + rr;

@@ -95,21 +95,22 @@ class _NetFunction(torch.autograd.Function):
     """Whole-network forward/backward as ONE autograd node (the reference builds ~400 per call)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, net):
+    def forward(ctx, x, anchor, net, groups=1):
         x = _lib.dev_f32(x, "FCDenseNet57 input")
-        out, tape = net._run_forward(x)
+        out, tape = net._run_forward(x, groups)
         ctx.net = net
         ctx.training = net.training
         ctx.tape = tape
+        ctx.groups = groups
         ctx.save_for_backward(x)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (x,) = ctx.saved_tensors
-        ctx.net._run_backward(x, ctx.tape, grad_out, ctx.training)
+        ctx.net._run_backward(x, ctx.tape, grad_out, ctx.training, ctx.groups)
         ctx.tape = None
-        return None, None, None
+        return None, None, None, None
 
 
 class FCDenseNet(nn.Module):
@@ -234,14 +235,15 @@ class FCDenseNet(nn.Module):
                 p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
 
     # ---- HIP library plumbing ------------------------------------------------------------------
-    def _handle(self, n, h, w):
-        key = (n, h, w)
+    def _handle(self, n, h, w, groups=1):
+        """n = samples per group."""
+        key = (n, h, w, groups)
         if key not in self._handles:
             lib = _lib.load()
             if lib.endo_net_param_floats() != self._flat.numel():
                 raise RuntimeError("parameter packing mismatch between Python and libendo_hip.so")
             hnd = ctypes.c_void_p()
-            _lib.check(lib.endo_net_create(ctypes.byref(hnd), n, h, w), "endo_net_create(%d,%d,%d)" % key)
+            _lib.check(lib.endo_net_create_grouped(ctypes.byref(hnd), n, h, w, groups), "endo_net_create_grouped(%d,%d,%d,%d)" % key)
             self._handles[key] = (hnd, int(lib.endo_net_tape_floats(hnd)), int(lib.endo_net_gradws_floats(hnd)))
         return self._handles[key]
 
@@ -253,7 +255,7 @@ class FCDenseNet(nn.Module):
         except Exception:
             pass
 
-    def _run_forward(self, x):
+    def _run_forward(self, x, groups=1):
         lib = _lib.load()
         x = _lib.dev_f32(x, "FCDenseNet57 input")
         if x.dim() != 4 or x.shape[1] != 3:
@@ -263,20 +265,22 @@ class FCDenseNet(nn.Module):
         if not self._views_intact():
             self._flatten()
         n, _, h, w = x.shape
-        hnd, tape_floats, _ = self._handle(n, h, w)
+        if n % groups:
+            raise RuntimeError("batch of %d samples does not split into %d groups" % (n, groups))
+        hnd, tape_floats, _ = self._handle(n // groups, h, w, groups)
         tape = torch.empty(tape_floats, dtype=torch.float32, device=x.device)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         _lib.check(lib.endo_net_fwd(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out),
                                     _lib.ptr(tape), 1 if self.training else 0, _lib.stream()), "endo_net_fwd")
         if self.training:
-            self._nbt.add_(1)
+            self._nbt.add_(groups)
         return out, tape
 
-    def _run_backward(self, x, tape, grad_out, training):
+    def _run_backward(self, x, tape, grad_out, training, groups=1):
         lib = _lib.load()
         n, _, h, w = x.shape
-        hnd, _, gradws_floats = self._handle(n, h, w)
-        key = (n, h, w)
+        hnd, _, gradws_floats = self._handle(n // groups, h, w, groups)
+        key = (n, h, w, groups)
         if key not in self._gradws:
             self._gradws[key] = torch.empty(gradws_floats, dtype=torch.float32, device=x.device)
         self._attach_grads()
@@ -290,6 +294,22 @@ class FCDenseNet(nn.Module):
             return _NetFunction.apply(x, self._anchor, self)
         out, _ = self._run_forward(x)
         return out
+
+    def forward_pair(self, x1, x2):
+        """``(self(x1), self(x2))`` -- the two forward passes of a training step (reference train.py:276-277) -- as ONE
+        pass over a grouped batch: every kernel launch covers both frames, each frame keeps its own BatchNorm batch
+        statistics and the running statistics are updated first with x1's, then with x2's, so values and gradients
+        equal the two separate calls (up to fp32 summation order in the shared parameter gradients).  Half the
+        launches, twice the blocks per launch: it is what the coarse levels of the network need on 256 CUs."""
+        if x1.shape != x2.shape:
+            raise RuntimeError("forward_pair needs two batches of the same shape")
+        x = torch.cat([_lib.dev_f32(x1, "FCDenseNet57 input"), _lib.dev_f32(x2, "FCDenseNet57 input")], dim=0)
+        if torch.is_grad_enabled():
+            out = _NetFunction.apply(x, self._anchor, self, 2)
+        else:
+            out, _ = self._run_forward(x, 2)
+        n = x1.shape[0]
+        return out[:n], out[n:]
 
     def level_buffers(self, x):
         """Debug/test hook: run a forward and return the six level buffers (views of the tape)."""

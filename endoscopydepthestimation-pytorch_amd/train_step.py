@@ -44,8 +44,11 @@ def mask_mul(a, mask):
 
 
 class TrainingStep(object):
-    def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8):
+    def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8, pair_forward=True):
         self.model = model
+        # both frames of the pair through the network as one grouped batch (FCDenseNet.forward_pair): same values as the
+        # reference's two calls (train.py:276-277), half the kernel launches
+        self.pair_forward = bool(pair_forward) and hasattr(model, "forward_pair")
         self.optimizer = optimizer
         self.sfl_weight = float(sfl_weight)
         self.dcl_weight = float(dcl_weight)
@@ -61,8 +64,11 @@ class TrainingStep(object):
         b = batch["boundaries"]
         colors_1 = mask_mul(batch["colors_1"], b)
         colors_2 = mask_mul(batch["colors_2"], b)
-        pred_1 = self.model(colors_1)
-        pred_2 = self.model(colors_2)
+        if self.pair_forward:
+            pred_1, pred_2 = self.model.forward_pair(colors_1, colors_2)
+        else:
+            pred_1 = self.model(colors_1)
+            pred_2 = self.model(colors_2)
         scaled_1, std_1 = self.depth_scaling_layer([pred_1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
         scaled_2, std_2 = self.depth_scaling_layer([pred_2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
         flows_1 = self.flow_from_depth_layer([scaled_1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],

@@ -132,6 +132,14 @@ int endo_mask_mul(const float* a, const float* mask, float* out, int n, int c, i
 typedef struct endo_net endo_net;
 
 int endo_net_create(endo_net** out, int n, int h, int w);
+/* Grouped batch: `groups` independent forward / backward passes of n samples each -- the two frames of a training
+ * pair, train.py:276-277 -- run inside every kernel launch: x / out / grad_out hold groups * n samples, each
+ * group keeps its own BatchNorm batch statistics (so the result equals `groups` separate calls, running statistics
+ * updated in group order), parameter gradients sum over the groups.  tape and gradws are then groups *
+ * endo_net_group_stride() floats (what endo_net_tape_floats / endo_net_gradws_floats return).  groups <= 4. */
+int endo_net_create_grouped(endo_net** out, int n, int h, int w, int groups);
+int endo_net_groups(const endo_net* net);
+int64_t endo_net_group_stride(const endo_net* net);
 void endo_net_destroy(endo_net* net);
 int64_t endo_net_param_floats(void);                 /* 1 374 865 */
 int64_t endo_net_bn_floats(void);                    /* 2 * sum of BN widths */

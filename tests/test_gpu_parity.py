@@ -346,6 +346,63 @@ def test_network_backward(shape):
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160), (3, 64, 64)])
+def test_forward_pair_is_two_calls(shape):
+    """forward_pair(x1, x2) -- both frames of a training pair as one grouped batch, every launch covering both, each
+    frame with its own BatchNorm batch statistics -- against the oracle's two sequential calls (reference
+    train.py:276-277): outputs, running statistics after both updates (order: x1 then x2), summed parameter gradients;
+    and against the library's own two separate calls."""
+    n, h, w = shape
+    state, model = make_model(61)
+    rng = np.random.default_rng(12)
+    x1 = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    x2 = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    cot1 = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    cot2 = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    names = onet.trainable_names()
+    # private copies first: state_as(.., float32) aliases its argument and a training-mode oracle forward updates the
+    # running statistics in place
+    st32 = {k: v.clone() for k, v in state.items()}
+    st64 = state_as(state, torch.float64)
+    y32 = [onet.forward(st32, x1, training=True), onet.forward(st32, x2, training=True)]
+    y64 = [onet.forward(st64, x1.double(), training=True), onet.forward(st64, x2.double(), training=True)]
+    g32a, g32b = reference_grads(state, x1, cot1, torch.float32), reference_grads(state, x2, cot2, torch.float32)
+    g64a, g64b = reference_grads(state, x1, cot1, torch.float64), reference_grads(state, x2, cot2, torch.float64)
+    g32 = {nm: g32a[nm] + g32b[nm] for nm in names}
+    g64 = {nm: g64a[nm] + g64b[nm] for nm in names}
+
+    _, twin = make_model(61)                   # same weights: the two-call path of the library itself
+    twin.train()
+    with torch.no_grad():
+        t1, t2 = twin(x1.to(dev())), twin(x2.to(dev()))
+
+    model.train()
+    y1, y2 = model.forward_pair(x1.to(dev()), x2.to(dev()))
+    assert y1.shape == (n, 1, h, w) and y2.shape == (n, 1, h, w)
+    ((y1 * cot1.to(dev())).sum() + (y2 * cot2.to(dev())).sum()).backward()
+    noise_aware(y1, y32[0], y64[0], "pair output 1")
+    noise_aware(y2, y32[1], y64[1], "pair output 2")
+    assert_close(y1, t1, 2e-5, "pair output 1 vs separate call")
+    assert_close(y2, t2, 2e-5, "pair output 2 vs separate call")
+    sd, sd_twin = model.state_dict(), twin.state_dict()
+    for name in ("denseBlocksDown.0.layers.0.norm", "transDownBlocks.2.norm", "bottleneck.bottleneck.layers.3.norm",
+                 "denseBlocksUp.4.layers.3.norm"):
+        for stat in (".running_mean", ".running_var"):
+            noise_aware(sd[name + stat], st32[name + stat], st64[name + stat], name + stat)
+            assert_close(sd[name + stat], sd_twin[name + stat], 1e-5, name + stat + " vs separate calls")
+        assert int(sd[name + ".num_batches_tracked"]) == 2
+    params = dict(model.named_parameters())
+    for nm in names:
+        # the sum of two passes carries the mask-flip noise of both: floor and factor are twice those of test_network_backward's
+        noise_aware(params[nm].grad, g32[nm], g64[nm], "pair grad " + nm, floor=4e-4, factor=12.0, scale=grad_scale(g64, nm))
+    model.eval()
+    twin.eval()
+    with torch.no_grad():
+        e1, e2 = model.forward_pair(x1.to(dev()), x2.to(dev()))
+        assert_close(e1, model(x1.to(dev())), 1e-6, "eval pair 1")
+        assert_close(e2, model(x2.to(dev())), 1e-6, "eval pair 2")
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 64), (2, 128, 160), (4, 256, 256)])
 def test_network_backward_last_block_exact(shape):
     """The layers that are differentiated FIRST (final conv, last up block, its transition-up) see no

@@ -1,0 +1,25 @@
+"""forward_pair running-statistics diagnosis (development tool)."""
+import importlib, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+from oracle import network as onet
+dev = torch.device("cuda:0")
+state = onet.perturb_affine(onet.synthetic_state(61), 62)
+def mk():
+    m = ea.FCDenseNet57(1); m.load_state_dict(state); return m.to(dev).train()
+model, twin = mk(), mk()
+rng = np.random.default_rng(12)
+x1 = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 64, 96)).astype(np.float32)).to(dev)
+x2 = torch.from_numpy(rng.uniform(-1, 1, (2, 3, 64, 96)).astype(np.float32)).to(dev)
+with torch.no_grad():
+    twin(x1); 
+    sd1 = {k: v.clone() for k, v in twin.state_dict().items()}
+    twin(x2)
+    model.forward_pair(x1, x2)
+sd, sdt = model.state_dict(), twin.state_dict()
+for name in ("denseBlocksDown.0.layers.0.norm", "denseBlocksDown.0.layers.1.norm", "transDownBlocks.0.norm", "denseBlocksUp.4.layers.3.norm"):
+    for stat in (".running_mean", ".running_var"):
+        k = name + stat
+        print(k, "init", state[k][:3].numpy(), "after1", sd1[k][:3].cpu().numpy(), "after2", sdt[k][:3].cpu().numpy(), "pair", sd[k][:3].cpu().numpy())
