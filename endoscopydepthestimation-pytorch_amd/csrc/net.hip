@@ -427,8 +427,11 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         ENDO_LAUNCH_CHECK();
         return 0;
     }
-    // 128x160-class levels: 16x8 tiles (1280 blocks) beat 16x16 (640 blocks, under 2 waves per SIMD) by 13 % (tools/conv_bench)
-    if (tiles_big < 512 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
+    // Tile shape by block count (tools/conv_bench, Cin = 228 at 128x160): the launch wants >= ~1000 blocks.
+    //   16 samples: 32x16 (640 blocks) 257 us, 32x8 (1280) 216 us;   8 samples: 16x16 (640) 143 us, 16x8 (1280) 125 us
+    const long tiles_wide = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
+    if (tiles_big < 1024 && tiles_wide >= 1024) return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1>(p, c.stream);
+    if (tiles_big < 1024 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
     return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
 }
 
