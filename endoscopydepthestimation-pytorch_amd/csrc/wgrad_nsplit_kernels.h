@@ -101,53 +101,77 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     f32x4 xr[NG][2];          // raw x of the chunk in flight
     unsigned xr_ok = 0;       // bit q: this lane's float4 q is inside the image
 
-    auto issue = [&](int chunk, int buf) {
-        const int n = chunk / (segs * p.h);
-        const int rem = chunk - n * segs * p.h;
-        const int y = rem / segs;
-        const int x0 = (rem - y * segs) * kNsSeg;
-        const WgSample sm(p, n);
+    // Everything about a chunk's loads that does not depend on the chunk is computed once: this thread's two units of
+    // the dY window (map, window row, column) and this lane's channel rows.  The chunk position (sample, row, segment)
+    // advances incrementally -- no divisions, no per-load branches in the loop (out-of-image units read a zero pad).
+    int d_off[2], d_row[2], d_col[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int e = k * kConvThreads + tid;
+        const int map = e / (kNsMap / 4);
+        const int r = e - map * (kNsMap / 4);
+        d_row[k] = r / (kNsCols / 4);
+        d_col[k] = 4 * (r - d_row[k] * (kNsCols / 4));
+        d_off[k] = map * p.dy_cs + d_row[k] * p.dy_w + d_col[k];
+    }
+    int64_t x_off[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) x_off[g] = static_cast<int64_t>(16 * (group0 + g) + li) * p.in_cs + 4 * lk;
+
+    // position of the next chunk to issue
+    int i_n = c_begin / (segs * p.h);
+    int i_y = (c_begin - i_n * segs * p.h) / segs;
+    int i_seg = c_begin - (i_n * p.h + i_y) * segs;
+    // sample group of the chunk being computed (for the BN constants); follows the same walk one chunk behind
+    int c_n = i_n, c_y = i_y, c_seg = i_seg;
+
+    auto issue = [&](int buf) {
+        const int x0 = i_seg * kNsSeg;
+        const WgSample sm(p, i_n);
         float* s_dy = smem + buf * kNsBuf;
-        const float* dy_n = p.dy + sm.dy_off(p);
+        const float* dy_base = p.dy + sm.dy_off(p) + static_cast<int64_t>(i_y - 1) * p.dy_w + x0 - 4;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int e0 = k * kConvThreads + wave * 64;
             if (e0 < kNsUnits) {
-                const int e = e0 + lane;
-                const int map = e / (kNsMap / 4);
-                const int r = e - map * (kNsMap / 4);
-                const int row = r / (kNsCols / 4), c4 = r - row * (kNsCols / 4);
-                const int gy = y - 1 + row, gx = x0 - 4 + 4 * c4;
-                const bool ok = e < kNsUnits && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-                const float* src = ok ? dy_n + static_cast<int64_t>(map) * p.dy_cs + gy * p.dy_w + gx : pad_zero;
-                if (!(EXP & 2) && e < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
+                const bool ok = static_cast<unsigned>(i_y - 1 + d_row[k]) < static_cast<unsigned>(p.h) &&
+                                static_cast<unsigned>(x0 - 4 + d_col[k]) < static_cast<unsigned>(p.w);
+                const float* src = ok ? dy_base + d_off[k] : pad_zero;
+                if (!(EXP & 2) && e0 + lane < kNsUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + 4 * e0), 16, 0, 0);
             }
         }
-        const float* in_n = p.in + sm.in_off(p) + static_cast<int64_t>(y) * p.in_w + x0 + 4 * lk;
+        const float* in_base = p.in + sm.in_off(p) + static_cast<int64_t>(i_y) * p.in_w + x0;
         xr_ok = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
             if (x0 + 16 * q + 4 * lk < p.w) xr_ok |= 1u << q;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const float* row = in_n + static_cast<int64_t>(16 * (group0 + g) + li) * p.in_cs;
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                xr[g][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (!(EXP & 1) && ch_ok[g] && (xr_ok & (1u << q))) xr[g][q] = *reinterpret_cast<const f32x4*>(row + 16 * q);
+                const bool ok = !(EXP & 1) && ch_ok[g] && (xr_ok & (1u << q));
+                const float* src = ok ? in_base + x_off[g] + 16 * q : pad_zero;          // pad: 4 zeros, masked again after BN
+                xr[g][q] = *reinterpret_cast<const f32x4*>(src);
             }
+        if (++i_seg == segs) {
+            i_seg = 0;
+            if (++i_y == p.h) { i_y = 0; ++i_n; }
         }
     };
 
-    if (c_begin < c_end) issue(c_begin, 0);
+    if (c_begin < c_end) issue(0);
     int buf = 0;
     for (int chunk = c_begin; chunk < c_end; ++chunk, buf ^= 1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!(EXP & 4)) __syncthreads();
         // BN + ReLU of this chunk's activations (registers), then start the next chunk's loads
         {
-            const int sg = WgSample(p, chunk / (segs * p.h)).grp;
+            const int sg = WgSample(p, c_n).grp;
             if (sg != cst_grp) load_consts(sg);
+            if (++c_seg == segs) {
+                c_seg = 0;
+                if (++c_y == p.h) { c_y = 0; ++c_n; }
+            }
         }
         f32x4 bv[NG][2];
 #pragma unroll
@@ -158,7 +182,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
 #pragma unroll
                 for (int e = 0; e < 4; ++e) bv[g][q][e] = ok ? __builtin_fmaxf(fmaf(xr[g][q][e] - mn[g], sc[g], bt[g]), 0.f) : 0.f;
             }
-        if (chunk + 1 < c_end) issue(chunk + 1, buf ^ 1);
+        if (chunk + 1 < c_end) issue(buf ^ 1);
 
         const float* s_dy = smem + buf * kNsBuf;
 #pragma unroll
