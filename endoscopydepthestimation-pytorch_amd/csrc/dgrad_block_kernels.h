@@ -387,6 +387,239 @@ inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// 8-wave variant: the dY tile (52 KB for 4 layers) is what limits a CU to two blocks; here a block is 512 threads and
+// its two halves (4 waves each, the same 32 x 6 pixel tile) work on DIFFERENT 16-channel groups of every step, each
+// half with its own double-buffered weight slice.  Same LDS per CU, twice the waves per SIMD to hide each other's
+// LDS waits, epilogues and barriers -- MFMA utilisation follows waves per SIMD on this part.
+// Needs <= 128 registers per lane for the four waves per SIMD: no deferred stores, no register double-buffering.
+// ---------------------------------------------------------------------------------------------
+template <int NL>
+struct DgradBlock8Geom {
+    static constexpr int WX = 2, R = 3;
+    static constexpr int kThreads = 512;
+    static constexpr int kTileX = 32, kTileY = 6;
+    static constexpr int kRows = kTileY + 2, kCols = kTileX + 2;
+    static constexpr int kPlane = kRows * kCols;                       // 272
+    static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;    // 272
+    static constexpr int kWG = 9 * 12 * 16;
+    static constexpr int kWPre = (kWG + 255) / 256;                    // per thread of a half
+    static constexpr int kRed = 4 * 16 * 2;                            // per (buffer, half): [4 waves][16][2]
+    static constexpr size_t kBytes = sizeof(float) * (NL * 12 * kCS + 2 * 2 * kWG + 2 * 2 * kRed);
+    static_assert(kBytes <= 80 * 1024, "two blocks per CU");
+};
+
+template <int NL>
+__global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockParams p0) {
+    using G = DgradBlock8Geom<NL>;
+    constexpr int R = G::R;
+    const int grp = p0.group_n > 0 ? blockIdx.z / p0.group_n : 0;
+    const int n = blockIdx.z - grp * p0.group_n;
+    const DgradBlockParams& p = p0;
+    const int64_t grp_off = grp * p0.gs;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_g = smem;                               // [NL*12][kCS]
+    float* s_w = s_g + NL * 12 * G::kCS;             // [half][2][9][12][16]
+    float* s_red = s_w + 4 * G::kWG;                 // [2][half][4 waves][16][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, w4 = wave & 3;
+    const int th = tid & 255;                        // thread inside its half
+    const int li = lane & 15;
+    const int lk = lane >> 4;
+    const int tile = (gridDim.x & 7) == 0 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    const int x0 = (tile % p.tiles_x) * G::kTileX;
+    const int y0 = (tile / p.tiles_x) * G::kTileY;
+    const int wx = (w4 & 1) * 16;
+    const int wy = (w4 >> 1) * R;
+    const int px = x0 + wx + 4 * lk;
+    // blockIdx.y: slice of the channel groups; inside the slice the two halves take alternate groups
+    const int ngroups = (p.count + 15) / 16;
+    const int g_per = (ngroups + gridDim.y - 1) / gridDim.y;
+    const int g_begin = blockIdx.y * g_per;
+    const int g_end = min(ngroups, g_begin + g_per);
+    if (g_begin >= g_end) return;
+    const int npairs = (g_end - g_begin + 1) / 2;
+    const int nsteps = npairs * NL;
+
+    // ---- G tiles: NL*12 maps with a 1-pixel halo, dword DMA by all 8 waves (once per block) ----
+    {
+        int goff = 0;
+        bool ok = false;
+        if (tid < G::kPlane) {
+            const int ry = tid / G::kCols, rx = tid - ry * G::kCols;
+            const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) { ok = true; goff = gy * p.g_w + gx; }
+        }
+        const float* g_n = p.g + grp_off + n * p.g_ns;
+        const int e0 = wave * 64;
+        if (e0 < G::kPlane) {
+            for (int c = 0; c < NL * 12; ++c) {
+                const float* src = ok ? g_n + static_cast<int64_t>(c) * p.g_cs + goff : g_pad_consts + 4;
+                if (e0 + lane < G::kPlane) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_g + c * G::kCS + e0), 4, 0, 0);
+            }
+        }
+    }
+
+    // ---- this half's weight slice of a step: element (tap, c, j) <- W_l[c][w_ci_off + 16 group + j][8 - tap] ----
+    int wc[G::kWPre], wrest[G::kWPre];
+#pragma unroll
+    for (int k = 0; k < G::kWPre; ++k) {
+        const int e = th + k * 256;
+        const int j = e % 16;
+        const int rest = e / 16;
+        const int c = rest % 12;
+        const int tap = rest / 12;
+        wc[k] = c * 9;
+        wrest[k] = j * 9 + (8 - tap);
+    }
+    auto step_group = [&](int step) { return g_begin + 2 * (step / NL) + half; };
+    auto issue_weights = [&](int step, int buf) {
+        const int gq = step_group(step), l = step % NL;
+        if (gq >= g_end) return;                                     // half-uniform
+        const float* wl = p.wgt[l] + static_cast<int64_t>(p.w_ci_off + gq * 16) * 9;
+        const int wcin = p.w_cin[l];
+        float* dst = s_w + (half * 2 + buf) * G::kWG;
+#pragma unroll
+        for (int k = 0; k < G::kWPre; ++k) {
+            const int e0 = k * 256 + w4 * 64;
+            if (e0 < G::kWG) {
+                const bool ok = gq * 16 + ((e0 + lane) & 15) < p.count;
+                const float* src = ok ? wl + wc[k] * wcin + wrest[k] : g_pad_consts + 4;
+                if (e0 + lane < G::kWG) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + e0), 4, 0, 0);
+            }
+        }
+    };
+
+    const float* x_n = p.x + grp_off + n * p.ns;
+    float* out_n = p.out + grp_off + n * p.ns;
+    f32x4 xc[R], dc[R], total[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) total[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    issue_weights(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const int gq = step_group(step), l = step % NL;
+        const bool active = gq < g_end;                              // half-uniform
+        const bool last_layer = (l == NL - 1);
+        const int co = gq * 16 + li;
+        float scale = 0.f, beta = 0.f, mean = 0.f, rstd = 0.f;
+        if (active) {
+            if (l == 0) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int y = y0 + wy + r;
+                    xc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (co < p.count && y < p.h && px + 3 < p.w) {
+                        xc[r] = *reinterpret_cast<const f32x4*>(x_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+                        if (co >= p.acc_from) dc[r] = *reinterpret_cast<const f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+                    }
+                }
+            }
+            if (co < p.count) {
+                mean = p.saved[l][grp_off + 2 * co]; rstd = p.saved[l][grp_off + 2 * co + 1];
+                scale = p.gamma[l][co] * rstd;
+                beta = p.beta[l][co];
+            }
+        }
+        if (step + 1 < nsteps) issue_weights(step + 1, buf ^ 1);
+        if (active) {
+            // ---- convT_l(G_l) for this half's 16 channels: K = 3 map quads x 9 taps ----
+            f32x4 acc[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* wb = s_w + (half * 2 + buf) * G::kWG;
+#pragma unroll
+            for (int quad = 0; quad < 3; ++quad) {
+                const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
+                const float* b_base = wb + (quad * 4 + lk) * 16 + li;
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    float av[R + 2];
+#pragma unroll
+                    for (int r = 0; r < R + 2; ++r) av[r] = a_base[r * G::kCols + dx];
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const float b = b_base[(dy * 3 + dx) * 12 * 16];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r + dy], b, acc[r], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- layer l's ReLU mask + BN backward, accumulated over the layers of the block ----
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                if (co < p.count && y < p.h && px + 3 < p.w) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xcen = xc[r][e] - mean;
+                        const float z = fmaf(xcen, scale, beta);
+                        const float dz = z > 0.f ? acc[r][e] : 0.f;
+                        s1 += dz;
+                        s2 += dz * (xcen * rstd);
+                        total[r][e] += scale * dz;
+                    }
+                    if (last_layer) {
+                        f32x4 o = dc[r];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] += total[r][e];
+                        *reinterpret_cast<f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px) = o;
+                    }
+                }
+                if (last_layer) total[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                float* red = s_red + (buf * 2 + half) * G::kRed;
+                red[(w4 * 16 + li) * 2] = s1;
+                red[(w4 * 16 + li) * 2 + 1] = s2;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (active && th < 32) {
+            const int j = th >> 1, which = th & 1;
+            const int cj = gq * 16 + j;
+            if (cj < p.count) {
+                const float* red = s_red + (buf * 2 + half) * G::kRed;
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
+                atomicAdd(p.scratch[l] + grp_off / 2 + 2 * cj + which, t);
+            }
+        }
+    }
+}
+
+template <int NL>
+inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
+    using G = DgradBlock8Geom<NL>;
+    p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
+    const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
+    static bool configured = false;
+    if (!configured) {
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block8_kernel<NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(G::kBytes)));
+        configured = true;
+    }
+    const int tiles = p.tiles_x * tiles_y * p.n;
+    const int pairs = ((p.count + 15) / 16 + 1) / 2;
+    int ysplit = (512 + tiles - 1) / tiles;
+    if (ysplit > pairs) ysplit = pairs;
+    if (ysplit < 1) ysplit = 1;
+    dgrad_block8_kernel<NL><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), G::kThreads, G::kBytes, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
 // float4 epilogue: W % 4 == 0 and 16-byte aligned planes
 inline bool dgrad_block_ok(const DgradBlockParams& p) {
     return (p.w % 4 == 0) && (p.cs % 4 == 0) && (p.ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.x) % 16 == 0) &&

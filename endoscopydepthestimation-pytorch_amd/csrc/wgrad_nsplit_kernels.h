@@ -20,6 +20,8 @@
 // i.e. each lane's 8 pixels are two aligned float4s.
 #pragma once
 
+#include <type_traits>
+
 #include "conv_dma_kernels.h"
 #include "wgrad_kernels.h"
 
@@ -36,7 +38,7 @@ constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
 template <int NG, int EXP = 0>
 __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradParams p, float* __restrict__ partial,
                                                                     int chunks_per_block) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * kNsBuf];
+    __shared__ __attribute__((aligned(16))) float smem[3 * kNsBuf];      // dY windows of the chunk computed and the two in flight
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,6 +91,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     for (int i = tid; i < 64; i += kConvThreads) {
         smem[12 * kNsMap + i] = 0.f;
         smem[kNsBuf + 12 * kNsMap + i] = 0.f;
+        smem[2 * kNsBuf + 12 * kNsMap + i] = 0.f;
     }
 
     f32x4 acc[NG][kNsMG];
@@ -98,8 +101,10 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         for (int m = 0; m < kNsMG; ++m) acc[g][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const float* pad_zero = g_pad_consts + 4;
-    f32x4 xr[NG][2];          // raw x of the chunk in flight
-    unsigned xr_ok = 0;       // bit q: this lane's float4 q is inside the image
+    // Loads run TWO chunks ahead of the MFMAs (one chunk of MFMAs, ~2.4 us, does not always cover an HBM round trip
+    // under load): raw x of chunks c+1 and c+2 sit in xr[(c+1)&1], xr[c&1]; their dY windows in two of the three buffers.
+    f32x4 xr[2][NG][2];
+    unsigned xr_ok[2] = {0, 0};       // bit q: this lane's float4 q is inside the image
 
     // Everything about a chunk's loads that does not depend on the chunk is computed once: this thread's two units of
     // the dY window (map, window row, column) and this lane's channel rows.  The chunk position (sample, row, segment)
@@ -125,7 +130,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
     // sample group of the chunk being computed (for the BN constants); follows the same walk one chunk behind
     int c_n = i_n, c_y = i_y, c_seg = i_seg;
 
-    auto issue = [&](int buf) {
+    auto issue = [&](int buf, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
         const int x0 = i_seg * kNsSeg;
         const WgSample sm(p, i_n);
         float* s_dy = smem + buf * kNsBuf;
@@ -141,17 +147,18 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
             }
         }
         const float* in_base = p.in + sm.in_off(p) + static_cast<int64_t>(i_y) * p.in_w + x0;
-        xr_ok = 0;
+        unsigned okbits = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (x0 + 16 * q + 4 * lk < p.w) xr_ok |= 1u << q;
+            if (x0 + 16 * q + 4 * lk < p.w) okbits |= 1u << q;
+        xr_ok[slot] = okbits;
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const bool ok = !(EXP & 1) && ch_ok[g] && (xr_ok & (1u << q));
+                const bool ok = !(EXP & 1) && ch_ok[g] && (okbits & (1u << q));
                 const float* src = ok ? in_base + x_off[g] + 16 * q : pad_zero;          // pad: 4 zeros, masked again after BN
-                xr[g][q] = *reinterpret_cast<const f32x4*>(src);
+                xr[slot][g][q] = *reinterpret_cast<const f32x4*>(src);
             }
         if (++i_seg == segs) {
             i_seg = 0;
@@ -159,12 +166,24 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         }
     };
 
-    if (c_begin < c_end) issue(0);
+    // every issue() is NG * 2 global loads plus this wave's share of the window DMA: waves 0 and 1 move two units each
+    // (360 float4 over 256 threads), waves 2 and 3 one -- the count the vmcnt below leaves in flight
+    using Slot0 = std::integral_constant<int, 0>;
+    using Slot1 = std::integral_constant<int, 1>;
+    if (c_begin < c_end) issue(0, Slot0{});
+    if (c_begin + 1 < c_end) issue(1, Slot1{});
     int buf = 0;
-    for (int chunk = c_begin; chunk < c_end; ++chunk, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // one chunk; the register slot of its x values is a compile-time constant (the loop below alternates)
+    auto do_chunk = [&](int chunk, auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+        if (chunk + 1 < c_end) {          // chunk + 1's loads may stay in flight
+            if ((EXP & 2) || wave >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * 2 + ((EXP & 2) ? 0 : 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NG * 2 + 2) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         if (!(EXP & 4)) __syncthreads();
-        // BN + ReLU of this chunk's activations (registers), then start the next chunk's loads
+        // BN + ReLU of this chunk's activations (registers), then start the loads of chunk + 2 into the slot just freed
         {
             const int sg = WgSample(p, c_n).grp;
             if (sg != cst_grp) load_consts(sg);
@@ -178,11 +197,11 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         for (int g = 0; g < NG; ++g)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const bool ok = ch_ok[g] && (xr_ok & (1u << q));
+                const bool ok = ch_ok[g] && (xr_ok[slot] & (1u << q));
 #pragma unroll
-                for (int e = 0; e < 4; ++e) bv[g][q][e] = ok ? __builtin_fmaxf(fmaf(xr[g][q][e] - mn[g], sc[g], bt[g]), 0.f) : 0.f;
+                for (int e = 0; e < 4; ++e) bv[g][q][e] = ok ? __builtin_fmaxf(fmaf(xr[slot][g][q][e] - mn[g], sc[g], bt[g]), 0.f) : 0.f;
             }
-        if (chunk + 1 < c_end) issue(buf ^ 1);
+        if (chunk + 2 < c_end) issue(buf == 0 ? 2 : buf - 1, slot_c);          // the buffer computed last iteration
 
         const float* s_dy = smem + buf * kNsBuf;
 #pragma unroll
@@ -200,6 +219,11 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
                             acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[g][q][e], acc[g][m], 0, 0, 0);
                     }
             }
+        buf = buf == 2 ? 0 : buf + 1;
+    };
+    for (int chunk = c_begin; chunk < c_end; chunk += 2) {
+        do_chunk(chunk, Slot0{});
+        if (chunk + 1 < c_end) do_chunk(chunk + 1, Slot1{});
     }
 
     // partial[((block * groups_total + group) * 7 + m) * 4 + r][lane] = D[row 16 m + 4 lk + r][ci = 16 group + li]

@@ -122,6 +122,7 @@ int main(int argc, char** argv) {
         const double bflops = 2.0 * n * plane * c0 * 12 * 9 * 4;
         std::vector<Variant> vs;
         vs.push_back({"dgrad_block<4> GP1 pipelined (library)", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 0, 1>(p, s); }});
+        vs.push_back({"dgrad_block8<4> (512 threads, 2 halves)", [&](hipStream_t s) { return launch_dgrad_block8<4>(p, s); }});
         vs.push_back({"dgrad_block<4> GP1 unpipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 1, 0, 0>(p, s); }});
         vs.push_back({"dgrad_block<4> GP2 pipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 2, 0, 1>(p, s); }});
         vs.push_back({"dgrad_block<4> GP2 unpipelined", [&](hipStream_t s) { return launch_dgrad_block<4, 2, 3, 2, 0, 0>(p, s); }});
