@@ -10,8 +10,8 @@
 //     not once per tap, and its tile needs no halo; the dY tile (12 maps + halo) is gathered with a
 //     per-lane (co, tap) offset table
 //   * both tiles arrive by 16-byte LDS-DMA into a double buffer, one barrier per tile
-// A block owns a 16-channel input slice and a strided set of 32 x 8 pixel tiles; the 4 waves split
-// the tile's rows, are reduced through LDS at the end, and issue one fp32 atomic per dW element.
+// A block owns a 16-channel input slice and a strided set of 32 x 8 pixel tiles; its 8 waves take one tile row
+// each, are reduced through LDS at the end, and issue one fp32 atomic per dW element.
 #pragma once
 
 #include "conv_dma_kernels.h"
@@ -34,14 +34,15 @@ struct WgradTapsGeom {
     static constexpr int kBuf = 16 * kCS + COUT * kDS + kZero;   // floats per buffer
     static constexpr int kInUnits = kInPlane / 4;             // 64 float4 per channel
     static constexpr int kDyUnits = kDyPlane / 4;             // 100 float4 per map
-    static constexpr size_t kRed = 4 * kMG * 256;             // cross-wave reduction scratch (floats)
+    static constexpr int kWaves = 8;                          // 512-thread blocks: LDS allows two per CU, so 4 waves per SIMD
+    static constexpr size_t kRed = kWaves * kMG * 256;        // cross-wave reduction scratch (floats)
     static constexpr size_t kFloats = (2 * kBuf > static_cast<int>(kRed) ? 2 * kBuf : kRed) + 64 * kMaxGroups;
     static constexpr size_t kBytes = sizeof(float) * kFloats;
     static_assert(kBytes <= 160 * 1024, "two tile buffers must fit the 160 KiB LDS");
 };
 
 template <int COUT, int IN>
-__global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(512, 4) wgrad_taps_kernel(const WgradParams p) {
     using G = WgradTapsGeom<COUT>;
     static_assert(IN == IN_BNRELU || IN == IN_PLAIN || IN == IN_UPSAMPLE, "supported activation load paths");
     constexpr int MG = G::kMG;
@@ -112,8 +113,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         if constexpr (IN == IN_UPSAMPLE) {
             // nearest x2 gather: one dword per output pixel, 4 issues per channel; wave w moves channels w, w+4, ...
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = wave + 4 * k;
+            for (int k = 0; k < 16 / G::kWaves; ++k) {
+                const int c = wave + G::kWaves * k;
                 const int ch = ci_base + c;
                 const float* plane = in_s + static_cast<int64_t>(ch) * p.in_cs;
 #pragma unroll
@@ -133,8 +134,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
             const bool ok = gy < p.h && gx < p.w;
             const float* base = in_s + gy * p.in_w + gx;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int c = wave + 4 * k;
+            for (int k = 0; k < 16 / G::kWaves; ++k) {
+                const int c = wave + G::kWaves * k;
                 const int ch = ci_base + c;
                 const float* src = (ok && ch < p.cin) ? base + static_cast<int64_t>(ch) * p.in_cs : pad_in;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + c * G::kCS), 16, 0, 0);
@@ -142,8 +143,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
         }
         // dY: COUT maps x 100 float4 (1-row / 4-column halo); wave w moves maps w, w+4, ... (two issues per map)
 #pragma unroll
-        for (int k = 0; k < (COUT + 3) / 4; ++k) {
-            const int co = wave + 4 * k;
+        for (int k = 0; k < (COUT + G::kWaves - 1) / G::kWaves; ++k) {
+            const int co = wave + G::kWaves * k;
             if (co < COUT && co_base + co < p.cout) {
                 const float* map = dy_s + static_cast<int64_t>(co_base + co) * p.dy_cs;
 #pragma unroll
@@ -162,12 +163,12 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
     };
 
     // the zero rows of both buffers (never touched by the DMA)
-    for (int i = tid; i < G::kZero; i += kConvThreads) {
+    for (int i = tid; i < G::kZero; i += 64 * G::kWaves) {
         smem[16 * G::kCS + COUT * G::kDS + i] = 0.f;
         smem[G::kBuf + 16 * G::kCS + COUT * G::kDS + i] = 0.f;
     }
 
-    const int rows_per_wave = G::kTY / 4;      // 2
+    const int rows_per_wave = G::kTY / G::kWaves;      // 1
 
     int tile = group;
     if (tile < tiles_total) issue_dma(tile, 0);
@@ -209,11 +210,13 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_taps_kernel(const WgradPar
 #pragma unroll
         for (int e = 0; e < 4; ++e) s_red[((wave * MG + g) * 4 + e) * 64 + lane] = acc[g][e];
     __syncthreads();
-    for (int idx = tid; idx < MG * 256; idx += kConvThreads) {
+    for (int idx = tid; idx < MG * 256; idx += 64 * G::kWaves) {
         const int ln = idx & 63;
         const int e = (idx >> 6) & 3;
         const int g = idx >> 8;
-        const float v = s_red[idx] + s_red[MG * 256 + idx] + s_red[2 * MG * 256 + idx] + s_red[3 * MG * 256 + idx];
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < G::kWaves; ++wv) v += s_red[wv * MG * 256 + idx];
         const int m = 16 * g + 4 * (ln >> 4) + e;
         const int ci = ci_base + (ln & 15);
         if (m < G::kM && ci < p.cin) {
@@ -242,7 +245,7 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
-    wgrad_taps_kernel<COUT, IN><<<dim3(ci_chunks, groups, co_sets), kConvThreads, G::kBytes, stream>>>(p);
+    wgrad_taps_kernel<COUT, IN><<<dim3(ci_chunks, groups, co_sets), 64 * G::kWaves, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
