@@ -11,8 +11,10 @@ loss.item(), backward, one gradient all-reduce (N > 1), fused clip_grad_norm_(10
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra objects on that line:
-  roofline      the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad, whichever took
-                the most time), algorithmic FLOPs / HIP-event time measured live over the timed steps
+  roofline      the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad: whichever took the most
+                time in the warm-up steps, where all three carry HIP events), algorithmic FLOPs / HIP-event time
+                of its launches measured live over the timed steps, on the launch stream; traffic = HBM bytes per
+                launch from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.py)
   cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host's cores on
                 a bounded sample (batch-1 steps)
 """
@@ -123,15 +125,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Warm-up steps time all three dense-layer conv families (HIP events around every launch of the family, on the
+    # launch stream) to find the dominant one; the timed steps then keep events only on THAT family -- two events per
+    # launch serialise neighbouring kernels, and 132 launches of the other two families need not pay for it.
+    all_mask = 0
+    for f in MFMA_FAMILIES:
+        all_mask |= 1 << f
     it = 0
+    lib.endo_prof_enable(all_mask if args.warmup > 0 else 0)
     for _ in range(args.warmup):
         scheduler.batch_step(batch_iteration=it)
         step_fn(batch)
         it += 1
-    mask = 0
-    for f in MFMA_FAMILIES:
-        mask |= 1 << f
     barrier()
+    fam_warm = {f: prof_read(lib, f) for f in MFMA_FAMILIES} if args.warmup > 0 else None
+    if fam_warm is not None:
+        dominant = max(MFMA_FAMILIES, key=lambda f: fam_warm[f][0])
+        mask = 1 << dominant
+    else:
+        dominant, mask = None, all_mask
     lib.endo_prof_enable(mask)
     t0 = time.perf_counter()
     skipped = 0
@@ -191,7 +203,8 @@ def main():
     if rank != 0:
         return
     pairs = BATCH * world * args.steps
-    dominant = max(MFMA_FAMILIES, key=lambda f: fam[f][0])
+    if dominant is None:
+        dominant = max(MFMA_FAMILIES, key=lambda f: fam[f][0])
     ms, cnt, fl, by = fam[dominant]
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
@@ -223,7 +236,8 @@ def main():
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by / cnt if cnt else None,
                      "launches": cnt, "avg_launch_ms": ms / cnt if cnt else None,
                      "algorithmic_gbs": by / ms / 1e6 if ms > 0 else None,
-                     "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam[f][0] / args.steps for f in MFMA_FAMILIES}},
+                     "families_ms_per_step_warmup": ({lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / args.warmup for f in MFMA_FAMILIES}
+                                                     if fam_warm is not None else None)},
     }
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline()
