@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libendo_hip.so")
+# ENDO_HIP_LIB points at another build of the same ABI (A/B runs of kernel variants inside one benchmark job)
+LIB_PATH = os.environ.get("ENDO_HIP_LIB") or os.path.join(_HERE, "lib", "libendo_hip.so")
 
 _P = ctypes.c_void_p
 _I = ctypes.c_int
