@@ -9,8 +9,7 @@
 // byte per pooled pixel); un-routing (byte extract, compare, select) and BN+ReLU happen on the fragment read.
 // GEMM view: M = 96 cout, N = 96 cin per block (3 x 3 MFMA tiles per wave), K = pixels; a block walks a strided
 // subset of the chunks with two LDS buffers (one barrier per chunk) and ends with one fp32 atomic per dW element.
-// 512 threads: the two halves of a block (4 waves each, same 96 x 96 tile, same staged chunk) take the first / second
-// half of the chunk's 16 k-steps -- LDS allows only two blocks per CU, this doubles the waves per SIMD behind them.
+// (A 512-thread variant whose halves split the k-steps of a chunk measured 1.5 % slower in the training step.)
 // LDS rows: x stride 66 (== 2 mod 32) and G stride 21 (odd): both fragment reads are bank-conflict free.
 #pragma once
 
@@ -26,7 +25,7 @@ constexpr int kP1DyStride = kP1Seg / 2 + kP1Seg / 8 + 1;
 constexpr int kP1Buf = kP1Tile * (kP1ActStride + kP1DyStride);     // floats per buffer
 constexpr size_t kP1Bytes = 2 * kP1Buf * sizeof(float);
 
-__global__ void __launch_bounds__(512, 4) wgrad1x1_dma_kernel(const WgradParams p) {
+__global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -38,8 +37,7 @@ __global__ void __launch_bounds__(512, 4) wgrad1x1_dma_kernel(const WgradParams 
     const int segs = (p.w + kP1Seg - 1) / kP1Seg;
     const int chunks_per_sample = segs * (p.h >> 1);
     const int chunks_total = chunks_per_sample * p.n;
-    const int half = wave >> 2;                   // which 8 of the chunk's 16 k-steps
-    const int wr = (wave >> 1) & 1, wc = wave & 1;      // wave's 48 x 48 quadrant of the 96 x 96 tile
+    const int wr = wave >> 1, wc = wave & 1;      // wave's 48 x 48 quadrant of the 96 x 96 tile
 
     float sc[3], mn[3], bt[3];
     int cur_grp = -1;
@@ -83,8 +81,8 @@ __global__ void __launch_bounds__(512, 4) wgrad1x1_dma_kernel(const WgradParams 
         const bool a_ok = xs + ax < p.w;
         const float* abase = p.in + sm.in_off(p) + static_cast<int64_t>(2 * y2 + arow) * p.in_w + xs + ax;
 #pragma unroll 4
-        for (int t = 0; t < kP1Tile / 8; ++t) {
-            const int r = wave * (kP1Tile / 8) + t;
+        for (int t = 0; t < kP1Tile / 4; ++t) {
+            const int r = wave * (kP1Tile / 4) + t;
             const int ch = ci_base + r;
             const void* src = (a_ok && ch < p.cin) ? static_cast<const void*>(abase + static_cast<int64_t>(ch) * p.in_cs)
                                                    : static_cast<const void*>(pad_nan);
@@ -96,8 +94,8 @@ __global__ void __launch_bounds__(512, 4) wgrad1x1_dma_kernel(const WgradParams 
         const char* dbase = dy_is_code ? reinterpret_cast<const char*>(p.dy_idx + sm.idx_off(p) + poff)
                                        : reinterpret_cast<const char*>(p.dy + sm.dy_off(p) + poff);
 #pragma unroll 4
-        for (int t = 0; t < kP1Tile / 8; ++t) {
-            const int r = wave * (kP1Tile / 8) + t;
+        for (int t = 0; t < kP1Tile / 4; ++t) {
+            const int r = wave * (kP1Tile / 4) + t;
             const int co = co_base + r;
             const char* src = (d_ok && co < p.cout) ? dbase + co * dstride : pad_zero;
             if (lane < kP1Seg / 2 + kP1Seg / 8)
@@ -118,8 +116,7 @@ __global__ void __launch_bounds__(512, 4) wgrad1x1_dma_kernel(const WgradParams 
 #pragma unroll
             for (int d = 0; d < 4; ++d) cw[i][d] = __float_as_uint(g_base[i * 16 * kP1DyStride + kP1Seg / 2 + d]);
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const int ks = 8 * half + kk;
+        for (int ks = 0; ks < 16; ++ks) {
             // k = pixel 4*ks + lk of the chunk: row ks>>3, x = 4*(ks&7) + lk; pooled column x>>1, code 2*row + (x&1)
             const int pc = 2 * (ks & 7) + (lk >> 1);
             const unsigned want = 2u * (ks >> 3) + lane_want;
@@ -182,7 +179,7 @@ inline int launch_wgrad1x1_dma(const WgradParams& p, hipStream_t stream) {
                                        static_cast<int>(kP1Bytes)));
         configured = true;
     }
-    wgrad1x1_dma_kernel<<<dim3(splits, tiles_co, tiles_ci), 512, kP1Bytes, stream>>>(p);
+    wgrad1x1_dma_kernel<<<dim3(splits, tiles_co, tiles_ci), kConvThreads, kP1Bytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
