@@ -612,7 +612,7 @@ inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
     }
     const int tiles = p.tiles_x * tiles_y * p.n;
     const int pairs = ((p.count + 15) / 16 + 1) / 2;
-    int ysplit = (512 + tiles - 1) / tiles;
+    int ysplit = (1024 + tiles - 1) / tiles;          // 4 blocks per CU at the coarse levels (in-job A/B: -1.5 % on the family vs 512)
     if (ysplit > pairs) ysplit = pairs;
     if (ysplit < 1) ysplit = 1;
     dgrad_block8_kernel<NL><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), G::kThreads, G::kBytes, stream>>>(p);

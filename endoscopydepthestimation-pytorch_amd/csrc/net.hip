@@ -452,7 +452,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.out_sums = c.sums(next) + 2 * oc0;
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
-    return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL>(p, c.stream);       // (Q = 6 with 32x8 tiles measured 10 % slower)
+    return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower)
 }
 
 // transition up: nearest x2 -> conv3x3 48->48 into channels [0,48) of the finer level (models.py:70-80)
