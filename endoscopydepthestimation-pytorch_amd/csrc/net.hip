@@ -171,8 +171,8 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const
     }
 }
 
-// the same for the four BN layers of a dense block over the channels they share (the block's input): one launch,
-// one read-modify-write of P and Q
+// the same for up to four BN layers of a dense block over channels they share: one launch, one read-modify-write of
+// P and Q
 struct BnFin4 {
     const double* scratch[4];
     const float* saved[4];
@@ -180,7 +180,7 @@ struct BnFin4 {
     float* ggamma[4];
     float* gbeta[4];
 };
-__global__ void bn_bwd_finalize4_kernel(const BnFin4 a, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
+__global__ void bn_bwd_finalize4_kernel(const BnFin4 a, int nl, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
                                         int training, int64_t gs) {
     const int64_t go = blockIdx.y * gs;          // sample group offset (floats)
     pq_p += go; pq_q += go;
@@ -188,6 +188,7 @@ __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, float* __restrict__ pq_p
         double dp = 0.0, dq = 0.0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (j >= nl) break;          // nl = layers in use (block-uniform)
             const double s1 = a.scratch[j][go / 2 + 2 * c], s2 = a.scratch[j][go / 2 + 2 * c + 1];
             atomicAdd(a.ggamma[j] + c, static_cast<float>(s2));
             atomicAdd(a.gbeta[j] + c, static_cast<float>(s1));
@@ -574,24 +575,40 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         if (rc) return rc;
         rc = dense_wgrad(c, level, ic0, new0 + kGrowth * j, bn[j], cv[j]);
         if (rc) return rc;
-        if (j > 0) {   // gradient into the new maps of layers 0..j-1 (always accumulates: a later consumer wrote them first)
+        if (j > 0) {
+            // Gradient into the 12 new maps of layer j-1 from ALL its consumers inside the block (layers j..3) in one pass:
+            // the layer-to-layer dependency only needs G_j..G_3 final, and this way every new map is read (x) and
+            // read-modify-written (gradient) once instead of once per consumer -- 180 instead of 252 plane passes per block.
+            const int nl = kLayers - j;
+            const int t0 = c0 + kGrowth * (j - 1);          // index of the target channels inside the consumers' inputs
             DgradBlockParams p{};
             fill_common(p);
             p.g = c.gbuf(level) + (new0 + kGrowth * j) * lv.plane;
-            p.x = c.act(level) + new0 * lv.plane;
-            p.out = c.gbuf(level) + new0 * lv.plane;
-            p.count = kGrowth * j;
-            p.acc_from = 0;
-            p.w_ci_off = c0;
-            p.wgt[0] = c.params + cv[j].w; p.w_cin[0] = cv[j].cin;
-            p.saved[0] = c.saved(bn[j]) + 2 * c0; p.gamma[0] = c.params + bn[j].g + c0; p.beta[0] = c.params + bn[j].b + c0;
-            p.scratch[0] = c.scratch(bn[j]) + 2 * c0;
-            ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * p.count * kGrowth * 9,
-                           4.0 * c.nt() * lv.plane * (3.0 * p.count + kGrowth));
-            rc = launch_dgrad_block<1, 2, 3>(p, c.stream);
-            if (rc) return rc;
-            rc = bn_finalize(c, bn[j], level, ic0, c0, kGrowth * j);
-            if (rc) return rc;
+            p.x = c.act(level) + (ic0 + t0) * lv.plane;
+            p.out = c.gbuf(level) + (ic0 + t0) * lv.plane;
+            p.count = kGrowth;
+            p.acc_from = 0;          // a later consumer (next block / transition) wrote these maps first
+            p.w_ci_off = t0;
+            BnFin4 a{};
+            for (int l = 0; l < nl; ++l) {
+                const BnP& b = bn[j + l];
+                p.wgt[l] = c.params + cv[j + l].w; p.w_cin[l] = cv[j + l].cin;
+                p.saved[l] = c.saved(b) + 2 * t0; p.gamma[l] = c.params + b.g + t0; p.beta[l] = c.params + b.b + t0;
+                p.scratch[l] = c.scratch(b) + 2 * t0;
+                a.scratch[l] = p.scratch[l]; a.saved[l] = p.saved[l]; a.gamma[l] = p.gamma[l];
+                a.ggamma[l] = c.grads + b.g + t0; a.gbeta[l] = c.grads + b.b + t0;
+            }
+            {
+                ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * kGrowth * kGrowth * 9 * nl,
+                               4.0 * c.nt() * lv.plane * (3.0 * kGrowth + kGrowth * nl));
+                rc = nl == 1 ? launch_dgrad_block<1, 2, 3>(p, c.stream)
+                   : nl == 2 ? launch_dgrad_block<2, 2, 3>(p, c.stream) : launch_dgrad_block<3, 2, 3>(p, c.stream);
+                if (rc) return rc;
+            }
+            ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
+            bn_bwd_finalize4_kernel<<<dim3(1, c.net->groups), 128, 0, c.stream>>>(a, nl, c.pq_p(level) + ic0 + t0, c.pq_q(level) + ic0 + t0, kGrowth,
+                                                                             static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
+            ENDO_LAUNCH_CHECK();
         }
     }
     {   // base channels, all four layers in one pass
@@ -620,7 +637,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             a.ggamma[j] = c.grads + bn[j].g; a.gbeta[j] = c.grads + bn[j].b;
         }
         ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
-        bn_bwd_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(a, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
+        bn_bwd_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(a, kLayers, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
                                                                          static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
         ENDO_LAUNCH_CHECK();
     }
