@@ -48,10 +48,11 @@ struct ConvDmaSmem {
 // XF: where BN+ReLU is applied.  0 = on every A-fragment read (3 VALU per read, each LDS value is
 // read by 3 taps); 1 = once, in place in LDS, by the thread whose DMA wrote the value, right after
 // its own vmcnt(0) and before the barrier that publishes the chunk (no extra synchronisation).
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF>
+// EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = only the first chunk is DMA'd, 2 = no BN+ReLU on the fragment read, 4 = DMA never waited for (racy: timing only)
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0>
 __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p0) {
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
-    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");
+    static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");      // (three buffers, DMA two chunks ahead: 7 % slower in the in-job A/B)
     static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL), "16-byte DMA needs contiguous sources");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
     using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC, IN>;
@@ -338,7 +339,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
                 float a[R + KS - 1];
-                if constexpr (IN == IN_BNRELU && !kInPlace) {
+                if constexpr (IN == IN_BNRELU && !kInPlace && !(EXP & 2)) {
                     // BN + ReLU two rows at a time: v_pk_add_f32 / v_pk_fma_f32 do the subtract and the fma of both values
                     // in one instruction each (same roundings as the scalar fmaf), so 4 VALU per pair instead of 6
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -392,9 +393,9 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             const int b = (chunk - chunk_begin) % NBUF;
             // own DMA of this chunk has landed; after the barrier everybody's has, and everybody has
             // finished reading the other buffer (chunk - 1), so it can be refilled
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!(EXP & 4) || chunk == chunk_begin) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (NBUF == 2 && chunk + 1 < nchunks) issue_dma(chunk + 1, b ^ 1);
+            if (NBUF == 2 && chunk + 1 < nchunks && !(EXP & 1)) issue_dma(chunk + 1, b ^ 1);
             compute(chunk, b);
             if (NBUF == 1 && chunk + 1 < nchunks) {      // single buffer: refill only once everybody is done reading
                 __syncthreads();
@@ -453,7 +454,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     conv_epilogue<Q, EPI, R>(po, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
 }
 
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0>
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0, int EXP = 0>
 inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     static_assert(XF == 0 || NBUF == 2 || IN != IN_BNRELU, "the in-place transform pipeline is written for two buffers");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
@@ -465,11 +466,11 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     const size_t smem = S::bytes(p.bn_cap);
     static size_t configured = 0;
     if (smem > 48 * 1024 && smem > configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF>),
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         configured = smem;
     }
-    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF><<<grid, kConvThreads, smem, stream>>>(p);
+    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP><<<grid, kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

@@ -98,6 +98,10 @@ int main(int argc, char** argv) {
     {
         std::vector<Variant> vs;
         vs.push_back({"fwd dma4 KC4 2buf 32x16 (library)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd 32x16 only first chunk DMA'd (EXP 1)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0, 1>(f, s); }});
+        vs.push_back({"fwd 32x16 no BN transform (EXP 2)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0, 2>(f, s); }});
+        vs.push_back({"fwd 32x16 DMA issued but not waited (EXP 4)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0, 4>(f, s); }});
+        vs.push_back({"fwd 32x16 neither (EXP 3)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 8, 2, 1, 4, 0, 3>(f, s); }});
         vs.push_back({"fwd dma4 KC4 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC8 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC4 2buf 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 4, 0>(f, s); }});
