@@ -118,3 +118,115 @@ extern "C" int endo_sparse_scatter(const double* points, int n_points, const dou
     ENDO_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Coloured point cloud of a depth map (reference utils.py:823-852 point_cloud_from_depth, called per frame by
+// evaluate.py:272,340): every `downsampling`-th pixel inside the mask becomes (x, y, z, r, g, b), row-major order.
+// Deterministic compaction: one block per image row counts its hits, a one-thread kernel scans the row counts, then one
+// block per row writes its points at the row's offset, ordered inside the row by a wave-ballot prefix.  fp32 with the reference's operation order ((w - cx) / fx * z: three
+// roundings; the compiler must not contract it into an fma).
+// ---------------------------------------------------------------------------------------------
+namespace endo {
+
+struct CloudParams {
+    const float* depth;        // [H][W]
+    const uint8_t* color;      // [H][W][3], B G R as cv2 images are
+    const float* mask;         // [H][W]
+    const float* k;            // [3][3] intrinsics
+    int height, width, downsampling, use_threshold;
+    float min_threshold, max_threshold;
+    int* row_offsets;          // [H + 1]
+    float* points;             // [capacity][6]
+    int* count;
+};
+
+__device__ __forceinline__ bool cloud_keep(const CloudParams& q, int h, int w) {
+    if (h % q.downsampling != 0 || w % q.downsampling != 0) return false;
+    const int64_t i = static_cast<int64_t>(h) * q.width + w;
+    if (!(q.mask[i] > 0.5f)) return false;
+    if (q.use_threshold) {
+        const int b = q.color[3 * i], g = q.color[3 * i + 1], r = q.color[3 * i + 2];
+        const int mx = max(r, max(g, b)), mn = min(r, min(g, b));
+        if (!(static_cast<float>(mx) >= q.max_threshold && static_cast<float>(mn) <= q.min_threshold)) return false;
+    }
+    return true;
+}
+
+__global__ void __launch_bounds__(256) cloud_count_kernel(const CloudParams q) {
+    __shared__ int s_cnt[4];
+    const int h = blockIdx.x;
+    int cnt = 0;
+    for (int w = threadIdx.x; w < q.width; w += 256) cnt += cloud_keep(q, h, w) ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) q.row_offsets[h + 1] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// in place: row_offsets[h + 1] holds row h's count on entry, the inclusive prefix on exit; row_offsets[0] = 0
+__global__ void cloud_scan_kernel(int* row_offsets, int height, int* count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int acc = 0;
+        row_offsets[0] = 0;
+        for (int h = 0; h < height; ++h) { acc += row_offsets[h + 1]; row_offsets[h + 1] = acc; }
+        *count = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) cloud_write_kernel(const CloudParams q) {
+    __shared__ int s_wave[4];
+    __shared__ int s_base;
+    const int h = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = q.row_offsets[h];
+    __syncthreads();
+    const float fx = q.k[0], cx = q.k[2], fy = q.k[4], cy = q.k[5];
+    for (int w0 = 0; w0 < q.width; w0 += 256) {
+        const int w = w0 + threadIdx.x;
+        const bool keep = w < q.width && cloud_keep(q, h, w);
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int wave_off = 0;
+        for (int i = 0; i < wave; ++i) wave_off += s_wave[i];
+        const int chunk_total = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (keep) {
+            const int64_t i = static_cast<int64_t>(h) * q.width + w;
+            const float z = q.depth[i];
+            // separate roundings, as numpy evaluates (w - cx) / fx * z
+            const float x = __fmul_rn(__fdiv_rn(__fsub_rn(static_cast<float>(w), cx), fx), z);
+            const float y = __fmul_rn(__fdiv_rn(__fsub_rn(static_cast<float>(h), cy), fy), z);
+            float* dst = q.points + static_cast<int64_t>(s_base + wave_off + before) * 6;
+            dst[0] = x; dst[1] = y; dst[2] = z;
+            dst[3] = static_cast<float>(q.color[3 * i + 2]);
+            dst[4] = static_cast<float>(q.color[3 * i + 1]);
+            dst[5] = static_cast<float>(q.color[3 * i]);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base += chunk_total;
+        __syncthreads();
+    }
+}
+
+}  // namespace endo
+
+extern "C" int endo_point_cloud(const float* depth, const uint8_t* color_bgr, const float* mask, const float* intrinsics, int height,
+                                int width, int downsampling, int use_threshold, float min_threshold, float max_threshold,
+                                int32_t* row_offsets, float* points, int32_t* count_out, void* stream_) {
+    using namespace endo;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (!depth || !color_bgr || !mask || !intrinsics || !row_offsets || !points || !count_out) return ENDO_E_BADARG;
+    if (height <= 0 || width <= 0 || downsampling <= 0) return ENDO_E_BADARG;
+    CloudParams q{depth, color_bgr, mask, intrinsics, height, width, downsampling, use_threshold, min_threshold, max_threshold,
+                  row_offsets, points, count_out};
+    ProfScope prof(kProfGeometry, stream, 0.0, 4.0 * height * width * 3);
+    cloud_count_kernel<<<height, 256, 0, stream>>>(q);
+    ENDO_LAUNCH_CHECK();
+    cloud_scan_kernel<<<1, 64, 0, stream>>>(row_offsets, height, count_out);
+    ENDO_LAUNCH_CHECK();
+    cloud_write_kernel<<<height, 256, 0, stream>>>(q);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}

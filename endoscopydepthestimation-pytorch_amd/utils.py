@@ -46,3 +46,38 @@ def load_model_state(model, state):
     """Load a reference checkpoint's ``state['model']`` with or without the 'module.' prefix."""
     cleaned = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}
     return model.load_state_dict(cleaned)
+
+
+def point_cloud_from_depth(depth_map, color_img, mask_img, intrinsic_matrix, point_cloud_downsampling,
+                           min_threshold=None, max_threshold=None, device="cuda"):
+    """Drop-in for reference utils.py:823-852 on the GPU (endo_point_cloud): (P, 6) float32 numpy array of
+    (x, y, z, r, g, b), row-major over the kept pixels.  The reference walks 81 920 pixels in a Python double loop per
+    frame (evaluate.py:272,340); this is three small kernels.  Inputs may be numpy arrays or tensors (any device);
+    there is no CPU fallback."""
+    import numpy as np
+    from . import _lib
+    lib = _lib.load()
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("point_cloud_from_depth needs a GPU device: the MI355X path has no CPU fallback")
+    depth = torch.as_tensor(np.asarray(depth_map.detach().cpu() if torch.is_tensor(depth_map) else depth_map), dtype=torch.float32)
+    height, width = int(depth.shape[0]), int(depth.shape[1])
+    depth = depth.contiguous().to(dev)
+    color = torch.as_tensor(np.ascontiguousarray(np.asarray(color_img.detach().cpu() if torch.is_tensor(color_img) else color_img)
+                                                 .reshape(height, width, 3)).astype(np.uint8)).to(dev)
+    mask = torch.as_tensor(np.asarray(mask_img.detach().cpu() if torch.is_tensor(mask_img) else mask_img), dtype=torch.float32)
+    mask = mask.reshape(height, width).contiguous().to(dev)
+    k = torch.as_tensor(np.asarray(intrinsic_matrix.detach().cpu() if torch.is_tensor(intrinsic_matrix) else intrinsic_matrix),
+                        dtype=torch.float32).reshape(3, 3).contiguous().to(dev)
+    use_thr = max_threshold is not None and min_threshold is not None
+    points = torch.empty((height * width, 6), dtype=torch.float32, device=dev)
+    offsets = torch.empty(height + 1, dtype=torch.int32, device=dev)
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.endo_point_cloud(_lib.ptr(depth), _lib.ptr(color), _lib.ptr(mask), _lib.ptr(k), height, width,
+                                  int(point_cloud_downsampling), 1 if use_thr else 0,
+                                  float(min_threshold) if use_thr else 0.0, float(max_threshold) if use_thr else 0.0,
+                                  _lib.ptr(offsets), _lib.ptr(points), _lib.ptr(count), _lib.stream())
+    _lib.check(rc, "endo_point_cloud")
+    n = int(count.item())
+    return points[:n].cpu().numpy().reshape(-1, 6)

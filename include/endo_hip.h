@@ -190,6 +190,18 @@ int endo_sparse_scatter(const double* points, int n_points, const double* projec
                         float depth_multiplier, int32_t* winner_scratch, float* depth_masks, float* depths, float* flow_masks,
                         float* flows, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Coloured point cloud of one depth map -- reference utils.py:823-852 (point_cloud_from_depth), the per-frame
+ * back-projection of evaluate.py:272,340.  depth, mask [H][W] fp32; color_bgr [H][W][3] uint8 (cv2 order);
+ * intrinsics [3][3] fp32.  A pixel is kept when h % downsampling == 0, w % downsampling == 0, mask > 0.5 and, with
+ * use_threshold != 0, max(r,g,b) >= max_threshold && min(r,g,b) <= min_threshold.  points receives
+ * (x, y, z, r, g, b) = ((w - cx) / fx * z, (h - cy) / fy * z, z, r, g, b) per kept pixel in row-major pixel order
+ * (capacity H * W rows of 6 floats); *count_out the number of rows written.  row_offsets: H + 1 int32 of workspace.
+ * ------------------------------------------------------------------------------------------- */
+int endo_point_cloud(const float* depth, const uint8_t* color_bgr, const float* mask, const float* intrinsics, int height,
+                     int width, int downsampling, int use_threshold, float min_threshold, float max_threshold,
+                     int32_t* row_offsets, float* points, int32_t* count_out, void* stream);
+
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f
  * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read

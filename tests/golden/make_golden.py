@@ -282,6 +282,27 @@ def scatter_case(ref, path):
     print("wrote", path, "hits", out["pair0_depths_idx"].shape[1])
 
 
+def point_cloud_case(ref, path):
+    """utils.point_cloud_from_depth (utils.py:823-852, called by evaluate.py:272,340) on seeded inputs: three cases --
+    every pixel, downsampling 2, colour thresholds -- with float32 intrinsics / depth as evaluate.py passes them."""
+    rng = np.random.default_rng(41)
+    h, w = 24, 40
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = (((xx - w / 2) / (0.45 * w)) ** 2 + ((yy - h / 2) / (0.45 * h)) ** 2 < 1.0).astype(np.float32)
+    depth = (rng.uniform(0.05, 1.5, (h, w)).astype(np.float32) * mask).astype(np.float32)
+    color = (rng.integers(0, 256, (h, w, 3)).astype(np.uint8) * mask[..., None].astype(np.uint8)).astype(np.uint8)
+    k = np.array([[33.25, 0.0, 19.5], [0.0, 31.75, 11.25], [0.0, 0.0, 1.0]], dtype=np.float32)
+    out = {"depth": depth, "color": color, "mask": mask, "intrinsics": k}
+    cases = (("all", dict(point_cloud_downsampling=1)), ("ds2", dict(point_cloud_downsampling=2)),
+             ("thr", dict(point_cloud_downsampling=1, min_threshold=60, max_threshold=180)))
+    for tag, kw in cases:
+        pc = ref["utils"].point_cloud_from_depth(depth, color, mask, k, **kw)
+        out["points_" + tag] = np.asarray(pc, dtype=np.float32)
+        assert pc.shape[0] > 10
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items()})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -295,6 +316,7 @@ def main():
     train_step_case(ref, 2, 64, 96, 31, os.path.join(HERE, "train_step_2x64x96.npz"))
     cyclic_lr_case(ref, os.path.join(HERE, "cyclic_lr.npz"))
     scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
+    point_cloud_case(ref, os.path.join(HERE, "point_cloud.npz"))
 
 
 if __name__ == "__main__":

@@ -100,3 +100,29 @@ def test_scatter_empty_cloud_and_multiplier(pkg):
     b = seq.planes(ext, proj, [[0, 1]], depth_multiplier=0.25)
     torch.testing.assert_close(b["depths"], a["depths"] * 0.25, rtol=0, atol=0)
     torch.testing.assert_close(b["flows"], a["flows"], rtol=0, atol=0)
+
+
+def test_point_cloud_golden_and_oracle(pkg, golden):
+    """endo_point_cloud against the fixture generated from reference utils.point_cloud_from_depth (bit exact: the kernel
+    keeps numpy's three separate float32 roundings) and against the oracle at 256 x 320 with the synthetic mask."""
+    from oracle import pointcloud as oracle_pc
+    g = golden("point_cloud.npz")
+    cases = (("all", dict(point_cloud_downsampling=1)), ("ds2", dict(point_cloud_downsampling=2)),
+             ("thr", dict(point_cloud_downsampling=1, min_threshold=60, max_threshold=180)))
+    for tag, kw in cases:
+        got = pkg.utils.point_cloud_from_depth(g["depth"], g["color"], g["mask"], g["intrinsics"], **kw)
+        assert got.dtype == np.float32 and got.shape[1] == 6
+        np.testing.assert_array_equal(got, g["points_" + tag], err_msg=tag)
+    rng = np.random.default_rng(5)
+    h, w = 256, 320
+    batch = pkg.synthetic.make_batch(1, h, w, seed=3)
+    mask = batch["boundaries"][0, 0].numpy()
+    depth = (rng.uniform(0.01, 2.0, (h, w)).astype(np.float32) * mask).astype(np.float32)
+    color = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    k = batch["intrinsics"][0].numpy().astype(np.float32)
+    for ds in (1, 3, 4):
+        got = pkg.utils.point_cloud_from_depth(torch.from_numpy(depth), color, mask, k, ds)
+        want = oracle_pc.point_cloud_from_depth(depth, color, mask, k, ds)
+        np.testing.assert_array_equal(got, want, err_msg="downsampling %d" % ds)
+    empty = pkg.utils.point_cloud_from_depth(depth, color, np.zeros_like(mask), k, 1)
+    assert empty.shape == (0, 6)
