@@ -553,19 +553,29 @@ __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockPa
                 }
             }
             // ---- layer l's ReLU mask + BN backward, accumulated over the layers of the block ----
-            float s1 = 0.f, s2 = 0.f;
+            // two pixels per instruction (v_pk_add / v_pk_fma): 9 VALU per pair; sum dz * xhat is kept as sum dz * (x - mean)
+            // and scaled by rstd once
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 mean2 = {mean, mean}, scale2 = {scale, scale}, beta2 = {beta, beta};
+            f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int y = y0 + wy + r;
                 if (co < p.count && y < p.h && px + 3 < p.w) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float xcen = xc[r][e] - mean;
-                        const float z = fmaf(xcen, scale, beta);
-                        const float dz = z > 0.f ? acc[r][e] : 0.f;
-                        s1 += dz;
-                        s2 += dz * (xcen * rstd);
-                        total[r][e] += scale * dz;
+                    for (int hp = 0; hp < 2; ++hp) {
+                        const f32x2 xv = {xc[r][2 * hp], xc[r][2 * hp + 1]};
+                        const f32x2 xcen = xv - mean2;
+                        const f32x2 z = __builtin_elementwise_fma(xcen, scale2, beta2);
+                        f32x2 dz;
+                        dz[0] = z[0] > 0.f ? acc[r][2 * hp] : 0.f;
+                        dz[1] = z[1] > 0.f ? acc[r][2 * hp + 1] : 0.f;
+                        s1v += dz;
+                        s2v = __builtin_elementwise_fma(dz, xcen, s2v);
+                        f32x2 tv = {total[r][2 * hp], total[r][2 * hp + 1]};
+                        tv = __builtin_elementwise_fma(dz, scale2, tv);
+                        total[r][2 * hp] = tv[0];
+                        total[r][2 * hp + 1] = tv[1];
                     }
                     if (last_layer) {
                         f32x4 o = dc[r];
@@ -576,6 +586,8 @@ __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockPa
                 }
                 if (last_layer) total[r] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            float s1 = s1v[0] + s1v[1];
+            float s2 = (s2v[0] + s2v[1]) * rstd;
             s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
             if (lk == 0) {
