@@ -2,7 +2,7 @@
 train-step fixture components.  Writes gpurun_out/diag.txt."""
 import importlib, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import network as onet, train_step as ostep
 ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")

@@ -1,6 +1,6 @@
 import importlib, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import network as onet
 ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")

@@ -1,7 +1,7 @@
 """forward_pair running-statistics diagnosis (development tool)."""
 import importlib, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
 from oracle import network as onet

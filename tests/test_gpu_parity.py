@@ -38,7 +38,7 @@ def noise_aware(got, ref32, ref64, what, floor=1e-4, factor=4.0, scale=None):
     """fp32 training-mode BatchNorm over a handful of samples is ill-conditioned, and ReLU masks /
     max-pool argmax / |.| are discontinuous: the reference's own fp32 CPU path differs from an fp64
     evaluation of the same graph by up to ~2e-3 on early-layer gradients at test sizes, with isolated
-    elements off by O(1/sqrt(#pixels)) where a single mask bit flipped (measured: tools/gpu_diag2.py).
+    elements off by O(1/sqrt(#pixels)) where a single mask bit flipped (measured: tests/diag/gpu_diag2.py).
     So the bar is "as close to the fp64 oracle as the fp32 CPU oracle is":
       * 90th percentile of |hip - fp64| <= max(factor x the same percentile for cpu32, floor)
       * max |hip - fp64| <= max(15 x max for cpu32, 5e-2)          (a few flipped mask bits)
