@@ -49,8 +49,15 @@ struct ConvDmaSmem {
 // read by 3 taps); 1 = once, in place in LDS, by the thread whose DMA wrote the value, right after
 // its own vmcnt(0) and before the barrier that publishes the chunk (no extra synchronisation).
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = only the first chunk is DMA'd, 2 = no BN+ReLU on the fragment read, 4 = DMA never waited for (racy: timing only)
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0>
+// PH: sub-pixel row phase of the transition-up forward (-1 = ordinary convolution).  nearest x2 followed by a 3x3
+// convolution (reference models.py:70-80) is, for the output pixels (2y+a, 2x+b), a 2x2 convolution of the LOW-resolution
+// input with tap-summed weights: the 3 upsampled rows a 3x3 window covers are only 2 distinct input rows.  With PH = a the
+// kernel runs on the low-resolution grid, its 16*Q "output channels" are [b = 0 | b = 1] x Q/2 tiles of real channels
+// (weights pre-summed by tu_phase_weights_kernel), the taps a phase does not use are skipped at compile time (16 of 36
+// tap-phase pairs remain: 4/9 of the MACs) and the epilogue interleaves the two column phases into full-resolution rows.
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0, int PH = -1>
 __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p0) {
+    static_assert(PH < 0 || (KS == 3 && (Q % 2) == 0 && IN == IN_PLAIN && EPI == EPI_FWD), "phase mode is the transition-up forward");
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");      // (three buffers, DMA two chunks ahead: 7 % slower in the in-job A/B)
     static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL), "16-byte DMA needs contiguous sources");
@@ -61,6 +68,8 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     constexpr int kWElems = S::kW;
     constexpr int kWPre = (kWElems + kConvThreads - 1) / kConvThreads;
     constexpr bool kDgrad = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_SUMPOOL);
+    constexpr int kPhW = 2 * 12 * 16 + 16;          // phase mode: floats per input channel (== 16 mod 32: conflict-free B reads)
+    static_assert(PH < 0 || KC * kPhW <= kWElems, "the phase weights fit the ordinary weight buffer");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_aux = smem + NBUF * S::kBuf;
@@ -220,8 +229,19 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 }
             }
         }
+        if constexpr (PH >= 0) {
+            // compact phase weights: [ci][kPhW] floats, the 2 x 12 (row tap, column-tap x tile) slices a row phase uses
+            constexpr int kUnitsW = KC * kPhW / 4;
+            const float* wsrc = p.wgt + static_cast<int64_t>(c_base) * kPhW;
 #pragma unroll
-        for (int k = 0; k < kWPre; ++k) {
+            for (int k = 0; k < (kUnitsW + kConvThreads - 1) / kConvThreads; ++k) {
+                const int u0 = k * kConvThreads + wave * 64;
+                if (u0 < kUnitsW && u0 + lane < kUnitsW)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 4 * (u0 + lane)), (lptr_t)(s_w + 4 * u0), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < (PH >= 0 ? 0 : kWPre); ++k) {
             const int e0 = k * kConvThreads + wave * 64;
             if (e0 < kWElems) {
                 const int e = e0 + lane;
@@ -232,7 +252,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 const int ci = c_base + c;
                 const int co = co_base + j;
                 const float* src = pad_zero;
-                if (e < kWElems && ci < p.cin && co < p.cout) {
+                if (e < kWElems && ci < p.cin && co < (PH >= 0 ? p.w_cout : p.cout)) {
                     if constexpr (kDgrad) src = p.wgt + (static_cast<int64_t>(ci) * p.w_cin + co) * KK + (KK - 1 - tap);
                     else src = p.wgt + (static_cast<int64_t>(co) * p.w_cin + ci) * KK + tap;
                 }
@@ -359,9 +379,18 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 }
 #pragma unroll
                 for (int dy = 0; dy < KS; ++dy) {
+                    if (PH == 0 && dy == 2) continue;          // row phase 0 sees input rows y-1, y; phase 1 rows y, y+1
+                    if (PH == 1 && dy == 0) continue;
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
-                        const float b = b_base[(dy * KS + dx) * KC * NB + q * 16];
+                        if (PH >= 0 && ((q < Q / 2 && dx == 2) || (q >= Q / 2 && dx == 0))) continue;      // column phase of this tile
+                        float b;
+                        if constexpr (PH >= 0) {
+                            const int slot = dx == 0 ? q : (dx == 1 ? Q / 2 + q : Q / 2 + Q + (q - Q / 2));
+                            b = s_w[(quad * 4 + lk) * kPhW + ((dy - PH) * 2 * Q + slot) * 16 + li];
+                        } else {
+                            b = b_base[(dy * KS + dx) * KC * NB + q * 16];
+                        }
 #pragma unroll
                         for (int r = 0; r < R; ++r)
                             acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r + dy], b, acc[r][q], 0, 0, 0);
@@ -451,10 +480,54 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             return;
         }
     }
+    if constexpr (PH >= 0) {
+        // lane holds, for real channel co = q*16 + li (q < Q/2), low-resolution pixels x = px..px+3 of rows y0+wy+r in both
+        // column phases (tiles q and q + Q/2): full-resolution row 2y + PH, columns 2px .. 2px+7 -- two float4 stores
+        constexpr int QH = Q / 2;
+        float* s_red = s_aux + 3 * cap + 4 * NB;
+        const int px = x0 + wx + 4 * lk;
+#pragma unroll
+        for (int q = 0; q < QH; ++q) {
+            const int co = q * 16 + li;
+            const bool co_ok = co < p.cout;
+            const float bias = (co_ok && p.bias) ? p.bias[co] : 0.f;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int y = y0 + wy + r;
+                if (co_ok && y < p.h && px + 3 < p.w) {
+                    f32x4 lo, hi;
+                    lo[0] = acc[r][q][0] + bias; lo[1] = acc[r][q + QH][0] + bias; lo[2] = acc[r][q][1] + bias; lo[3] = acc[r][q + QH][1] + bias;
+                    hi[0] = acc[r][q][2] + bias; hi[1] = acc[r][q + QH][2] + bias; hi[2] = acc[r][q][3] + bias; hi[3] = acc[r][q + QH][3] + bias;
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + static_cast<int64_t>(2 * y + PH) * p.out_w + 2 * px;
+                    *reinterpret_cast<f32x4*>(dst) = lo;
+                    *reinterpret_cast<f32x4*>(dst + 4) = hi;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s1 += lo[e] + hi[e]; s2 += lo[e] * lo[e] + hi[e] * hi[e]; }
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lk == 0) {
+                s_red[((tid >> 6) * NB + q * 16 + li) * 2] = s1;
+                s_red[((tid >> 6) * NB + q * 16 + li) * 2 + 1] = s2;
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * 16 * QH) {
+            const int j = tid >> 1, which = tid & 1;
+            if (j < p.cout) {
+                double t = 0.0;
+                for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
+                atomicAdd(p.out_sums + 2 * j + which, t);
+            }
+        }
+        return;
+    }
     conv_epilogue<Q, EPI, R>(po, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
 }
 
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0, int EXP = 0>
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0, int EXP = 0, int PH = -1>
 inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     static_assert(XF == 0 || NBUF == 2 || IN != IN_BNRELU, "the in-place transform pipeline is written for two buffers");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
@@ -462,15 +535,15 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = (IN == IN_BNRELU) ? ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16 : 0;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
-    dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (p.cout + 16 * Q - 1) / (16 * Q), p.n);
+    dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (PH >= 0 ? 1 : (p.cout + 16 * Q - 1) / (16 * Q)), p.n);
     const size_t smem = S::bytes(p.bn_cap);
     static size_t configured = 0;
     if (smem > 48 * 1024 && smem > configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP>),
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         configured = smem;
     }
-    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP><<<grid, kConvThreads, smem, stream>>>(p);
+    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH><<<grid, kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

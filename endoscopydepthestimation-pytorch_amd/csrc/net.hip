@@ -208,6 +208,38 @@ __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, int nl, float* __restric
     }
 }
 
+// Tap-summed weights of the transition-up sub-pixel phases (conv_dma_kernels.h, PH) in the compact layout the kernel
+// DMAs: out[a][ci][400] with, for row tap t in {0,1} and slot in [0,12): slot 0-2 = column tap 0 of the b = 0 tiles,
+// 3-8 = column tap 1 of all six tiles (b = 0 | b = 1), 9-11 = column tap 2 of the b = 1 tiles; 16 channels per tile.
+// Row phase 0 sees input rows (y-1, y): row tap 0 <- ky 0, 1 <- ky 1 + ky 2; row phase 1 sees (y, y+1): 0 <- ky 0 + ky 1,
+// 1 <- ky 2.  Column phases likewise: b = 0 sees (x-1, x), b = 1 sees (x, x+1).
+__global__ void tu_phase_weights_kernel(const float* __restrict__ w, int cout, int cin, float* __restrict__ out) {
+    constexpr int kPhW = 2 * 12 * 16 + 16;
+    const int total = 2 * cin * 2 * 12 * 16;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int lane16 = i & 15;
+        const int slot = (i >> 4) % 12;
+        const int t = (i / (16 * 12)) & 1;
+        const int ci = (i / (16 * 12 * 2)) % cin;
+        const int a = i / (16 * 12 * 2 * cin);
+        int ctap, tile;                                     // column tap (0..2 on the low-res grid) and tile (0..5)
+        if (slot < 3) { ctap = 0; tile = slot; } else if (slot < 9) { ctap = 1; tile = slot - 3; } else { ctap = 2; tile = slot - 9 + 3; }
+        const int b = tile / 3, co = (tile % 3) * 16 + lane16;
+        float v = 0.f;
+        if (co < cout) {
+            const float* src = w + (static_cast<int64_t>(co) * cin + ci) * 9;
+            // original rows / columns that fall on this low-res tap
+            const int ky0 = a == 0 ? (t == 0 ? 0 : 1) : (t == 0 ? 0 : 2), ky1 = a == 0 ? (t == 0 ? 0 : 2) : (t == 0 ? 1 : 2);
+            int kx0, kx1;
+            if (b == 0) { kx0 = ctap == 0 ? 0 : 1; kx1 = ctap == 0 ? 0 : 2; }          // b = 0: tap 0 <- kx 0, tap 1 <- kx 1 + kx 2
+            else { kx0 = ctap == 1 ? 0 : 2; kx1 = ctap == 1 ? 1 : 2; }                  // b = 1: tap 1 <- kx 0 + kx 1, tap 2 <- kx 2
+            for (int ky = ky0; ky <= ky1; ++ky)
+                for (int kx = kx0; kx <= kx1; ++kx) v += src[ky * 3 + kx];
+        }
+        out[(static_cast<int64_t>(a) * cin + ci) * kPhW + (t * 12 + slot) * 16 + lane16] = v;
+    }
+}
+
 // split-K epilogue of the coarse-level dense layers: out = bias + sum over K slices of the partial sums,
 // plus the per-channel sum / sum^2 that later BN layers need.  grid (x blocks, channel, sample).
 __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __restrict__ partial, int64_t split_stride, int ksplit,
@@ -458,14 +490,35 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
 
 // transition up: nearest x2 -> conv3x3 48->48 into channels [0,48) of the finer level (models.py:70-80)
 static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const ConvP& cv) {
+    const auto& sv = c.net->lv[src_level];
+    ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
+                   4.0 * c.nt() * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
+    if (sv.w % 4 == 0 && cv.cout == kNew && cv.cin % 4 == 0) {
+        // sub-pixel form: two launches (row phases) on the low-resolution grid, 4/9 of the MACs.  The tap-summed weights
+        // go to the (idle) split-K scratch of group 0's tape; they are shared by all groups.
+        float* w3 = c.tape + c.net->partial_off;
+        tu_phase_weights_kernel<<<(2 * cv.cin * 384 + 255) / 256, 256, 0, c.stream>>>(c.params + cv.w, cv.cout, cv.cin, w3);
+        ENDO_LAUNCH_CHECK();
+        for (int a = 0; a < 2; ++a) {
+            ConvParams p{};
+            fill_grid(c, p, src_level);                     // the launch runs over the low-resolution pixels
+            fill_in(c, p, c.act(src_level), src_level, src_c0, cv.cin);
+            p.wgt = w3 + static_cast<int64_t>(a) * cv.cin * 400; p.w_cout = 2 * cv.cout; p.w_cin = cv.cin;
+            p.bias = c.params + cv.b;
+            fill_out(c, p, c.act(level), level, 0, cv.cout);
+            p.out_sums = c.sums(level);
+            int rc = a == 0 ? launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 0>(p, c.stream)
+                            : launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 1>(p, c.stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     ConvParams p{};
     fill_grid(c, p, level);
     fill_in(c, p, c.act(src_level), src_level, src_c0, cv.cin);
     p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.act(level), level, 0, cv.cout);
     p.out_sums = c.sums(level);
-    ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
-                   4.0 * c.nt() * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
     return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
