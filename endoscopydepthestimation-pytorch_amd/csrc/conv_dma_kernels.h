@@ -60,7 +60,11 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     static_assert(PH < 0 || (KS == 3 && (Q % 2) == 0 && IN == IN_PLAIN && EPI == EPI_FWD), "phase mode is the transition-up forward");
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");      // (three buffers, DMA two chunks ahead: 7 % slower in the in-job A/B)
-    static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL), "16-byte DMA needs contiguous sources");
+    static_assert(VEC == 1 || (VEC == 4 && IN != IN_UPSAMPLE && IN != IN_UNPOOL && IN != IN_SUBPIX), "16-byte DMA needs contiguous sources");
+    // IN_SUBPIX: the transition-up data gradient in sub-pixel form.  d(low-res input) = sum over the four sub-pixel phases
+    // (alpha, beta) of the full-resolution dY, each a stride-2 sub-sampled plane ("pseudo input channel" (alpha, beta, co))
+    // seen through 2 x 2 of the 3 x 3 low-resolution taps with tap-summed weights: 16 instead of 36 tap-phase pairs.
+    static_assert(IN != IN_SUBPIX || (KS == 3 && EPI == EPI_FWD && PH < 0), "sub-pixel input mode is the transition-up data gradient");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
     using S = ConvDmaSmem<KS, KC, Q, WX, R, NBUF, VEC, IN>;
     constexpr int KK = KS * KS;
@@ -70,6 +74,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     constexpr bool kDgrad = (EPI == EPI_DGRAD_BN || EPI == EPI_DGRAD_SUMPOOL);
     constexpr int kPhW = 2 * 12 * 16 + 16;          // phase mode: floats per input channel (== 16 mod 32: conflict-free B reads)
     static_assert(PH < 0 || KC * kPhW <= kWElems, "the phase weights fit the ordinary weight buffer");
+    constexpr int kSubW = 4 * 16 * Q + 16;          // IN_SUBPIX: floats per pseudo input channel (== 16 mod 32 for Q = 3)
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_aux = smem + NBUF * S::kBuf;
@@ -146,6 +151,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {      // W % VEC == 0: a unit is entirely in or out
                 pos_ok |= (1u << k);
                 if constexpr (IN == IN_UPSAMPLE) goff[k] = (gy >> 1) * p.in_w + (gx >> 1);
+                else if constexpr (IN == IN_SUBPIX) goff[k] = 2 * gy * p.in_w + 2 * gx;
                 else goff[k] = gy * p.in_w + gx;
             }
         }
@@ -210,10 +216,14 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 }
             }
         }
+        int sub_ph = 0;          // IN_SUBPIX: the chunk's sub-pixel phase (a chunk never straddles phases: KC divides sub_c)
+        if constexpr (IN == IN_SUBPIX) sub_ph = c_base / p.sub_c;
 #pragma unroll
         for (int c = 0; c < (IN == IN_UNPOOL ? 0 : KC); ++c) {
             const int ch = c_base + c;
             const float* plane = in_n + static_cast<int64_t>(ch) * p.in_cs;
+            if constexpr (IN == IN_SUBPIX)
+                plane = in_n + static_cast<int64_t>(ch - sub_ph * p.sub_c) * p.in_cs + (sub_ph >> 1) * p.in_w + (sub_ph & 1);
 #pragma unroll
             for (int k = 0; k < G::kPos; ++k) {
                 const int e0 = k * kConvThreads + wave * 64;          // wave-uniform first unit
@@ -229,6 +239,17 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 }
             }
         }
+        if constexpr (IN == IN_SUBPIX) {
+            // compact weights: [pseudo channel][kSubW] floats = 2 x 2 taps x NB output channels (+ pad)
+            constexpr int kUnitsW = KC * kSubW / 4;
+            const float* wsrc = p.wgt + static_cast<int64_t>(c_base) * kSubW;
+#pragma unroll
+            for (int k = 0; k < (kUnitsW + kConvThreads - 1) / kConvThreads; ++k) {
+                const int u0 = k * kConvThreads + wave * 64;
+                if (u0 < kUnitsW && u0 + lane < kUnitsW)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 4 * (u0 + lane)), (lptr_t)(s_w + 4 * u0), 16, 0, 0);
+            }
+        }
         if constexpr (PH >= 0) {
             // compact phase weights: [ci][kPhW] floats, the 2 x 12 (row tap, column-tap x tile) slices a row phase uses
             constexpr int kUnitsW = KC * kPhW / 4;
@@ -241,7 +262,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             }
         }
 #pragma unroll
-        for (int k = 0; k < (PH >= 0 ? 0 : kWPre); ++k) {
+        for (int k = 0; k < ((PH >= 0 || IN == IN_SUBPIX) ? 0 : kWPre); ++k) {
             const int e0 = k * kConvThreads + wave * 64;
             if (e0 < kWElems) {
                 const int e = e0 + lane;
@@ -319,6 +340,12 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     auto compute = [&](int chunk, int buf) {
         const float* s_in = smem + buf * S::kBuf;
         const float* s_w = s_in + KC * S::kChan;
+        int sub_alpha = 0, sub_beta = 0;          // IN_SUBPIX: sub-pixel phase of this chunk's pseudo-channels (block-uniform)
+        if constexpr (IN == IN_SUBPIX) {
+            const int sub_ph = (chunk * KC) / p.sub_c;
+            sub_alpha = sub_ph >> 1; sub_beta = sub_ph & 1;
+        }
+        (void)sub_alpha; (void)sub_beta;
         if constexpr (IN == IN_UNPOOL) {
             // a[row][x] = g[row/2][x/2] if code[row/2][x/2] == 2*(row&1) + (x&1) else 0 (y0, wy and wx are even)
             constexpr int PC = G::kTileX / 2;
@@ -377,15 +404,24 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
 #pragma unroll
                     for (int r = 0; r < R + KS - 1; ++r) a[r] = a_base[r * G::kCols + dx];
                 }
+                if constexpr (IN == IN_SUBPIX) {
+                    if (dx == (sub_beta == 0 ? 0 : 2)) continue;          // beta = 0 sees columns x, x+1; beta = 1 columns x-1, x
+                }
 #pragma unroll
                 for (int dy = 0; dy < KS; ++dy) {
                     if (PH == 0 && dy == 2) continue;          // row phase 0 sees input rows y-1, y; phase 1 rows y, y+1
                     if (PH == 1 && dy == 0) continue;
+                    if constexpr (IN == IN_SUBPIX) {
+                        if (dy == (sub_alpha == 0 ? 0 : 2)) continue;     // alpha = 0 sees rows y, y+1; alpha = 1 rows y-1, y
+                    }
 #pragma unroll
                     for (int q = 0; q < Q; ++q) {
                         if (PH >= 0 && ((q < Q / 2 && dx == 2) || (q >= Q / 2 && dx == 0))) continue;      // column phase of this tile
                         float b;
-                        if constexpr (PH >= 0) {
+                        if constexpr (IN == IN_SUBPIX) {
+                            const int tyi = dy - (sub_alpha == 0 ? 1 : 0), txi = dx - (sub_beta == 0 ? 1 : 0);
+                            b = s_w[(quad * 4 + lk) * kSubW + (tyi * 2 + txi) * NB + q * 16 + li];
+                        } else if constexpr (PH >= 0) {
                             const int slot = dx == 0 ? q : (dx == 1 ? Q / 2 + q : Q / 2 + Q + (q - Q / 2));
                             b = s_w[(quad * 4 + lk) * kPhW + ((dy - PH) * 2 * Q + slot) * 16 + li];
                         } else {

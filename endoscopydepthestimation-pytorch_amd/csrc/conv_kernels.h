@@ -32,7 +32,7 @@
 
 namespace endo {
 
-enum InMode { IN_PLAIN = 0, IN_BNRELU = 1, IN_UPSAMPLE = 2, IN_UNPOOL = 3 };
+enum InMode { IN_PLAIN = 0, IN_BNRELU = 1, IN_UPSAMPLE = 2, IN_UNPOOL = 3, IN_SUBPIX = 4 };
 enum Epilogue { EPI_FWD = 0, EPI_FWD_POOL = 1, EPI_DGRAD_BN = 2, EPI_DGRAD_SUMPOOL = 3 };
 
 constexpr int kConvThreads = 256;
@@ -90,6 +90,7 @@ struct ConvParams {
     // caller tensors), parameter pointers do not move.  group_n == 0 means "not grouped" (one group of n samples).
     int group_n;
     int64_t gs, in_gs, out_gs;
+    int sub_c;        // IN_SUBPIX: real channels per sub-pixel phase (cin = 4 * sub_c pseudo-channels)
 };
 
 // this block's group and sample inside it

@@ -240,6 +240,29 @@ __global__ void tu_phase_weights_kernel(const float* __restrict__ w, int cout, i
     }
 }
 
+// Tap-summed weights of the transition-up DATA gradient in sub-pixel form (conv_dma_kernels.h, IN_SUBPIX):
+// out[pseudo = (alpha, beta, co)][208] = [(tyi, txi)][ci] (+ pad).  With u = a + 1 - ky the row offset of dY seen from low-res
+// row y:  alpha = 0: tyi 0 (row y) <- ky 1 + ky 2, tyi 1 (row y+1) <- ky 0;  alpha = 1: tyi 0 (row y-1) <- ky 2,
+// tyi 1 (row y) <- ky 0 + ky 1.  Columns likewise.
+__global__ void tu_subpix_dgrad_weights_kernel(const float* __restrict__ w, int cout, int cin, float* __restrict__ out) {
+    const int pitch = 4 * cin + 16;
+    const int total = 4 * cout * 4 * cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int ci = i % cin;
+        const int tap = (i / cin) & 3;
+        const int co = (i / (4 * cin)) % cout;
+        const int ph = i / (4 * cin * cout);
+        const int alpha = ph >> 1, beta = ph & 1, tyi = tap >> 1, txi = tap & 1;
+        const int ky0 = alpha == 0 ? (tyi == 0 ? 1 : 0) : (tyi == 0 ? 2 : 0), ky1 = alpha == 0 ? (tyi == 0 ? 2 : 0) : (tyi == 0 ? 2 : 1);
+        const int kx0 = beta == 0 ? (txi == 0 ? 1 : 0) : (txi == 0 ? 2 : 0), kx1 = beta == 0 ? (txi == 0 ? 2 : 0) : (txi == 0 ? 2 : 1);
+        const float* src = w + (static_cast<int64_t>(co) * cin + ci) * 9;
+        float v = 0.f;
+        for (int ky = ky0; ky <= ky1; ++ky)
+            for (int kx = kx0; kx <= kx1; ++kx) v += src[ky * 3 + kx];
+        out[static_cast<int64_t>(ph * cout + co) * pitch + tap * cin + ci] = v;
+    }
+}
+
 // split-K epilogue of the coarse-level dense layers: out = bias + sum over K slices of the partial sums,
 // plus the per-channel sum / sum^2 that later BN layers need.  grid (x blocks, channel, sample).
 __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __restrict__ partial, int64_t split_stride, int ksplit,
@@ -751,12 +774,26 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
+    ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cout + cv.cin / 4.0));
+    if (sv.w % 4 == 0 && cv.cin == kNew && cv.cout == kNew) {
+        // sub-pixel form on the low-resolution grid: the four stride-2 phases of dY are 4 x 48 pseudo input channels of a
+        // 3x3 convolution that uses 2x2 of its taps per phase (4/9 of the MACs); the weights go to the (idle) n-split scratch
+        float* wd = c.gradws + c.net->wg_scratch_off;
+        tu_subpix_dgrad_weights_kernel<<<(16 * cv.cout * cv.cin + 255) / 256, 256, 0, c.stream>>>(c.params + cv.w, cv.cout, cv.cin, wd);
+        ENDO_LAUNCH_CHECK();
+        ConvParams p{};
+        fill_grid(c, p, src_level);
+        fill_in(c, p, c.gbuf(level), level, 0, 4 * cv.cout);      // strides of the full-resolution gradient buffer
+        p.sub_c = cv.cout;
+        p.wgt = wd; p.w_cout = cv.cin; p.w_cin = 4 * cv.cout;
+        fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
+        return launch_conv_dma_vec<3, 8, 3, IN_SUBPIX, EPI_FWD, 2, 4, 2, 1, 1>(p, c.stream);
+    }
     ConvParams p{};
     fill_grid(c, p, level);
     fill_in(c, p, c.gbuf(level), level, 0, cv.cout);
     p.wgt = c.params + cv.w; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
-    ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cout + cv.cin / 4.0));
     return launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_DGRAD_SUMPOOL, 4>(p, c.stream);
 }
 
