@@ -22,6 +22,7 @@
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
+#include "wgrad_subpix_kernels.h"
 
 namespace endo {
 
@@ -771,7 +772,10 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
         ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin / 4.0 + cv.cout));
-        rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
+        WgradParams ps = p;                    // sub-pixel form walks the low-resolution grid
+        ps.h = sv.h; ps.w = sv.w;
+        if (tu_wgrad_subpix_ok(ps)) rc = launch_tu_wgrad_subpix(ps, c.gradws + c.net->wg_scratch_off, c.stream);
+        else rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
         if (rc) return rc;
     }
     ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cout + cv.cin / 4.0));
@@ -841,7 +845,7 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->scratch_off = align_up((acts + net->pq_floats) * 4, 256);
     net->scratch_bytes = tb.bn_width_total * 2 * 8;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
-    net->gradws_floats = net->wg_scratch_off + kNsScratchFloats;
+    net->gradws_floats = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
