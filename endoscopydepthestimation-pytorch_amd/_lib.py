@@ -38,6 +38,7 @@ SIGNATURES = {
     "endo_net_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
     "endo_net_create_grouped": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "endo_net_groups": (_I, [_P]),
+    "endo_set_wgrad_overlap": (_I, [_I]),
     "endo_net_group_stride": (_L, [_P]),
     "endo_net_destroy": (None, [_P]),
     "endo_net_param_floats": (_L, []),

@@ -33,6 +33,8 @@ constexpr int kLevels = 5;
 constexpr int kNew = kGrowth * kLayers;   // 48
 constexpr float kBnEps = 1.0e-5f;
 constexpr float kBnMomentum = 0.1f;
+constexpr int kSideStreamFromLevel = 0;      // weight gradients of levels >= this run on the side stream (in-job A/B: 0 -> -4.7 %, 1 -> -3 %, 2 -> -1.8 % step time)
+static int g_wgrad_overlap = 1;              // endo_set_wgrad_overlap: 0 = weight gradients in line on the caller's stream
 
 struct ConvP { int64_t w, b; int cout, cin, ks; };
 struct BnP { int64_t g, b; int c; int64_t run; int64_t saved; };   // run: offset in bn_running; saved: offset (pairs) in saved/scratch
@@ -107,7 +109,13 @@ struct endo_net {
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
     int64_t scratch_bytes;
     int64_t wg_scratch_off;   // float offset in gradws of the weight-gradient partial sums (wgrad_nsplit_kernels.h)
+    int64_t tuw_scratch_off;  // float offset in gradws of the transition-up data-gradient weights (tu_subpix_dgrad_weights_kernel)
     int64_t gradws_floats;
+    // Weight gradients run on a side stream: a layer's wgrad depends only on its prepared dY and the forward tape, nothing on the
+    // backward chain depends on it (it only adds into the flat gradient), so it overlaps the data-gradient chain -- which at the
+    // coarse levels is a string of launches too small to fill the chip.  Forked after every prep_dy, joined once at the end.
+    hipStream_t wstream;
+    hipEvent_t ev_fork, ev_join;
 };
 
 namespace endo {
@@ -393,6 +401,15 @@ struct Ctx {
     hipStream_t stream;
 
     int nt() const { return net->n * net->groups; }      // samples of all groups
+    // context of the weight-gradient side stream, ordered after everything issued so far on the main stream
+    int fork_wgrad(Ctx& side, int level) const {
+        side = *this;
+        if (!net->wstream || !g_wgrad_overlap || level < kSideStreamFromLevel) return 0;          // run in line
+        ENDO_CHECK(hipEventRecord(net->ev_fork, stream));
+        ENDO_CHECK(hipStreamWaitEvent(net->wstream, net->ev_fork, 0));
+        side.stream = net->wstream;
+        return 0;
+    }
     float* act(int level) const { return tape + net->lv[level].act; }
     float* gbuf(int level) const { return gradws + net->lv[level].grad; }
     double* sums(int level) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(tape) + net->sums_off) + net->lv[level].sums; }
@@ -599,8 +616,13 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     const auto& lv = c.net->lv[level];
     int rc = prep_dy(c, level, oc0, cv.cout, c.grads + cv.b);
     if (rc) return rc;
-    rc = dense_wgrad(c, level, ic0, oc0, b, cv);
-    if (rc) return rc;
+    {
+        Ctx cw;
+        rc = c.fork_wgrad(cw, level);
+        if (rc) return rc;
+        rc = dense_wgrad(cw, level, ic0, oc0, b, cv);
+        if (rc) return rc;
+    }
     {
         ConvParams p{};
         fill_grid(c, p, level);
@@ -650,8 +672,13 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     for (int j = kLayers - 1; j >= 0; --j) {
         int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b);
         if (rc) return rc;
-        rc = dense_wgrad(c, level, ic0, new0 + kGrowth * j, bn[j], cv[j]);
-        if (rc) return rc;
+        {
+            Ctx cw;
+            rc = c.fork_wgrad(cw, level);
+            if (rc) return rc;
+            rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * j, bn[j], cv[j]);
+            if (rc) return rc;
+        }
         if (j > 0) {
             // Gradient into the 12 new maps of layer j-1 from ALL its consumers inside the block (layers j..3) in one pass:
             // the layer-to-layer dependency only needs G_j..G_3 final, and this way every new map is read (x) and
@@ -736,8 +763,11 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.dy = c.gbuf(next) + oc0 * nx.plane; p.dy_ns = nx.t * nx.plane; p.dy_cs = static_cast<int>(nx.plane); p.dy_w = nx.w; p.cout = cv.cout;
         p.dy_idx = c.idx(level); p.idx_ns = static_cast<int64_t>(cv.cout) * nx.plane;
         p.dw = c.grads + cv.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * cv.cin);
-        rc = wgrad1x1_dma_ok(p) ? launch_wgrad1x1_dma(p, c.stream) : launch_wgrad1x1(p, c.stream);
+        Ctx cw;
+        rc = c.fork_wgrad(cw, level);
+        if (rc) return rc;
+        ProfScope prof(kProfWgradOther, cw.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * cv.cin);
+        rc = wgrad1x1_dma_ok(p) ? launch_wgrad1x1_dma(p, cw.stream) : launch_wgrad1x1(p, cw.stream);
         if (rc) return rc;
     }
     {
@@ -771,18 +801,21 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.in = c.act(src_level) + src_c0 * sv.plane; p.in_ns = sv.t * sv.plane; p.in_cs = static_cast<int>(sv.plane); p.in_w = sv.w; p.cin = cv.cin;
         p.dy = c.gbuf(level); p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
         p.dw = c.grads + cv.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin / 4.0 + cv.cout));
+        Ctx cw;
+        rc = c.fork_wgrad(cw, level);
+        if (rc) return rc;
+        ProfScope prof(kProfWgradOther, cw.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin / 4.0 + cv.cout));
         WgradParams ps = p;                    // sub-pixel form walks the low-resolution grid
         ps.h = sv.h; ps.w = sv.w;
-        if (tu_wgrad_subpix_ok(ps)) rc = launch_tu_wgrad_subpix(ps, c.gradws + c.net->wg_scratch_off, c.stream);
-        else rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, c.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, c.stream);
+        if (tu_wgrad_subpix_ok(ps)) rc = launch_tu_wgrad_subpix(ps, c.gradws + c.net->wg_scratch_off, cw.stream);
+        else rc = wgrad_taps_ok(p, true) ? launch_wgrad_taps<12, IN_UPSAMPLE>(p, cw.stream) : launch_wgrad<3, 1, IN_UPSAMPLE, DY_PLAIN>(p, cw.stream);
         if (rc) return rc;
     }
     ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cout + cv.cin / 4.0));
     if (sv.w % 4 == 0 && cv.cin == kNew && cv.cout == kNew) {
         // sub-pixel form on the low-resolution grid: the four stride-2 phases of dY are 4 x 48 pseudo input channels of a
-        // 3x3 convolution that uses 2x2 of its taps per phase (4/9 of the MACs); the weights go to the (idle) n-split scratch
-        float* wd = c.gradws + c.net->wg_scratch_off;
+        // 3x3 convolution that uses 2x2 of its taps per phase (4/9 of the MACs); the weights have their own scratch (the n-split scratch belongs to the side stream)
+        float* wd = c.gradws + c.net->tuw_scratch_off;
         tu_subpix_dgrad_weights_kernel<<<(16 * cv.cout * cv.cin + 255) / 256, 256, 0, c.stream>>>(c.params + cv.w, cv.cout, cv.cin, wd);
         ENDO_LAUNCH_CHECK();
         ConvParams p{};
@@ -816,6 +849,7 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     endo_net* net = new (std::nothrow) endo_net();
     if (!net) return ENDO_E_BADARG;
     net->n = n; net->h = h; net->w = w; net->groups = groups;
+    net->wstream = nullptr; net->ev_fork = nullptr; net->ev_join = nullptr;
     int64_t off = 0, sums = 0, pq = 0;
     for (int l = 0; l <= kLevels; ++l) {
         auto& lv = net->lv[l];
@@ -845,7 +879,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->scratch_off = align_up((acts + net->pq_floats) * 4, 256);
     net->scratch_bytes = tb.bn_width_total * 2 * 8;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
-    net->gradws_floats = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
+    net->tuw_scratch_off = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
+    net->gradws_floats = net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16);
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
@@ -855,7 +890,19 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
 
 extern "C" int endo_net_create(endo_net** out, int n, int h, int w) { return endo_net_create_grouped(out, n, h, w, 1); }
 
-extern "C" void endo_net_destroy(endo_net* net) { delete net; }
+extern "C" int endo_set_wgrad_overlap(int enable) {
+    const int old = g_wgrad_overlap;
+    g_wgrad_overlap = enable ? 1 : 0;
+    return old;
+}
+
+extern "C" void endo_net_destroy(endo_net* net) {
+    if (!net) return;
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->wstream) (void)hipStreamDestroy(net->wstream);
+    delete net;
+}
 extern "C" int64_t endo_net_param_floats(void) { return table().param_floats; }
 extern "C" int64_t endo_net_bn_floats(void) { return table().bn_floats; }
 extern "C" int64_t endo_net_tape_floats(const endo_net* net) { return !net ? 0 : (net->groups > 1 ? net->groups * net->gs : net->tape_floats); }
@@ -936,6 +983,11 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     if (!net || !params || !x || !tape || !grad_out || !grads || !gradws) return ENDO_E_BADARG;
     const Table& tb = table();
     Ctx c{net, params, nullptr, const_cast<float*>(tape), grads, gradws, training, static_cast<hipStream_t>(stream_)};
+    if (!net->wstream) {          // side stream of the weight gradients (see endo_net), created on first use on the caller's device
+        ENDO_CHECK(hipStreamCreateWithFlags(&net->wstream, hipStreamNonBlocking));
+        ENDO_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        ENDO_CHECK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+    }
     // zero the deferred-term tables and the BN reduction scratch
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(gradws + g * net->gs + net->pq_off, 0,
@@ -981,7 +1033,18 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         p.in_gs = net->n * p.in_ns;                 // the caller's image tensor
         p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
         p.dw = grads + tb.first.w;
-        ProfScope prof(kProfWgradOther, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * lv.plane * (3 + kFirst));
-        return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, c.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, c.stream);
+        Ctx cw;
+        rc = c.fork_wgrad(cw, 0);
+        if (rc) return rc;
+        {
+            ProfScope prof(kProfWgradOther, cw.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * lv.plane * (3 + kFirst));
+            rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, cw.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, cw.stream);
+            if (rc) return rc;
+        }
     }
+    if (net->wstream) {          // join: the caller's stream continues only after every weight gradient has landed
+        ENDO_CHECK(hipEventRecord(net->ev_join, net->wstream));
+        ENDO_CHECK(hipStreamWaitEvent(c.stream, net->ev_join, 0));
+    }
+    return 0;
 }

@@ -139,6 +139,10 @@ int endo_net_create(endo_net** out, int n, int h, int w);
  * endo_net_group_stride() floats (what endo_net_tape_floats / endo_net_gradws_floats return).  groups <= 4. */
 int endo_net_create_grouped(endo_net** out, int n, int h, int w, int groups);
 int endo_net_groups(const endo_net* net);
+/* endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient chain and joined
+ * before it returns.  0 puts them back in line on the caller's stream (clean per-kernel timings);
+ * returns the previous setting.  Process-wide. */
+int endo_set_wgrad_overlap(int enable);
 int64_t endo_net_group_stride(const endo_net* net);
 void endo_net_destroy(endo_net* net);
 int64_t endo_net_param_floats(void);                 /* 1 374 865 */
