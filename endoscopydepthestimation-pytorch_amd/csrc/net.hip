@@ -995,15 +995,22 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     int rc;
     {
         const auto& lv = net->lv[0];
-        ProfScope prof(kProfConvFinal, c.stream, 4.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (2 * 192 + 4));
+        {   // final conv weight / bias gradient: reads only grad_out and the tape, so it goes to the side stream first
+            Ctx cw;
+            rc = c.fork_wgrad(cw, 0);
+            if (rc) return rc;
+            int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
+            by = by < 1 ? 1 : (by > 16 ? 16 : by);
+            ProfScope prof(kProfConvFinal, cw.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (192 + 2));
+            final_bwd_weight_kernel<<<dim3(193, by, c.nt()), 256, 0, cw.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
+                                                                         static_cast<int>(lv.plane), 192, net->n, net->gs, grads + tb.final_.w,
+                                                                         grads + tb.final_.b);
+            ENDO_LAUNCH_CHECK();
+        }
+        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (192 + 2));
         int bx = static_cast<int>((lv.plane + 255) / 256);
         final_bwd_data_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
                                                                       lv.t * lv.plane, static_cast<int>(lv.plane), 192, net->n, net->gs);
-        int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
-        by = by < 1 ? 1 : (by > 16 ? 16 : by);
-        final_bwd_weight_kernel<<<dim3(193, by, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
-                                                                     static_cast<int>(lv.plane), 192, net->n, net->gs, grads + tb.final_.w,
-                                                                     grads + tb.final_.b);
         ENDO_LAUNCH_CHECK();
     }
     for (int i = kLevels - 1; i >= 0; --i) {
