@@ -546,6 +546,46 @@ def test_nonfinite_guard():
     assert torch.equal(before, model.flat_parameters())
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])
+def test_wgrad_overlap_is_transparent(shape):
+    """endo_net_bwd runs the weight gradients on a side stream, overlapped with the data-gradient chain.
+    With the overlap switched off the same kernels run in line on one stream; the gradients after one backward pass, and
+    the parameters after three training iterations, must agree to the noise of fp32 atomic accumulation order -- a race
+    between the streams (a weight gradient reading a buffer the chain is rewriting) would show up as an O(1) difference
+    in some tensor."""
+    n, h, w = shape
+    lib = ea._lib.load()
+    results = []
+    try:
+        for overlap in (1, 0):
+            lib.endo_set_wgrad_overlap(overlap)
+            _, model = make_model(57, positive_depth=True)
+            model.train()
+            opt = ea.optim.FusedClipSGD(model, lr=1.0e-3)
+            step = ea.train_step.TrainingStep(model, opt, h, w)
+            batch = to_dev(synthetic.make_batch(n, h, w, seed=71))
+            # one backward pass without the optimizer: raw gradients
+            loss, _, _, _ = step.losses(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = model.flat_gradients().clone()
+            for _ in range(3):
+                step(batch, lr=1.0e-3)
+            torch.cuda.synchronize()
+            results.append((grads, model.flat_parameters().clone()))
+    finally:
+        lib.endo_set_wgrad_overlap(1)
+    (g_on, p_on), (g_off, p_off) = results
+    assert torch.isfinite(g_on).all() and torch.isfinite(p_on).all()
+    assert_close(g_on, g_off, 2e-5, "gradients, overlap on vs off")
+    assert_close(p_on, p_off, 2e-5, "parameters after 3 iterations, overlap on vs off")
+    # per tensor, so that a small tensor cannot hide behind the largest one
+    for (nm, prm), o in zip(model.named_parameters(), model._offsets):
+        a, b = g_on[o:o + prm.numel()], g_off[o:o + prm.numel()]
+        scale = max(float(b.abs().max()), 1e-3 * float(g_off.abs().max()))
+        assert float((a - b).abs().max()) <= 1e-3 * scale, "gradient of %s differs between overlap on and off" % nm
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json config 2: N = 8, 256 x 320)
 # ---------------------------------------------------------------------------------------------
