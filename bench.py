@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """Headline benchmark: training frame-pairs/s of the full hot-path step (BASELINE.json metric) on
-synthetic 256 x 320 frame pairs, batch 8 per GPU, fp32 -- config 2 of BASELINE.json.
+synthetic frame pairs -- by default config 2 of BASELINE.json (configs[1]): 256 x 320, batch 8 per GPU, fp32.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--config 1|3|4]
+
+With N > 1 and no WORLD_SIZE in the environment the script starts N fresh rank processes itself
+(``python -m torch.distributed.run --nproc-per-node N ... bench.py``, before this process touches the GPU) and relays
+rank 0's JSON line; under torchrun it is one of the ranks.  It never prints an ``n_gpus`` it did not reach.
 
 A step = reference train.py:272-328 on the MI355X path: boundary masking, two FC-DenseNet57
 forwards, depth scaling, flow-from-depth, sparse-flow loss, depth warping, depth-consistency loss,
 loss.item(), backward, one gradient all-reduce (N > 1), fused clip_grad_norm_(10) + SGD(0.9).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
+--config selects the BASELINE.json workload by its index in ``configs``:
+    1   256 x 320, batch 8 per GPU, fp32                                   (default; the metric's configuration)
+    3   512 x 640, batch 4 per GPU, fp32
+    4   256 x 320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10 ("adjacent range 5-30");
+        fp32 storage (the fp16-storage half of configs[4] does not exist in this library)
+
 Extra objects on that line:
-  roofline      the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad: whichever took the most
-                time in the warm-up steps, where all three carry HIP events), algorithmic FLOPs / HIP-event time
-                of its launches measured live over the timed steps, on the launch stream; traffic = HBM bytes per
-                launch from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.py)
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference path) timed on this host's cores on
-                a bounded sample (batch-1 steps)
+  roofline             the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad: whichever took the most
+                       time in the warm-up steps, where all three carry HIP events), algorithmic FLOPs / HIP-event time
+                       of its launches measured live over the timed steps, on the launch stream; traffic = HBM bytes per
+                       launch from the rocprofv3 PMC passes committed under profiles/ (tools/pmc_traffic.py)
+  roofline_depth_warp  the second BASELINE metric (depth-warp fwd+bwd, both directions, + the consistency loss that
+                       consumes it): HBM bound; algorithmic bytes / HIP-event kernel time, and the host-inclusive ms/pair
+  cpu_baseline         the CPU oracle (oracle/, a port of the reference path) timed on this host's physical cores on a
+                       bounded sample of the same workload (the GPU batch size) and at batch 1
 """
 
 import argparse
@@ -24,20 +35,77 @@ import ctypes
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HEIGHT, WIDTH, BATCH = 256, 320, 8
 FP32_MFMA_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
 HBM_PEAK_GBS = 8000.0
-PAIR_GFLOP = 192.752                   # algorithmic conv work per frame pair (fwd+dgrad+wgrad)
+PAIR_GFLOP_256x320 = 192.752           # algorithmic conv work per frame pair (fwd+dgrad+wgrad)
 MFMA_FAMILIES = (0, 5, 6)              # conv3x3_dense_fwd, dgrad_dense, wgrad_dense (endo_hip.h prof families)
+FAMILY_GEOMETRY, FAMILY_LOSS = 10, 11
+
+CONFIGS = {
+    1: dict(height=256, width=320, batch=8, gap=None,
+            metric="train frame-pairs/sec at 256x320 bs=8",
+            workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
+                     "256x320, batch 8 per GPU, fp32 (BASELINE.json configs[1])"),
+    3: dict(height=512, width=640, batch=4, gap=None,
+            metric="train frame-pairs/sec at 512x640 bs=4",
+            workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
+                     "512x640, batch 4 per GPU, fp32 (BASELINE.json configs[3])"),
+    4: dict(height=256, width=320, batch=8, gap=(5, 30),
+            metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30",
+            workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, "
+                     "fp32 storage (BASELINE.json configs[4] without its fp16-storage half)"),
+}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N outside torchrun: N fresh rank processes (this process has not touched the GPU and never will).
+    Relays the children's output; the exit code is theirs."""
+    import torch
+    have = torch.cuda.device_count()          # counts devices without initialising HIP on this image
+    if have < args.gpus and not os.environ.get("ENDO_BENCH_SHARE_GPU"):
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible; refusing to report a smaller job as %d GPUs\n"
+                         % (args.gpus, have, args.gpus))
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    result = None
+    for ln in lines:
+        try:
+            obj = json.loads(ln)
+        except ValueError:
+            sys.stderr.write(ln + "\n")
+            continue
+        if isinstance(obj, dict) and "metric" in obj:
+            result = obj
+    if proc.returncode != 0 or result is None:
+        sys.stderr.write("bench.py: the %d-rank job failed (exit code %d)\n" % (args.gpus, proc.returncode))
+        return proc.returncode or 1
+    if result.get("n_gpus") != args.gpus:
+        sys.stderr.write("bench.py: asked for %d ranks, the job reports %r\n" % (args.gpus, result.get("n_gpus")))
+        return 1
+    print(json.dumps(result))
+    sys.stdout.flush()
+    return 0
 
 
 def prof_read(lib, family):
@@ -48,31 +116,81 @@ def prof_read(lib, family):
     return ms.value, cnt.value, fl.value, by.value
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The oracle's full training iteration on the host CPU, batch 1 at 256 x 320 (bounded sample)."""
+def host_cpu():
+    """(model string, physical cores this process may use, logical CPUs it may use)."""
+    model = "unknown"
+    cores = {}
+    try:
+        cpu = phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for line in fh.read().splitlines() + [""]:
+                if not line.strip():
+                    if cpu is not None:
+                        cores[cpu] = (phys, core if core is not None else cpu)
+                    cpu = phys = core = None
+                    continue
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "processor":
+                    cpu = int(val)
+                elif key == "model name":
+                    model = val
+                elif key == "physical id":
+                    phys = int(val)
+                elif key == "core id":
+                    core = int(val)
+    except (OSError, ValueError):
+        pass
+    try:
+        allowed = os.sched_getaffinity(0)
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    physical = len({cores[c] for c in allowed if c in cores}) or len(allowed)
+    return model, physical, len(allowed)
+
+
+def cpu_baseline(cfg):
+    """The oracle's full training iteration on the host CPU, a bounded sample: batch 1 at two thread
+    counts (all physical cores, and 32 -- oneDNN on a large shared host often runs slower on every core than on 32), then the
+    GPU workload's batch at the better of the two.  `value` is the workload-batch figure; `cores` the threads it used."""
+    import torch
     from oracle import network as onet, train_step as ostep      # checker / timed baseline only
     pkg = importlib.import_module("endoscopydepthestimation-pytorch_amd")
-    # oneDNN at batch 1 stops scaling (and oversubscribes badly on a shared 256-thread host) well
-    # before the full core count; 32 threads is what we actually use and report
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
-    state = onet.synthetic_state(10085)
-    momentum = {}
-    batch = pkg.synthetic.make_batch(1, HEIGHT, WIDTH, seed=0)
-    ostep.train_iteration(state, momentum, batch, 1.0e-3)            # warm-up
-    times = []
-    start = time.perf_counter()
-    while len(times) < 3 or (time.perf_counter() - start < seconds_budget and len(times) < 6):
+    model, physical, logical = host_cpu()
+    h, w = cfg["height"], cfg["width"]
+
+    def run(batch_size, threads, timed, give_up_after=None):
+        torch.set_num_threads(threads)
+        state = onet.synthetic_state(10085)
+        momentum = {}
+        batch = pkg.synthetic.make_batch(batch_size, h, w, seed=0, gap_scale=cfg["gap"])
         t0 = time.perf_counter()
-        ostep.train_iteration(state, momentum, batch, 1.0e-3)
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - start > 2.5 * seconds_budget:
-            break
-    times.sort()
-    median = times[len(times) // 2]
-    return {"value": 1.0 / median, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d full training iterations of the CPU oracle at batch 1, 256x320 (median; the GPU workload is batch 8)" % len(times),
-            "ms_per_step": median * 1e3}
+        ostep.train_iteration(state, momentum, batch, 1.0e-3)            # warm-up (primitive creation, page faults)
+        warm = time.perf_counter() - t0
+        times = []
+        if give_up_after is None or warm < give_up_after:
+            for _ in range(timed):
+                t0 = time.perf_counter()
+                ostep.train_iteration(state, momentum, batch, 1.0e-3)
+                times.append(time.perf_counter() - t0)
+        times.sort()
+        median = times[len(times) // 2] if times else warm
+        return {"value": batch_size / median, "unit": "frame-pairs/s", "batch": batch_size, "threads": threads,
+                "iterations": len(times), "ms_per_step": median * 1e3, "warmup_only": not times}
+
+    counts = sorted({min(physical, 32), physical})
+    sweep = [run(1, counts[0], 3)]
+    for threads in counts[1:]:
+        # a thread count whose warm-up alone takes 3x the best step so far is not going to win: one iteration is enough
+        sweep.append(run(1, threads, 2, give_up_after=3.0 * sweep[0]["ms_per_step"] / 1e3))
+    best = max(sweep, key=lambda r: r["value"])
+    full = run(cfg["batch"], best["threads"], 1 if best["ms_per_step"] * cfg["batch"] > 4000.0 else 2)
+    return {"value": full["value"], "unit": "frame-pairs/s", "cores": full["threads"], "kind": "port",
+            "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
+            "sample": "%d full training iteration(s) of the CPU oracle at batch %d, %dx%d (the GPU workload's batch) after 1 warm-up, "
+                      "%d torch threads = the faster of {32, all %d physical cores} at batch 1" % (
+                          max(full["iterations"], 1), cfg["batch"], h, w, full["threads"], physical),
+            "ms_per_step": full["ms_per_step"], "batch": cfg["batch"], "batch1_by_threads": sweep}
 
 
 def pmc_traffic(family):
@@ -80,7 +198,7 @@ def pmc_traffic(family):
     serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
     bench.py command).  None when there is no such file."""
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     for path in reversed(files):
         try:
             with open(path) as fh:
@@ -97,16 +215,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-family time table to stderr")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and env_world <= 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))          # before anything here touches the GPU
+    if env_world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, env_world))
 
+    import torch
+    cfg = CONFIGS[args.config]
+    height, width, batch_size = cfg["height"], cfg["width"], cfg["batch"]
+    pair_gflop = PAIR_GFLOP_256x320 * (height * width) / (256.0 * 320.0)
     pkg = importlib.import_module("endoscopydepthestimation-pytorch_amd")
     rank, world, local = pkg.distributed.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # ENDO_BENCH_SHARE_GPU=1 (with ENDO_DIST_BACKEND=gloo): every rank on GPU 0 -- a plumbing check of the multi-rank path
+    # on a one-GPU box (launcher, rendezvous, parameter broadcast, gradient all-reduce, non-finite consensus, rank-0 line);
+    # the line it prints is marked and is not a measurement
+    shared = bool(os.environ.get("ENDO_BENCH_SHARE_GPU")) and world > 1
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = pkg._lib.load()
@@ -117,8 +253,8 @@ def main():
     model = model.to(dev).train()
     optimizer = pkg.optim.FusedClipSGD(model, lr=1.0e-3, momentum=0.9, max_norm=10.0)
     scheduler = pkg.scheduler.CyclicLR(optimizer, base_lr=1.0e-4, max_lr=1.0e-3, step_size=2000)
-    step_fn = pkg.train_step.TrainingStep(model, optimizer, HEIGHT, WIDTH, sfl_weight=20.0, dcl_weight=0.1)
-    batch = {k: v.to(dev) for k, v in pkg.synthetic.make_batch(BATCH, HEIGHT, WIDTH, seed=rank).items()}
+    step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1)
+    batch = {k: v.to(dev) for k, v in pkg.synthetic.make_batch(batch_size, height, width, seed=rank, gap_scale=cfg["gap"]).items()}
 
     def barrier():
         if world > 1:
@@ -129,7 +265,7 @@ def main():
     # weight-gradient side stream switched OFF so that kernels run one at a time: that gives each family's stand-alone
     # duration ("roofline_serial") and names the dominant family.  The last warm-up step and the timed steps run the
     # product configuration -- weight gradients overlapped with the data-gradient chain -- with events only on the
-    # dominant family (two events per launch serialise neighbouring kernels; 88 launches of the other two families need
+    # dominant family (two events per launch serialise neighbouring kernels; the launches of the other two families need
     # not pay for it).  Under overlap a kernel shares the chip with its neighbour, so its duration in the timed region is
     # longer than stand-alone: `roofline` reports what the timed region measured, `roofline_serial` the stand-alone figure.
     all_mask = 0
@@ -165,20 +301,27 @@ def main():
         out = step_fn(batch)
         skipped += int(out["skipped"])
         it += 1
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0                             # this rank's own steps (before waiting for the others)
     barrier()
     elapsed = time.perf_counter() - t0
     fam = {f: prof_read(lib, f) for f in MFMA_FAMILIES}
     lib.endo_prof_enable(0)
+    per_rank = [batch_size * args.steps / own_elapsed]
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
+        mine = torch.tensor([per_rank[0]], device=dev, dtype=torch.float64)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(gathered, mine)
+        per_rank = [float(g) for g in gathered]
 
     # second metric of BASELINE.json: depth-warp (+ consistency loss) fwd+bwd, both directions
     warp = pkg.models.DepthWarpingLayer()
-    dcl = pkg.losses.NormalizedDistanceLoss(HEIGHT, WIDTH)
-    d1 = pkg.synthetic.smooth_depth(BATCH, HEIGHT, WIDTH, seed=1).to(dev).requires_grad_(True)
-    d2 = pkg.synthetic.smooth_depth(BATCH, HEIGHT, WIDTH, seed=2).to(dev).requires_grad_(True)
+    dcl = pkg.losses.NormalizedDistanceLoss(height, width)
+    d1 = pkg.synthetic.smooth_depth(batch_size, height, width, seed=1).to(dev).requires_grad_(True)
+    d2 = pkg.synthetic.smooth_depth(batch_size, height, width, seed=2).to(dev).requires_grad_(True)
 
     def warp_both():
         w21, i1 = warp([d1, d2, batch["boundaries"], batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
@@ -195,7 +338,17 @@ def main():
     for _ in range(reps):
         warp_both()
     torch.cuda.synchronize()
-    warp_ms_per_pair = (time.perf_counter() - tw) / reps / BATCH * 1e3
+    warp_ms_per_pair = (time.perf_counter() - tw) / reps / batch_size * 1e3
+    # kernel time of the same calls (HIP events on the launch stream around every geometry / loss entry point)
+    lib.endo_prof_enable((1 << FAMILY_GEOMETRY) | (1 << FAMILY_LOSS))
+    for _ in range(reps):
+        warp_both()
+    torch.cuda.synchronize()
+    geo = prof_read(lib, FAMILY_GEOMETRY)
+    los = prof_read(lib, FAMILY_LOSS)
+    lib.endo_prof_enable(0)
+    warp_kernel_ms = (geo[0] + los[0]) / reps
+    warp_bytes = (geo[3] + los[3]) / reps                              # algorithmic bytes of one warp_both() call (the library's own count)
 
     breakdown = None
     if args.breakdown and rank == 0:
@@ -213,19 +366,26 @@ def main():
         lib.endo_prof_enable(0)
         print(json.dumps({"family_breakdown_one_step": breakdown}), file=sys.stderr)
 
+    if world > 1:
+        torch.distributed.barrier()
     if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
         return
-    pairs = BATCH * world * args.steps
+    pairs = batch_size * world * args.steps
     if dominant is None:
         dominant = max(MFMA_FAMILIES, key=lambda f: fam[f][0])
     ms, cnt, fl, by = fam[dominant]
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
-    traffic, traffic_src = pmc_traffic(dom_name)          # bytes per step -> per launch with the launches counted here
+    traffic, traffic_src = (None, None)
+    if args.config == 1:
+        traffic, traffic_src = pmc_traffic(dom_name)      # bytes per step -> per launch with the launches counted here
     if traffic is not None and cnt:
         traffic = traffic / (cnt / args.steps)
+    warp_gbs = warp_bytes / warp_kernel_ms / 1e6 if warp_kernel_ms > 0 else 0.0
     result = {
-        "metric": "train frame-pairs/sec at 256x320 bs=8",
+        "metric": cfg["metric"],
         "value": pairs / elapsed,
         "unit": "frame-pairs/s",
         "n_gpus": world,
@@ -237,11 +397,14 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
-                               "256x320, batch 8 per GPU, fp32 (BASELINE.json configs[1])",
-                   "global_batch": BATCH * world, "height": HEIGHT, "width": WIDTH, "parallelism": "dp%d" % world},
+        "config": {"workload": cfg["workload"], "baseline_config_index": args.config,
+                   "global_batch": batch_size * world, "height": height, "width": width, "parallelism": "dp%d" % world},
+        "world": world,
+        "shared_gpu_plumbing_check_not_a_measurement": True if shared else None,
+        "collective_backend": torch.distributed.get_backend() if world > 1 else None,
+        "per_rank_pairs_per_s": per_rank,
         "skipped_steps": skipped,
-        "conv_roofline_frac_whole_step": (pairs / elapsed) * PAIR_GFLOP / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world),
+        "conv_roofline_frac_whole_step": (pairs / elapsed) * pair_gflop / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world),
         "depth_warp_fwd_bwd_ms_per_pair": warp_ms_per_pair,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
@@ -254,12 +417,21 @@ def main():
             "note": "stand-alone kernel durations: warm-up steps with the weight-gradient side stream off (endo_set_wgrad_overlap(0))",
             "kernel": dom_name, "achieved": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9,
             "frac": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9 / FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / serial_steps for f in MFMA_FAMILIES}},
+            "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / serial_steps for f in MFMA_FAMILIES},
+            "families_tflops": {lib.endo_prof_family_name(f).decode(): fam_warm[f][2] / fam_warm[f][0] / 1e9 for f in MFMA_FAMILIES}},
+        "roofline_depth_warp": {
+            "kernel": "depth_warp fwd+bwd (both directions) + depth-consistency loss fwd+bwd", "bound": "hbm",
+            "achieved": warp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp_gbs / HBM_PEAK_GBS, "traffic": None,
+            "algorithmic_bytes_per_pair": warp_bytes / batch_size, "kernel_ms_per_pair": warp_kernel_ms / batch_size,
+            "host_inclusive_ms_per_pair": warp_ms_per_pair,
+            "note": "latency/launch bound at this size: %.0f KB per launch" % (warp_bytes / max(geo[1] + los[1], 1) * reps / 1e3)},
     }
-    if not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline()
+    if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
+        result["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(result))
     sys.stdout.flush()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

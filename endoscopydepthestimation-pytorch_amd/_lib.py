@@ -49,6 +49,7 @@ SIGNATURES = {
     "endo_net_bn_offset": (_L, [_I, _I]),
     "endo_net_level_channels": (_I, [_I]),
     "endo_net_act_offset": (_L, [_P, _I]),
+    "endo_net_tape_offset": (_L, [_P, _I, _I]),
     "endo_net_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_net_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_sgd_clip_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),

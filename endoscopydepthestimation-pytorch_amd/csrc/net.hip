@@ -922,6 +922,21 @@ extern "C" int64_t endo_net_bn_offset(int bn_index, int which) {
 extern "C" int endo_net_level_channels(int level) { return (level < 0 || level > kLevels) ? -1 : level_channels(level); }
 extern "C" int64_t endo_net_act_offset(const endo_net* net, int level) { return (!net || level < 0 || level > kLevels) ? -1 : net->lv[level].act; }
 
+extern "C" int64_t endo_net_tape_offset(const endo_net* net, int what, int index) {
+    if (!net) return -1;
+    const Table& tb = table();
+    switch (what) {
+        case ENDO_TAPE_PRE: return net->pre_off;
+        case ENDO_TAPE_BN_SAVED:
+            if (index < 0 || index >= static_cast<int>(tb.bn_order.size())) return -1;
+            return net->saved_off + 2 * tb.bn_order[index]->saved;
+        case ENDO_TAPE_POOL:
+            if (index < 0 || index >= kLevels) return -1;
+            return net->idx_off[index];
+        default: return -1;
+    }
+}
+
 extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_running, const float* x, float* out, float* tape,
                             int training, void* stream_) {
     if (!net || !params || !bn_running || !x || !out || !tape) return ENDO_E_BADARG;

@@ -13,18 +13,24 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun)."""
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun).
+
+    backend: "nccl" (= RCCL on ROCm) or "gloo"; default from ENDO_DIST_BACKEND, else nccl when a GPU is visible.  The
+    environment defaults are set before the first HIP call of this function (the runtime reads them when it
+    initialises; ``torch.cuda.device_count()`` does not initialise it, ``is_available()`` / ``set_device`` do)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world <= 1:
         return 0, 1, 0
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC
     rank = int(os.environ["RANK"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend == "nccl":
+            backend = os.environ.get("ENDO_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() > 0 else "gloo")
+        if backend == "nccl":          # RCCL wants one device per rank, selected before the communicator is built
+            if local >= torch.cuda.device_count():
+                raise RuntimeError("LOCAL_RANK %d but only %d GPU(s) are visible" % (local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
@@ -71,6 +77,33 @@ def broadcast_buffers(flat_bn, src=0):
     if world_size() > 1:
         dist.broadcast(flat_bn, src=src)
     return flat_bn
+
+
+def sync_parameters(model, optimizer=None, src=0):
+    """Make every replica start from rank ``src``'s state: parameters, BN running statistics and (when the optimizer
+    already has one) the momentum buffer.  ``nn.DataParallel`` re-broadcasts the module on every forward (reference
+    train.py:197); persistent replicas need it once -- after construction, and after any rank-local change such as
+    loading a checkpoint on one rank.  TrainingStep calls it when the world has more than one rank."""
+    if world_size() <= 1:
+        return
+    dist.broadcast(model.flat_parameters(), src=src)
+    flat_bn = getattr(model, "_flat_bn", None)
+    if flat_bn is not None:
+        dist.broadcast(flat_bn, src=src)
+    nbt = getattr(model, "_nbt", None)
+    if nbt is not None:
+        dist.broadcast(nbt, src=src)
+    momentum = getattr(optimizer, "_momentum", None) if optimizer is not None else None
+    has = torch.tensor([1 if momentum is not None else 0], device=model.flat_parameters().device)
+    dist.all_reduce(has, op=dist.ReduceOp.MAX)
+    if int(has) > 0:
+        if momentum is None:
+            optimizer._ensure_state()
+            momentum = optimizer._momentum
+        dist.broadcast(momentum, src=src)
+        steps = torch.tensor([optimizer._steps], device=momentum.device)
+        dist.broadcast(steps, src=src)
+        optimizer._steps = int(steps)
 
 
 def mean_scalars(values):

@@ -107,6 +107,12 @@ class _NetFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("FCDenseNet57 on the MI355X path does not produce a gradient for its input image "
+                               "(the training path never needs one, reference train.py:272-277); detach the input")
+        if ctx.tape is None:
+            raise RuntimeError("FCDenseNet57: the forward tape of this call was released by its first backward pass; "
+                               "run the forward again (retain_graph=True is not supported for the network node)")
         (x,) = ctx.saved_tensors
         ctx.net._run_backward(x, ctx.tape, grad_out, ctx.training, ctx.groups)
         ctx.tape = None
@@ -252,8 +258,38 @@ class FCDenseNet(nn.Module):
             lib = _lib.load()
             for hnd, _, _ in self._handles.values():
                 lib.endo_net_destroy(hnd)
+            self._handles = {}
         except Exception:
             pass
+
+    # native handles, workspaces and the gradient views belong to ONE module object: a copy (copy.deepcopy for an EMA or
+    # best-model snapshot, pickling) starts without them and re-packs its own flat buffers
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for key in ("_handles", "_gradws"):
+            state[key] = {}
+        for key in ("_flat_grad", "_anchor"):
+            state[key] = None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._handles, self._gradws = {}, {}
+        self._flatten()
+
+    def __deepcopy__(self, memo):
+        import copy
+        clone = self.__class__.__new__(self.__class__)
+        memo[id(self)] = clone
+        state = self.__getstate__()
+        for key in ("_flat", "_flat_bn", "_nbt", "_params", "_bns", "_offsets"):
+            state.pop(key, None)          # rebuilt by _flatten from the copied parameter / buffer tensors
+        clone.__dict__.update(copy.deepcopy(state, memo))
+        clone._handles, clone._gradws = {}, {}
+        for p in clone.parameters():
+            p.grad = None
+        clone._flatten()
+        return clone
 
     def _run_forward(self, x, groups=1):
         lib = _lib.load()

@@ -58,6 +58,8 @@ class TrainingStep(object):
         self.sparse_flow_loss_function = losses.SparseMaskedL1Loss()
         self.depth_consistency_loss_function = losses.NormalizedDistanceLoss(height=height, width=width)
         self.bucket = distributed.GradientBucket(model.flat_gradients)
+        # persistent replicas must start from the same state (nn.DataParallel re-broadcasts on every forward, train.py:197)
+        distributed.sync_parameters(model, optimizer)
 
     def losses(self, batch):
         """Forward part: returns (loss, depth_consistency_loss, sparse_flow_loss, extras)."""

@@ -167,6 +167,19 @@ int endo_net_bwd(endo_net* net, const float* params, const float* x, const float
  * channel count of level buffer `level` (0..5) and its offset (floats) inside the tape */
 int endo_net_level_channels(int level);
 int64_t endo_net_act_offset(const endo_net* net, int level);
+/* more of the tape's layout, for tests that rebuild the activation pattern a forward pass took (which ReLU inputs were
+ * positive -- models.py:24, which pixel each 2x2 max-pool kept -- models.py:66, the sign under the final |.| --
+ * models.py:186) so that gradients can be compared against an exact evaluation on the SAME pattern:
+ *   ENDO_TAPE_PRE     (index ignored)        float offset of the final conv's pre-activation, n x 1 x H x W
+ *   ENDO_TAPE_BN_SAVED index = BN layer in module order (0..48): float offset of its (mean, rstd) pairs, 2 per channel
+ *   ENDO_TAPE_POOL    index = level 0..4:    BYTE offset of the argmax codes of that level's max-pool,
+ *                                            n x C x H/2 x W/2 bytes, code = 2 * (row & 1) + (col & 1)
+ * Offsets are inside one group's tape; group g of a grouped handle starts endo_net_group_stride() floats further.
+ * Returns -1 for a bad argument. */
+#define ENDO_TAPE_PRE 0
+#define ENDO_TAPE_BN_SAVED 1
+#define ENDO_TAPE_POOL 2
+int64_t endo_net_tape_offset(const endo_net* net, int what, int index);
 
 /* ---------------------------------------------------------------------------------------------
  * clip_grad_norm_(params, max_norm) + SGD(momentum) -- reference train.py:327-328, 202

@@ -121,43 +121,70 @@ def trainable_names():
     return [n for n, _, k in parameter_spec() if k in ("conv_w", "conv_b", "bn_w", "bn_b")]
 
 
-def _bn_relu(state, prefix, x, training):
+def _bn_relu(state, prefix, x, training, pattern=None):
     y = F.batch_norm(x, state[prefix + ".running_mean"], state[prefix + ".running_var"],
                      state[prefix + ".weight"], state[prefix + ".bias"],
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         state[prefix + ".num_batches_tracked"] += 1
+    if pattern is not None:
+        return y * pattern["relu::" + prefix].to(y.dtype)
     return F.relu(y)
 
 
-def _dense_block(state, prefix, x, training, keep_input):
+def _max_pool(x, prefix, pattern=None):
+    if pattern is None:
+        return F.max_pool2d(x, 2)
+    n, c, h, w = x.shape
+    windows = x.reshape(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+    return torch.gather(windows, 4, pattern["pool::" + prefix].long().unsqueeze(-1)).squeeze(-1)
+
+
+def _dense_block(state, prefix, x, training, keep_input, trace=None, pattern=None):
     new = []
     for j in range(LAYERS_PER_BLOCK):
         p = "%s.layers.%d" % (prefix, j)
-        a = _bn_relu(state, p + ".norm", x, training)
+        a = _bn_relu(state, p + ".norm", x, training, pattern)
         out = F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"], padding=1)
+        if trace is not None:
+            trace["conv::" + p] = out
         x = torch.cat([x, out], dim=1)
         new.append(out)
     return x if keep_input else torch.cat(new, dim=1)
 
 
-def forward(state, x, training=True, trace=None):
+def forward(state, x, training=True, trace=None, pattern=None):
     """FCDenseNet.forward (models.py:171-187).  ``state`` running buffers are updated in place in
-    training mode, exactly as nn.BatchNorm2d does.  ``trace`` (optional dict) receives the
-    intermediate maps: skip_L (down block L output), bott_in, bott_new, tu_L, upnew_L."""
+    training mode, exactly as nn.BatchNorm2d does.
+
+    ``pattern`` (optional dict) FIXES the network's discontinuous choices instead of deriving them from the values:
+    "relu::<bn module>" (bool, the inputs ReLU lets through), "pool::<transition down module>" (which of the 2x2 pixels
+    each max-pool keeps, 2 * row + col) and "sign" (the sign under the final |.|).  With the pattern another evaluation
+    took -- tests read it off the HIP forward pass -- the result is that evaluation's piecewise-linear branch of the
+    network, computed exactly: gradients can then be compared without the O(1) per-pixel differences a single flipped
+    ReLU bit makes between ANY two finite-precision runs.
+
+    ``trace`` (optional dict) receives the
+    intermediate maps: skip_L (down block L output), bott_in, bott_new, tu_L, upnew_L, and "conv::<module>" = the
+    output of every convolution (after the max-pool for a transition down), whose autograd gradient is the TOTAL
+    gradient of those maps -- what the HIP gradient workspace holds for the same channel planes."""
     out = F.conv2d(x, state["firstconv.weight"], state["firstconv.bias"], padding=1)
+    if trace is not None:
+        trace["conv::firstconv"] = out
     skips = []
     for i in range(LEVELS):
-        out = _dense_block(state, "denseBlocksDown.%d" % i, out, training, keep_input=True)
+        out = _dense_block(state, "denseBlocksDown.%d" % i, out, training, keep_input=True, trace=trace, pattern=pattern)
         skips.append(out)
         if trace is not None:
             trace["skip_%d" % i] = out
         p = "transDownBlocks.%d" % i
-        a = _bn_relu(state, p + ".norm", out, training)
-        out = F.max_pool2d(F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"]), 2)
+        a = _bn_relu(state, p + ".norm", out, training, pattern)
+        out = _max_pool(F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"]), p, pattern)
+        if trace is not None:
+            trace["conv::" + p] = out
     if trace is not None:
         trace["bott_in"] = out
-    out = _dense_block(state, "bottleneck.bottleneck", out, training, keep_input=False)
+    out = _dense_block(state, "bottleneck.bottleneck", out, training, keep_input=False, trace=trace, pattern=pattern)
     if trace is not None:
         trace["bott_new"] = out
     for i in range(LEVELS):
@@ -170,11 +197,16 @@ def forward(state, x, training=True, trace=None):
         up = up[:, :, dy:dy + skip.shape[2], dx:dx + skip.shape[3]]
         if trace is not None:
             trace["tu_%d" % (LEVELS - 1 - i)] = up
+            trace["conv::transUpBlocks.%d" % i] = up
         out = torch.cat([up, skip], dim=1)
-        out = _dense_block(state, "denseBlocksUp.%d" % i, out, training, keep_input=(i == LEVELS - 1))
+        out = _dense_block(state, "denseBlocksUp.%d" % i, out, training, keep_input=(i == LEVELS - 1), trace=trace,
+                           pattern=pattern)
         if trace is not None:
             trace["upnew_%d" % (LEVELS - 1 - i)] = out[:, -GROWTH * LAYERS_PER_BLOCK:]
-    return torch.abs(F.conv2d(out, state["finalConv.weight"], state["finalConv.bias"]))
+    pre = F.conv2d(out, state["finalConv.weight"], state["finalConv.bias"])
+    if pattern is not None:
+        return pre * pattern["sign"].to(pre.dtype)
+    return torch.abs(pre)
 
 
 def conv_macs(height, width):

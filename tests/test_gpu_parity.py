@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import geometry as ogeo, losses as olos, network as onet, schedule as osch, train_step as ostep
+from device_pattern import pattern_of
 
 pytestmark = pytest.mark.gpu
 
@@ -291,14 +292,35 @@ def test_network_forward_levels(shape):
                     "eval-mode output")
 
 
-def reference_grads(state, x, cot, dtype):
+def reference_grads(state, x, cot, dtype, pattern=None):
+    """Oracle parameter gradients; with ``pattern`` on the piecewise-linear branch a HIP forward pass took (device_pattern.py)."""
     st = state_as(state, dtype)
     names = onet.trainable_names()
     for nm in names:
         st[nm].requires_grad_(True)
-    y = onet.forward(st, x.to(dtype), training=True)
+    y = onet.forward(st, x.to(dtype), training=True, pattern=pattern)
     grads = torch.autograd.grad((y * cot.to(dtype)).sum(), [st[nm] for nm in names])
     return dict(zip(names, grads))
+
+
+def assert_grads_on_pattern(params, g64, g32, tol, what):
+    """Every parameter gradient against the fp64 oracle evaluated on the HIP pass's own activation pattern: max abs error
+    <= tol x the tensor's scale.  g32 (the fp32 CPU oracle on the same pattern) is only reported, to show where plain fp32
+    rounding sits."""
+    report = []
+    for nm in onet.trainable_names():
+        got = params[nm].grad
+        assert got is not None, nm
+        scale = grad_scale(g64, nm)
+        e_hip = float((got.detach().double().cpu() - g64[nm]).abs().max()) / scale
+        e_cpu = float((g32[nm].double() - g64[nm]).abs().max()) / scale if g32 is not None else float("nan")
+        report.append((e_hip, e_cpu, nm))
+    report.sort(reverse=True)
+    print("%s: worst gradient errors on the shared pattern (hip-vs-fp64, cpu32-vs-fp64):" % what,
+          ["%.2e %.2e %s" % r for r in report[:5]])
+    bad = [r for r in report if not r[0] <= tol]
+    assert not bad, "%s: %d tensors over %.1e: %s" % (what, len(bad), tol, ["%.2e %s" % (r[0], r[2]) for r in bad[:8]])
+    return report
 
 
 def grad_scale(ref64, name):
@@ -311,39 +333,71 @@ def grad_scale(ref64, name):
     return max(own, 1e-30)
 
 
+GRAD_TOL = 3e-5          # every parameter gradient: max abs error / the tensor's max, against the fp64 oracle on the HIP pass's
+                         # own activation pattern.  Measured: <= 1.0e-5 on every tensor at every size below, 1.0-2x the fp32 CPU
+                         # oracle's own distance from fp64 on the same pattern; BASELINE.json's bar is 1e-4.
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160)])
 def test_network_backward(shape):
-    """All 210 parameter gradients against the fp64 oracle, judged against the fp32 CPU oracle's own
-    distance from it (see noise_aware): one flipped ReLU-mask bit at a pixel with z ~ 0 is an O(1)
-    change of that pixel's gradient and spreads through every earlier layer, for any fp32 path."""
+    """All 210 parameter gradients against the fp64 oracle at 1e-4 -- evaluated on the activation pattern the HIP forward
+    pass itself took (device_pattern.py).  Without that, the comparison is a lottery: any two finite-precision runs of a
+    ReLU network disagree on the few mask bits whose pre-activation lies within rounding of zero, each an O(1) change of
+    that pixel's gradient (tests/diag/gpu_diag7.py found exactly the three borderline elements behind round 1's
+    "8x noisier" late-layer gradient).  The unconstrained comparison is kept below as a statistic with the round-1 bound."""
     n, h, w = shape
     state, model = make_model(52)
     rng = np.random.default_rng(6)
     x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
     cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
-    g32 = reference_grads(state, x, cot, torch.float32)
-    g64 = reference_grads(state, x, cot, torch.float64)
     model.train()
     y = model(x.to(dev()))
+    (pattern,) = pattern_of(y, model, n, h, w)
     (y * cot.to(dev())).sum().backward()
     params = dict(model.named_parameters())
-    report = []
-    for nm in onet.trainable_names():
-        got = params[nm].grad
-        assert got is not None, nm
-        # gradients: factor 6 / floor 2e-4 (the 1e-4 of north_star is stated for loss and depth)
-        e_hip, e_cpu = noise_aware(got, g32[nm], g64[nm], "grad " + nm, floor=2e-4, factor=6.0, scale=grad_scale(g64, nm))
-        report.append((e_hip, e_cpu, nm))
-    report.sort(reverse=True)
-    print("worst gradient errors (hip-vs-fp64, cpu32-vs-fp64):", report[:5])
-    flat64 = torch.cat([g64[nm].reshape(-1) for nm in onet.trainable_names()])
-    flat32 = torch.cat([g32[nm].reshape(-1) for nm in onet.trainable_names()])
+    g64p = reference_grads(state, x, cot, torch.float64, pattern)
+    g32p = reference_grads(state, x, cot, torch.float32, pattern)
+    assert_grads_on_pattern(params, g64p, g32p, GRAD_TOL, "network backward %s" % (shape,))
+    flat64 = torch.cat([g64p[nm].reshape(-1) for nm in onet.trainable_names()])
     first = model.flat_gradients().clone()
-    noise_aware(first, flat32, flat64, "flat gradient vector")
+    assert_close(first, flat64, GRAD_TOL, "flat gradient vector")
+    # how many bits of the pattern differ from the fp64 oracle's own: a handful (the lottery the pattern removes)
+    trace = {}
+    own = reference_pattern(state_as(state, torch.float64), x.double())
+    flips = sum(int((own[k] != pattern[k]).sum()) for k in pattern if k.startswith("relu::"))
+    total = sum(pattern[k].numel() for k in pattern if k.startswith("relu::"))
+    print("ReLU bits that differ between the HIP pass and the fp64 oracle: %d of %d" % (flips, total))
+    assert flips <= 1e-5 * total
+    # the unconstrained comparison, as a statistic (round-1 criterion, factor 4 again)
+    g32 = reference_grads(state, x, cot, torch.float32)
+    g64 = reference_grads(state, x, cot, torch.float64)
+    flat32 = torch.cat([g32[nm].reshape(-1) for nm in onet.trainable_names()])
+    flat64u = torch.cat([g64[nm].reshape(-1) for nm in onet.trainable_names()])
+    noise_aware(first, flat32, flat64u, "flat gradient vector, own patterns", factor=4.0)
     # two backward passes accumulate (train.py:276-277 runs the network twice per step)
     y = model(x.to(dev()))
     (y * cot.to(dev())).sum().backward()
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
+
+
+def reference_pattern(state64, x64):
+    """The fp64 oracle's own ReLU pattern (for counting how many bits a HIP pass flips)."""
+    import torch.nn.functional as F
+    own = {}
+    plain = onet._bn_relu
+
+    def recording(state, prefix, xx, training, pattern=None):
+        yy = F.batch_norm(xx, state[prefix + ".running_mean"].clone(), state[prefix + ".running_var"].clone(),
+                          state[prefix + ".weight"], state[prefix + ".bias"], training, onet.BN_MOMENTUM, onet.BN_EPS)
+        own["relu::" + prefix] = yy > 0
+        return plain(state, prefix, xx, training, pattern)
+    onet._bn_relu = recording
+    try:
+        with torch.no_grad():
+            onet.forward(state64, x64, training=True)
+    finally:
+        onet._bn_relu = plain
+    return own
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160), (3, 64, 64)])
@@ -366,10 +420,6 @@ def test_forward_pair_is_two_calls(shape):
     st64 = state_as(state, torch.float64)
     y32 = [onet.forward(st32, x1, training=True), onet.forward(st32, x2, training=True)]
     y64 = [onet.forward(st64, x1.double(), training=True), onet.forward(st64, x2.double(), training=True)]
-    g32a, g32b = reference_grads(state, x1, cot1, torch.float32), reference_grads(state, x2, cot2, torch.float32)
-    g64a, g64b = reference_grads(state, x1, cot1, torch.float64), reference_grads(state, x2, cot2, torch.float64)
-    g32 = {nm: g32a[nm] + g32b[nm] for nm in names}
-    g64 = {nm: g64a[nm] + g64b[nm] for nm in names}
 
     _, twin = make_model(61)                   # same weights: the two-call path of the library itself
     twin.train()
@@ -379,6 +429,7 @@ def test_forward_pair_is_two_calls(shape):
     model.train()
     y1, y2 = model.forward_pair(x1.to(dev()), x2.to(dev()))
     assert y1.shape == (n, 1, h, w) and y2.shape == (n, 1, h, w)
+    pat1, pat2 = pattern_of(y1, model, n, h, w, groups=2)          # each frame's own activation pattern (its own BN statistics)
     ((y1 * cot1.to(dev())).sum() + (y2 * cot2.to(dev())).sum()).backward()
     noise_aware(y1, y32[0], y64[0], "pair output 1")
     noise_aware(y2, y32[1], y64[1], "pair output 2")
@@ -392,9 +443,12 @@ def test_forward_pair_is_two_calls(shape):
             assert_close(sd[name + stat], sd_twin[name + stat], 1e-5, name + stat + " vs separate calls")
         assert int(sd[name + ".num_batches_tracked"]) == 2
     params = dict(model.named_parameters())
-    for nm in names:
-        # the sum of two passes carries the mask-flip noise of both: floor and factor are twice those of test_network_backward's
-        noise_aware(params[nm].grad, g32[nm], g64[nm], "pair grad " + nm, floor=4e-4, factor=12.0, scale=grad_scale(g64, nm))
+    # summed parameter gradients of the two frames against the fp64 oracle on the two patterns the grouped pass took
+    g64a, g64b = reference_grads(state, x1, cot1, torch.float64, pat1), reference_grads(state, x2, cot2, torch.float64, pat2)
+    g32a, g32b = reference_grads(state, x1, cot1, torch.float32, pat1), reference_grads(state, x2, cot2, torch.float32, pat2)
+    g64 = {nm: g64a[nm] + g64b[nm] for nm in names}
+    g32 = {nm: g32a[nm] + g32b[nm] for nm in names}
+    assert_grads_on_pattern(params, g64, g32, GRAD_TOL, "pair backward %s" % (shape,))
     model.eval()
     twin.eval()
     with torch.no_grad():
@@ -584,6 +638,150 @@ def test_wgrad_overlap_is_transparent(shape):
         a, b = g_on[o:o + prm.numel()], g_off[o:o + prm.numel()]
         scale = max(float(b.abs().max()), 1e-3 * float(g_off.abs().max()))
         assert float((a - b).abs().max()) <= 1e-3 * scale, "gradient of %s differs between overlap on and off" % nm
+
+
+# ---------------------------------------------------------------------------------------------
+# the benchmark configuration itself (BASELINE.json configs[1]: N = 8, 256 x 320, grouped pair forward) against the
+# fixture the REFERENCE produced at that size
+# ---------------------------------------------------------------------------------------------
+def test_train_step_full_size_golden(golden):
+    """One training iteration at the size and through the code path bench.py times -- TrainingStep(pair_forward=True):
+    16 samples per launch, the 32x16 / split-K / n-split / 8-wave fused-dgrad variants that only these grids select --
+    against tests/golden/train_step_8x256x320.npz, which make_golden.py wrote by running the reference's own modules,
+    torch.optim.SGD and clip_grad_norm_ on the same seeded batch (reference train.py:272-328).
+
+    Forward (loss terms, depth, scaled depth, warped depth, BN running statistics): 1e-4 relative, BASELINE.json's bar
+    (measured 1e-7 on the losses, 8e-7 on the depth).
+    Gradients: a fixture cannot carry the activation pattern of a 2 x 8 x 256 x 320 pass (2 G mask bits), so here the HIP
+    gradient and the reference's fp32 gradient are two evaluations on slightly different patterns, and the fixture's fp64
+    evaluation (a third) is the yardstick: the reference's own fp32 gradients sit up to 2.6e-3 (elementwise) / 4.4e-3
+    (projection) from fp64, the coarse levels worst, where one flipped ReLU bit is one of only 1280 pixels of a channel.
+    Bounds: per tensor, norm / seeded random projection (sees every element) / the 23 tensors kept in full within 1e-2 of
+    the tensor's scale from fp64; over all tensors, the median distance within 3x the reference's median.  The TIGHT
+    statement about these kernel variants is test_full_size_pair_backward_on_pattern below (same grids, same pattern,
+    1e-4 on every tensor)."""
+    g = golden("train_step_8x256x320.npz")
+    n, h, w, seed, sub = (int(g[k]) for k in ("n", "h", "w", "seed", "subsample"))
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(seed), seed + 1), bias=float(g["final_bias_shift"]))
+    model = ea.FCDenseNet57(1)
+    model.load_state_dict(state)
+    model = model.to(dev()).train()
+    opt = ea.optim.FusedClipSGD(model, lr=float(g["lr"]))
+    step = ea.train_step.TrainingStep(model, opt, h, w, sfl_weight=float(g["sfl_weight"]), dcl_weight=float(g["dcl_weight"]),
+                                      pair_forward=True)
+    assert step.pair_forward
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=seed + 10, sparse_points=500))
+    loss, dcl, sfl, ex = step.losses(batch)
+    problems = []
+
+    def check(ok, msg):
+        if not ok:
+            problems.append(msg)
+
+    for key, val in (("loss", loss), ("dcl", dcl), ("sfl", sfl)):
+        err = abs(float(val) - float(g[key])) / abs(float(g[key]))
+        print("%-5s hip %.8f  reference %.8f  fp64 oracle %.8f  rel %.2e" % (key, float(val), float(g[key]), float(g["o64_" + key]), err))
+        check(err <= 1e-4, "%s: rel err %.3e > 1e-4" % (key, err))
+    for key in ("pred_1", "pred_2", "scaled_1", "warped_21"):
+        full = ex[key].detach()
+        got = full[:, :, ::sub, ::sub].cpu()
+        err = rel_err(got, torch.from_numpy(g[key]))
+        check(err <= 1e-4, "%s (every %dth pixel): %.3e > 1e-4" % (key, sub, err))
+        s_err = abs(float(full.double().sum()) - float(g[key + "_sum"])) / float(g[key + "_abs"])
+        check(s_err <= 1e-5, "%s plane sum: %.3e > 1e-5 of the absolute sum" % (key, s_err))
+        print("%-10s max rel err %.2e  sum rel err %.2e" % (key, err, s_err))
+    opt.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [str(s) for s in g["grad_names"]]
+    params = dict(model.named_parameters())
+    assert [nm for nm, _ in model.named_parameters()] == names
+    n32, n64, p32, p64 = g["grad_norms"], g["o64_grad_norms"], g["grad_probes"], g["o64_grad_probes"]
+    top = float(n64.max())
+    report = []
+    for i, nm in enumerate(names):
+        got = params[nm].grad.detach().double().cpu().reshape(-1)
+        if n64[i] <= 1e-7 * top:
+            # a conv bias in front of training-mode BNs only: the true gradient is exactly zero, fp32 leaves rounding noise
+            # (the reference's own value is ~1e-5 of the weight gradient); judged on the scale of its weight (listed just before)
+            check(float(got.norm()) <= 1e-4 * n64[i - 1], "grad %s: |g| = %.3e, expected ~0 (weight gradient norm %.3e)" % (nm, float(got.norm()), n64[i - 1]))
+            continue
+        scale = float(n64[i])
+        e_norm = abs(float(got.norm()) - n64[i]) / scale
+        r_norm = abs(n32[i] - n64[i]) / scale
+        probe = np.random.default_rng(seed * 1000 + i).standard_normal(got.numel())
+        e_probe = abs(float((got.numpy() * probe).sum()) - p64[i]) / scale
+        r_probe = abs(p32[i] - p64[i]) / scale
+        report.append((max(e_norm, e_probe), nm, e_norm, r_norm, e_probe, r_probe))
+        check(e_norm <= 1e-2, "grad norm %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_norm, r_norm))
+        check(e_probe <= 1e-2, "grad projection %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_probe, r_probe))
+    med = [float(np.median([r[k] for r in report])) for k in (2, 3, 4, 5)]
+    print("median over %d tensors: norm err hip %.2e / reference %.2e, projection err hip %.2e / reference %.2e" % (len(report), *med))
+    check(med[0] <= max(3.0 * med[1], 1e-4), "median gradient-norm distance from fp64: hip %.3e, reference %.3e" % (med[0], med[1]))
+    check(med[2] <= max(3.0 * med[3], 1e-4), "median gradient-projection distance from fp64: hip %.3e, reference %.3e" % (med[2], med[3]))
+    report.sort(reverse=True)
+    print("worst gradient tensors (name, norm err hip / ref32, projection err hip / ref32):")
+    for row in report[:8]:
+        print("   %-46s %.2e %.2e %.2e %.2e" % row[1:])
+    for nm in (str(s) for s in g["keep"]):
+        r32, r64 = torch.from_numpy(g["grad::" + nm]).double(), torch.from_numpy(g["o64_grad::" + nm]).double()
+        scale = max(float(r64.abs().max()), 1e-30)
+        e = float((params[nm].grad.detach().double().cpu() - r64).abs().max()) / scale
+        r = float((r32 - r64).abs().max()) / scale
+        print("   kept %-46s hip-vs-fp64 %.2e  reference-vs-fp64 %.2e" % (nm, e, r))
+        if not nm.endswith("conv.bias") and not nm.endswith("convTrans.1.bias"):
+            check(e <= 1e-2, "grad tensor %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e, r))
+    norm = opt.step()
+    e = abs(float(norm) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
+    r = abs(float(g["grad_norm"]) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
+    print("total gradient norm: hip %.6f reference %.6f fp64 %.6f" % (float(norm), float(g["grad_norm"]), float(g["o64_grad_norm"])))
+    check(e <= max(4.0 * r, 1e-4), "total gradient norm: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (e, r))
+    # parameters after clip_grad_norm_(10) + SGD: the update has norm lr * 10 = 1e-2 in total, so agreement of the
+    # per-tensor norms and sums to 2e-5 absolute pins the update to ~1e-3 of itself
+    norms = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
+    check(np.abs(norms - g["param_norms"]).max() <= 2e-5, "parameter norms after the step: %.3e" % np.abs(norms - g["param_norms"]).max())
+    check(np.abs(sums - g["param_sums"]).max() <= 2e-4, "parameter sums after the step: %.3e" % np.abs(sums - g["param_sums"]).max())
+    sd = model.state_dict()
+    for name in (str(s) for s in g["buffers"]):
+        for stat in (".running_mean", ".running_var"):
+            err = rel_err(sd[name + stat], torch.from_numpy(g["buf::" + name + stat]))
+            check(err <= 1e-4, "%s: %.3e > 1e-4" % (name + stat, err))
+        check(int(sd[name + ".num_batches_tracked"]) == 2, name + ".num_batches_tracked")
+    assert not problems, "\n".join(problems)
+
+
+def test_full_size_pair_backward_on_pattern():
+    """The grouped 2 x 8 x 256 x 320 pass bench.py times (forward_pair: 16 samples per launch -- the 32x16 forward tiles,
+    split-K coarse levels, n-split weight gradients and 8-wave fused data gradients that only these grids select), all 210
+    parameter gradients against the CPU oracle evaluated on the activation pattern the pass itself took
+    (device_pattern.py), frame by frame with each frame's own BatchNorm statistics.  The oracle runs in fp32 here (fp64 at
+    this size costs minutes and 40 GB): both sides then carry fp32 rounding, ~1e-5 each at the smaller sizes, and the bound
+    is BASELINE.json's 1e-4 on every tensor."""
+    n, h, w = 8, 256, 320
+    state, model = make_model(58)
+    rng = np.random.default_rng(14)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    model.train()
+    y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+    patterns = pattern_of(y1, model, n, h, w, groups=2)
+    ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names = onet.trainable_names()
+    total = None
+    for x, cot, pat, got in zip(xs, cots, patterns, (y1, y2)):
+        st = {k: v.clone() for k, v in state.items()}
+        for nm in names:
+            st[nm].requires_grad_(True)
+        y = onet.forward(st, x, training=True, pattern=pat)
+        assert_close(got, y.detach(), 1e-4, "depth of one frame of the pair vs the oracle on the same pattern")
+        grads = torch.autograd.grad((y * cot).sum(), [st[nm] for nm in names])
+        total = list(grads) if total is None else [a + b for a, b in zip(total, grads)]
+        del y, grads, st
+    ref = dict(zip(names, total))
+    assert_grads_on_pattern(params, ref, None, 1e-4, "full-size pair backward")
 
 
 # ---------------------------------------------------------------------------------------------
