@@ -23,6 +23,9 @@
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
 #include "wgrad_subpix_kernels.h"
+#include "wino_fwd_kernels.h"
+
+#include <cstdlib>
 
 namespace endo {
 
@@ -36,7 +39,7 @@ constexpr float kBnMomentum = 0.1f;
 constexpr int kSideStreamFromLevel = 0;      // weight gradients of levels >= this run on the side stream (in-job A/B: 0 -> -4.7 %, 1 -> -3 %, 2 -> -1.8 % step time)
 static int g_wgrad_overlap = 1;              // endo_set_wgrad_overlap: 0 = weight gradients in line on the caller's stream
 
-struct ConvP { int64_t w, b; int cout, cin, ks; };
+struct ConvP { int64_t w, b; int cout, cin, ks; int64_t u; };      // u: offset of the layer's Winograd-domain weights (dense layers), floats
 struct BnP { int64_t g, b; int c; int64_t run; int64_t saved; };   // run: offset in bn_running; saved: offset (pairs) in saved/scratch
 
 struct Table {
@@ -46,6 +49,8 @@ struct Table {
     std::vector<int64_t> param_offsets;   // 210 tensors in .parameters() order
     std::vector<BnP*> bn_order;           // 49 BN layers in module order
     int64_t param_floats = 0, bn_floats = 0, bn_width_total = 0;
+    WinoWeightTable wino;                 // the 44 dense layers' forward weights in Winograd form (wino_fwd_kernels.h)
+    int64_t wino_floats = 0;
 };
 
 inline int down_in(int level) { return kFirst + kNew * level; }          // C_L
@@ -56,7 +61,7 @@ static const Table& table() {
         Table* tb = new Table();
         int64_t off = 0;
         auto conv = [&](ConvP& c, int cout, int cin, int ks) {
-            c.cout = cout; c.cin = cin; c.ks = ks;
+            c.cout = cout; c.cin = cin; c.ks = ks; c.u = -1;
             c.w = off; tb->param_offsets.push_back(off); off += static_cast<int64_t>(cout) * cin * ks * ks;
             c.b = off; tb->param_offsets.push_back(off); off += cout;
         };
@@ -83,6 +88,22 @@ static const Table& table() {
         tb->param_floats = off;
         tb->bn_floats = run;
         tb->bn_width_total = saved;
+        {   // Winograd-domain weights of the dense layers: kWinoUStride floats per input channel, layer after layer
+            WinoWeightTable& wt = tb->wino;
+            wt.layers = 0; wt.start[0] = 0;
+            int64_t uoff = 0;
+            auto add = [&](ConvP& c) {
+                const int l = wt.layers++;
+                c.u = uoff;
+                wt.cin[l] = c.cin; wt.cout[l] = c.cout; wt.w_off[l] = c.w; wt.u_off[l] = uoff;
+                wt.start[l + 1] = wt.start[l] + c.cin * 16;
+                uoff += static_cast<int64_t>(c.cin) * kWinoUStride;
+            };
+            for (int l = 0; l < kLevels; ++l) for (int j = 0; j < kLayers; ++j) add(tb->down_conv[l][j]);
+            for (int j = 0; j < kLayers; ++j) add(tb->bott_conv[j]);
+            for (int i = 0; i < kLevels; ++i) for (int j = 0; j < kLayers; ++j) add(tb->up_conv[i][j]);
+            tb->wino_floats = uoff;
+        }
         return tb;
     }();
     return *t;
@@ -104,6 +125,7 @@ struct endo_net {
     int64_t sums_bytes;
     int64_t tape_floats;
     int64_t partial_off;   // split-K partial sums of the coarse-level dense layers (floats, tape)
+    int64_t wino_off;      // Winograd-domain forward weights of the dense layers (floats, tape; group 0's copy serves all groups)
     int64_t pq_off;        // floats, gradws: P then Q per level channel
     int64_t pq_floats;
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
@@ -462,6 +484,14 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
     return 2.0 * net->n * net->groups * net->lv[level].plane * cin * cout * ks * ks;
 }
 
+// ENDO_WINO_FWD=0 keeps the dense-layer forward on the direct convolution (A/B runs of the two forms inside one job)
+// (2 = 32 x 8 tiles at every eligible level)
+static int wino_fwd_mode() {
+    static const int mode = [] { const char* e = std::getenv("ENDO_WINO_FWD"); return e ? std::atoi(e) : 1; }();
+    return mode;
+}
+static bool wino_fwd_enabled() { return wino_fwd_mode() != 0; }
+
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
     const auto& lv = c.net->lv[level];
@@ -474,6 +504,18 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     p.out_sums = c.sums(level) + 2 * oc0;
     ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
+    // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
+    // 32 x 16 pixel tiles while they fill the chip several times over, 32 x 8 below that.
+    if (wino_fwd_enabled() && cv.u >= 0) {
+        ConvParams pw = p;
+        pw.wgt = c.tape + c.net->wino_off + cv.u;          // group 0's tape: weights are shared by the groups
+        const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
+        const long t8 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
+        if (wino_fwd_ok(pw)) {
+            if (t16 >= 1024 && wino_fwd_mode() != 2) return launch_wino_fwd<2, 4, 2>(pw, c.stream);
+            if (t8 >= 768) return launch_wino_fwd<1, 4, 3>(pw, c.stream);
+        }
+    }
     // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over
     // blockIdx.y, write raw partial sums, and let a small kernel add them up (+ bias, + BN statistics).
     // Scratch bound: slices * N * plane <= (768 / tiles + 1) * 128 * tiles <= 98304 + 65536 floats per channel.
@@ -873,6 +915,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     byte_off += align_up(net->sums_bytes, 256);
     net->partial_off = byte_off / 4;
     byte_off += static_cast<int64_t>(kGrowth) * 163840 * 4;     // bound: see dense_fwd
+    net->wino_off = byte_off / 4;
+    byte_off += align_up(tb.wino_floats * 4, 256);
     net->tape_floats = byte_off / 4;
     net->pq_off = acts;
     net->pq_floats = 2 * pq;
@@ -944,6 +988,11 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape + g * net->gs) + net->sums_off, 0, net->sums_bytes, c.stream));
+    if (wino_fwd_enabled()) {          // dense-layer weights in Winograd form, all 44 layers in one launch
+        ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * (tb.wino_floats + tb.wino_floats * 9 / 16));
+        wino_fwd_weights_kernel<<<(tb.wino.start[tb.wino.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino, params, tape + net->wino_off);
+        ENDO_LAUNCH_CHECK();
+    }
     int rc;
     {   // first conv 3 -> 48 into level-0 channels [48, 96)
         ConvParams p{};
