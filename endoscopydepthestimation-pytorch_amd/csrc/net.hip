@@ -512,8 +512,35 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
         const long t8 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
         if (wino_fwd_ok(pw)) {
-            if (t16 >= 1024 && wino_fwd_mode() != 2) return launch_wino_fwd<2, 4, 2>(pw, c.stream);
-            if (t8 >= 768) return launch_wino_fwd<1, 4, 3>(pw, c.stream);
+            const int mode = wino_fwd_mode();          // in-job A/B: 1 = 2 LDS stages (default), 3 = 3 stages, 4 = 4 stages
+            if (mode == 4) {
+                if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 4>(pw, c.stream);
+                if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 4>(pw, c.stream);
+            }
+            if (mode == 3) {
+                if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 3>(pw, c.stream);
+                if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 3>(pw, c.stream);
+            }
+#ifdef ENDO_WINO_DIAG          // stub-out timing variants of the level-0 kernel (wrong results): -DENDO_WINO_DIAG, ENDO_WINO_EXP=<mask>
+            if (t16 >= 1024) {
+                static const int exp = [] { const char* e = std::getenv("ENDO_WINO_EXP"); return e ? std::atoi(e) : 0; }();
+                switch (exp) {
+                    case 1: return launch_wino_fwd<2, 4, 2, 2, 1>(pw, c.stream);
+                    case 2: return launch_wino_fwd<2, 4, 2, 2, 2>(pw, c.stream);
+                    case 6: return launch_wino_fwd<2, 4, 2, 2, 6>(pw, c.stream);
+                    case 14: return launch_wino_fwd<2, 4, 2, 2, 14>(pw, c.stream);
+                    case 30: return launch_wino_fwd<2, 4, 2, 2, 30>(pw, c.stream);
+                    case 31: return launch_wino_fwd<2, 4, 2, 2, 31>(pw, c.stream);
+                    case 63: return launch_wino_fwd<2, 4, 2, 2, 63>(pw, c.stream);
+                    case 33: return launch_wino_fwd<2, 4, 2, 2, 33>(pw, c.stream);
+                    case 64: return launch_wino_fwd<2, 4, 2, 2, 64>(pw, c.stream);
+                    case 65: return launch_wino_fwd<2, 4, 2, 2, 65>(pw, c.stream);
+                    default: break;
+                }
+            }
+#endif
+            if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 2>(pw, c.stream);
+            if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 2>(pw, c.stream);
         }
     }
     // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over

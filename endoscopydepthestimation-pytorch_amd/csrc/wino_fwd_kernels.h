@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) wino_fwd_weights_kernel(const WinoWeightT
     }
 }
 
-template <int R, int KC>
+template <int R, int KC, int NS = 2>
 struct WinoFwdGeom {
     static constexpr int kTileX = 32;
     static constexpr int kTileY = 8 * R;                      // 4 waves x R tile rows x 2 pixel rows
@@ -91,18 +91,31 @@ struct WinoFwdGeom {
     static constexpr int kPos = (kUnits + kConvThreads - 1) / kConvThreads;
     static constexpr int kUUnits = KC * kWinoUStride / 4;
     static constexpr int kUPos = (kUUnits + kConvThreads - 1) / kConvThreads;
-    static constexpr int kBuf = KC * kCS + KC * kWinoUStride;          // floats per buffer
+    // one flat list of the chunk's DMA units (input tile of KC channels, then the U slice) dealt out round-robin: every wave
+    // issues kDma instructions per chunk, the last wave(s) one fewer when the final round does not reach them (kDmaMin), so
+    // "all but the newest k chunks have landed" is guaranteed by s_waitcnt vmcnt(k * kDmaMin) (loads retire in order)
+    static constexpr int kFlat = KC * kUnits + kUUnits;
+    static constexpr int kDma = (kFlat + kConvThreads - 1) / kConvThreads;
+    static constexpr int kDmaMin = (kFlat - (kDma - 1) * kConvThreads > 3 * 64) ? kDma : kDma - 1;
+    static_assert(kCS == 4 * kUnits, "a stage is one contiguous array of DMA units");
+    static constexpr int kBuf = KC * kCS + KC * kWinoUStride;          // floats per stage
     static constexpr int kTail = 4 * 16 * 2;                  // statistics scratch: [4 waves][16][2]
-    static size_t bytes(int bn_cap) { return sizeof(float) * (2 * kBuf + 3 * bn_cap + kTail); }
+    static size_t bytes(int bn_cap) { return sizeof(float) * (NS * kBuf + 3 * bn_cap + kTail); }
 };
 
 // p.wgt = this layer's U (kWinoUStride floats per input channel), p.cout <= 16, p.w % 4 == 0, 16-byte aligned planes.
-template <int R, int KC, int MINW>
+// NS: LDS stages.  The Winograd form does 4/9 of the arithmetic on the same input bytes, so a K-chunk's MFMAs (~0.5 us) no
+// longer cover the latency of the next chunk's DMA (~1.5 us): with two stages the kernel ran at 42 % MFMA utilisation and
+// 2 TB/s, bound by neither.  NS stages keep NS - 1 chunks in flight.
+// EXP: diagnostic bit mask (0 in the product; timing only, results are wrong): 1 = only the first NS - 1 chunks are DMA'd,
+// 2 = no BN + ReLU, 4 = no input transform, 8 = patch values are constants (no LDS reads), 16 = U values are constants,
+// 32 = no chunk barrier / DMA wait, 64 = no MFMAs
+template <int R, int KC, int MINW, int NS, int EXP = 0>
 __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const ConvParams p0) {
-    using G = WinoFwdGeom<R, KC>;
+    using G = WinoFwdGeom<R, KC, NS>;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* s_aux = smem + 2 * G::kBuf;
+    float* s_aux = smem + NS * G::kBuf;
     int grp, n;
     group_of(p0, blockIdx.z, grp, n);
     const ConvParams p = group_view(p0, grp);
@@ -136,54 +149,49 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) acc[r][xi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int goff[G::kPos];
-    unsigned pos_ok = 0;
+    // this thread's DMA units of a chunk (the same every chunk): a running source pointer per unit that advances by a fixed
+    // byte stride per chunk (KC input planes, KC rows of U, or 0 for a padding unit) -- two VALU per DMA and no scalar
+    // address arithmetic in the K loop.  p.cin % KC == 0 (wino_fwd_ok), so a chunk never needs a channel-range check.
+    const float* d_ptr[G::kDma];
+    unsigned d_stride[G::kDma];
+    {
+        const float* in_n = p.in + n * p.in_ns;
 #pragma unroll
-    for (int k = 0; k < G::kPos; ++k) {
-        const int e = tid + k * kConvThreads;
-        goff[k] = 0;
-        if (e < G::kUnits) {
-            const int ry = e / (G::kCols / 4);
-            const int rx = (e - ry * (G::kCols / 4)) * 4;
-            const int gy = y0 - 1 + ry;
-            const int gx = x0 - G::kLeft + rx;
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) { pos_ok |= (1u << k); goff[k] = gy * p.in_w + gx; }
+        for (int k = 0; k < G::kDma; ++k) {
+            const int e = tid + k * kConvThreads;
+            d_ptr[k] = g_pad_consts;          // NaN pad: out-of-image pixels of a BN+ReLU input
+            d_stride[k] = 0;
+            if (e < KC * G::kUnits) {
+                const int c = e / G::kUnits, u = e - c * G::kUnits;
+                const int ry = u / (G::kCols / 4);
+                const int rx = (u - ry * (G::kCols / 4)) * 4;
+                const int gy = y0 - 1 + ry;
+                const int gx = x0 - G::kLeft + rx;
+                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+                    d_ptr[k] = in_n + static_cast<int64_t>(c) * p.in_cs + gy * p.in_w + gx;
+                    d_stride[k] = static_cast<unsigned>(KC) * static_cast<unsigned>(p.in_cs) * 4u;
+                }
+            } else if (e < G::kFlat) {
+                d_ptr[k] = p.wgt + 4 * (e - KC * G::kUnits);
+                d_stride[k] = KC * kWinoUStride * 4u;
+            }
         }
     }
-    const float* in_n = p.in + n * p.in_ns;
-    const float* pad_nan = g_pad_consts;
-    const float* pad_zero = g_pad_consts + 4;
-    const int nchunks = (p.cin + KC - 1) / KC;
+    const int nchunks = p.cin / KC;
 
-    auto issue_dma = [&](int chunk, int buf) {
-        const int c_base = chunk * KC;
-        float* s_in = smem + buf * G::kBuf;
-        float* s_u = s_in + KC * G::kCS;
-#pragma unroll
-        for (int c = 0; c < KC; ++c) {
-            const int ch = c_base + c;
-            const float* plane = in_n + static_cast<int64_t>(ch) * p.in_cs;
-#pragma unroll
-            for (int k = 0; k < G::kPos; ++k) {
+    // chunks are issued in order, each exactly once: the pointers simply walk
+    auto issue_dma = [&](int buf) {
+        float* s_stage = smem + buf * G::kBuf + wave * 256;          // the wave's 64 units of round k land at 16 (256 k + 64 wave) bytes and up:
+#pragma unroll                                                    // a stage is one contiguous array of units in list order (kCS == 4 kUnits)
+        for (int k = 0; k < G::kDma; ++k) {
+            if (k + 1 < G::kDma) {          // full rounds: every lane of every wave has a unit
+                __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[k], (lptr_t)(s_stage + k * 4 * kConvThreads), 16, 0, 0);
+            } else {                        // last round: partially filled
                 const int e0 = k * kConvThreads + wave * 64;
-                if (e0 < G::kUnits) {
-                    const bool ok = (ch < p.cin) && (pos_ok & (1u << k));
-                    const float* src = ok ? plane + goff[k] : pad_nan;
-                    if (e0 + lane < G::kUnits)
-                        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_in + c * G::kCS + 4 * e0), 16, 0, 0);
-                }
+                if (e0 < G::kFlat && e0 + lane < G::kFlat)
+                    __builtin_amdgcn_global_load_lds((gptr_t)d_ptr[k], (lptr_t)(s_stage + k * 4 * kConvThreads), 16, 0, 0);
             }
-        }
-        const float* usrc = p.wgt + static_cast<int64_t>(c_base) * kWinoUStride;
-#pragma unroll
-        for (int k = 0; k < G::kUPos; ++k) {
-            const int u0 = k * kConvThreads + wave * 64;
-            if (u0 < G::kUUnits) {
-                const int u = u0 + lane;
-                const bool ok = c_base + u / (kWinoUStride / 4) < p.cin;
-                const float* src = ok ? usrc + 4 * u : pad_zero;
-                if (u < G::kUUnits) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_u + 4 * u0), 16, 0, 0);
-            }
+            d_ptr[k] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(d_ptr[k]) + d_stride[k]);
         }
     };
 
@@ -198,52 +206,76 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
             const float* b_base = s_u + (quad * 4 + lk) * kWinoUStride + li;
             float b[16];
 #pragma unroll
-            for (int xi = 0; xi < 16; ++xi) b[xi] = b_base[xi * 16];
+            for (int xi = 0; xi < 16; ++xi) b[xi] = (EXP & 16) ? static_cast<float>(xi + lane) : b_base[xi * 16];
+            // the lane's patch rows: LDS rows 2 t0 .. 2 t0 + 2R + 1 of its R tile rows (consecutive tile rows share two rows),
+            // LDS columns 2i+3 .. 2i+6: columns (1, 2) of the patch as one aligned 8-byte read, columns 0 and 3 as dword reads.
+            // BN + ReLU once per value; max(NaN, 0) = 0 turns the NaN pad into the zero padding of the post-activation tensor.
+            const float* a_base = s_in + (quad * 4 + lk) * G::kCS + (2 * wave * R) * G::kCols + 2 * li + 2;
+            f32x2 mid[2 * R + 2], end[2 * R + 2];
+#pragma unroll
+            for (int row = 0; row < 2 * R + 2; ++row) {
+                f32x2 m, e;
+                if constexpr ((EXP & 8) != 0) {
+                    m = f32x2{sc + row, mn + row}; e = f32x2{bt + row, sc - row};
+                } else {
+                    m = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 2);
+                    e = f32x2{a_base[row * G::kCols + 1], a_base[row * G::kCols + 4]};
+                }
+                if constexpr ((EXP & 2) == 0) {
+                    m = __builtin_elementwise_fma(m - mn2, sc2, bt2);
+                    e = __builtin_elementwise_fma(e - mn2, sc2, bt2);
+                    mid[row] = f32x2{__builtin_fmaxf(m[0], 0.f), __builtin_fmaxf(m[1], 0.f)};
+                    end[row] = f32x2{__builtin_fmaxf(e[0], 0.f), __builtin_fmaxf(e[1], 0.f)};
+                } else {
+                    mid[row] = m; end[row] = e;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                // the lane's 4x4 patch: LDS rows 2t .. 2t+3 of tile row t, LDS columns 2i+3 .. 2i+6, fetched as the three
-                // aligned pairs (2i+2, 2i+3) (2i+4, 2i+5) (2i+6, 2i+7): 16 lanes x 8 bytes are contiguous, no bank conflicts
-                const float* a_base = s_in + (quad * 4 + lk) * G::kCS + (2 * (wave * R + r)) * G::kCols + 2 * li + 2;
-                f32x2 d[4][2];          // [row][column pair]: columns (0,1) and (2,3) of the patch
+                // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3); then (.) B: columns (c0 - c2, c1 + c2, c2 - c1, c1 - c3)
+                f32x2 tm[4], te[4];
+                if constexpr ((EXP & 4) == 0) {
+                    tm[0] = mid[2 * r] - mid[2 * r + 2];     te[0] = end[2 * r] - end[2 * r + 2];
+                    tm[1] = mid[2 * r + 1] + mid[2 * r + 2]; te[1] = end[2 * r + 1] + end[2 * r + 2];
+                    tm[2] = mid[2 * r + 2] - mid[2 * r + 1]; te[2] = end[2 * r + 2] - end[2 * r + 1];
+                    tm[3] = mid[2 * r + 1] - mid[2 * r + 3]; te[3] = end[2 * r + 1] - end[2 * r + 3];
+                } else {
 #pragma unroll
-                for (int row = 0; row < 4; ++row) {
-                    const f32x2 q0 = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols);
-                    const f32x2 q1 = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 2);
-                    const f32x2 q2 = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 4);
-                    f32x2 lo = {q0[1], q1[0]}, hi = {q1[1], q2[0]};
-                    lo = __builtin_elementwise_fma(lo - mn2, sc2, bt2);
-                    hi = __builtin_elementwise_fma(hi - mn2, sc2, bt2);
-                    d[row][0] = f32x2{__builtin_fmaxf(lo[0], 0.f), __builtin_fmaxf(lo[1], 0.f)};
-                    d[row][1] = f32x2{__builtin_fmaxf(hi[0], 0.f), __builtin_fmaxf(hi[1], 0.f)};
+                    for (int a = 0; a < 4; ++a) { tm[a] = mid[2 * r + a]; te[a] = end[2 * r + a]; }
                 }
-                // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3), two columns per instruction
-                f32x2 t[4][2];
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    t[0][h] = d[0][h] - d[2][h];
-                    t[1][h] = d[1][h] + d[2][h];
-                    t[2][h] = d[2][h] - d[1][h];
-                    t[3][h] = d[1][h] - d[3][h];
-                }
-                // (.) B: columns (c0 - c2, c1 + c2, c2 - c1, c1 - c3)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const float c0 = t[a][0][0], c1 = t[a][0][1], c2 = t[a][1][0], c3 = t[a][1][1];
-                    acc[r][4 * a + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(c0 - c2, b[4 * a + 0], acc[r][4 * a + 0], 0, 0, 0);
-                    acc[r][4 * a + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1 + c2, b[4 * a + 1], acc[r][4 * a + 1], 0, 0, 0);
-                    acc[r][4 * a + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(c2 - c1, b[4 * a + 2], acc[r][4 * a + 2], 0, 0, 0);
-                    acc[r][4 * a + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(c1 - c3, b[4 * a + 3], acc[r][4 * a + 3], 0, 0, 0);
+                    const float c0 = te[a][0], c1 = tm[a][0], c2 = tm[a][1], c3 = te[a][1];
+                    float v0 = c0 - c2, v1 = c1 + c2, v2 = c2 - c1, v3 = c1 - c3;
+                    if constexpr ((EXP & 4) != 0) { v0 = c0; v1 = c1; v2 = c2; v3 = c3; }
+                    if constexpr ((EXP & 64) != 0) {
+                        acc[r][4 * a + 0][0] += v0 * b[4 * a]; acc[r][4 * a + 1][0] += v1 * b[4 * a + 1];
+                        acc[r][4 * a + 2][0] += v2 * b[4 * a + 2]; acc[r][4 * a + 3][0] += v3 * b[4 * a + 3];
+                    } else {
+                        acc[r][4 * a + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b[4 * a + 0], acc[r][4 * a + 0], 0, 0, 0);
+                        acc[r][4 * a + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, b[4 * a + 1], acc[r][4 * a + 1], 0, 0, 0);
+                        acc[r][4 * a + 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(v2, b[4 * a + 2], acc[r][4 * a + 2], 0, 0, 0);
+                        acc[r][4 * a + 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(v3, b[4 * a + 3], acc[r][4 * a + 3], 0, 0, 0);
+                    }
                 }
             }
         }
     };
 
-    issue_dma(0, 0);
+    // NS - 1 chunks in flight.  Every wave issues exactly kDma DMA instructions per chunk, so when chunk c is about to be
+    // consumed the newer chunks c + 1 .. c + NS - 2 may still be outstanding: vmcnt((NS - 2) * kDmaMin) (fewer near the end).
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nchunks) issue_dma(s0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const int b = chunk & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // own DMA of this chunk has landed
-        __syncthreads();                                          // everybody's has; the other buffer is free again
-        if (chunk + 1 < nchunks) issue_dma(chunk + 1, b ^ 1);
+        const int b = chunk % NS;
+        const int newer = min(nchunks - 1 - chunk, NS - 2);          // chunks issued after this one (block-uniform)
+        if ((EXP & 32) && chunk > 0) {}
+        else if (newer >= NS - 2 && NS > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * G::kDmaMin) : "memory");
+        else if (newer == 1 && NS > 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::kDmaMin) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!(EXP & 32) || chunk == 0) __syncthreads();           // everybody's chunk has landed; stage (chunk - 1) % NS is free again
+        if (chunk + NS - 1 < nchunks && !(EXP & 1)) issue_dma((chunk + NS - 1) % NS);
         compute(chunk, b);
     }
 
@@ -313,25 +345,27 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
 inline bool wino_fwd_ok(const ConvParams& p) {
     return p.cout <= 16 && (p.w % 4 == 0) && (p.in_w % 4 == 0) && (p.out_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
            (p.out_cs % 4 == 0) && (p.out_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.in) % 16 == 0) &&
-           (reinterpret_cast<uintptr_t>(p.out) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.wgt) % 16 == 0) && p.ksplit == 0;
+           (reinterpret_cast<uintptr_t>(p.out) % 16 == 0) && (reinterpret_cast<uintptr_t>(p.wgt) % 16 == 0) && p.ksplit == 0 &&
+           p.cin % 4 == 0 && p.cin >= 8;          // whole K-chunks only (dense layers: cin = 48 + 12 j)
 }
 
-template <int R, int KC, int MINW>
+template <int R, int KC, int MINW, int NS, int EXP = 0>
 inline int launch_wino_fwd(ConvParams p, hipStream_t stream) {
-    using G = WinoFwdGeom<R, KC>;
+    using G = WinoFwdGeom<R, KC, NS>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     const size_t smem = G::bytes(p.bn_cap);
     static size_t configured = 0;
     if (smem > 48 * 1024 && smem > configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fwd_kernel<R, KC, MINW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fwd_kernel<R, KC, MINW, NS, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(smem)));
         configured = smem;
     }
-    wino_fwd_kernel<R, KC, MINW><<<dim3(p.tiles_x * tiles_y, 1, p.n), kConvThreads, smem, stream>>>(p);
+    wino_fwd_kernel<R, KC, MINW, NS, EXP><<<dim3(p.tiles_x * tiles_y, 1, p.n), kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
+
 
 }  // namespace endo
