@@ -28,6 +28,8 @@ SIGNATURES = {
     "endo_flow_from_depth_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "endo_depth_warp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "endo_depth_warp_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "endo_depth_warp_fwd_tiled": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
+    "endo_depth_warp_bwd_tiled": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I, _I, _P]),
     "endo_sparse_l1_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "endo_sparse_l1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "endo_norm_dist_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),

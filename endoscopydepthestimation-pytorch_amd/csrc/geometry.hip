@@ -381,6 +381,232 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-staged depth warp.  A block owns a TY x TX tile of frame-1 pixels.  Every pixel's sample position is computed first;
+// the bounding box of the block's north-west taps (+1 for the south-east ones) is the SOURCE tile of frame 2 -- the output
+// tile displaced by the local flow, a few pixels larger where the flow shears or zooms.  When it fits the (TY + MY) x
+// (TX + MX) staging buffers, the block computes D = m (w2z + d2 m s) and keeps m ONCE per source pixel, with coalesced row
+// reads, and the four taps of every output pixel come from LDS: 2 coalesced loads per source pixel instead of 8 gathers per
+// output pixel.  Otherwise (large or divergent motion) the block takes the same arithmetic from global memory as
+// warp_fwd_kernel does.  Taps outside the image are staged as zeros, which is grid_sample's zeros padding; values and
+// summation order per pixel are those of the gather kernels, so the results are bit-identical to them.
+// Backward: the d2 gradient is accumulated in an LDS tile (ds_add_f32) and flushed with one global atomic per touched source
+// pixel instead of four per output pixel.
+// ------------------------------------------------------------------------------------------
+template <int TY, int TX>
+struct WarpTile {
+    static constexpr int kThreads = 256;
+    static constexpr int kPix = TY * TX / kThreads;          // pixels per thread
+    static constexpr int MY = 8, MX = 8;                     // margin of the source tile over the output tile
+    static constexpr int BH = TY + MY, BW = TX + MX;
+    static_assert(TY * TX % kThreads == 0 && TX % 32 == 0, "whole pixels per thread, rows of whole half-waves");
+};
+
+// bounding box of the valid taps of a block: min / max of x0, y0 over the pixels that have a tap in range
+__device__ __forceinline__ void block_tap_box(int minx, int miny, int maxx, int maxy, int* s_box, int& bx0, int& by0, int& bw, int& bh) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        minx = min(minx, __shfl_down(minx, off, 64)); miny = min(miny, __shfl_down(miny, off, 64));
+        maxx = max(maxx, __shfl_down(maxx, off, 64)); maxy = max(maxy, __shfl_down(maxy, off, 64));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_box[wave * 4] = minx; s_box[wave * 4 + 1] = miny; s_box[wave * 4 + 2] = maxx; s_box[wave * 4 + 3] = maxy; }
+    __syncthreads();
+    minx = min(min(s_box[0], s_box[4]), min(s_box[8], s_box[12]));
+    miny = min(min(s_box[1], s_box[5]), min(s_box[9], s_box[13]));
+    maxx = max(max(s_box[2], s_box[6]), max(s_box[10], s_box[14]));
+    maxy = max(max(s_box[3], s_box[7]), max(s_box[11], s_box[15]));
+    bx0 = minx; by0 = miny;
+    bw = maxx - minx + 2;          // + the east / south taps
+    bh = maxy - miny + 2;
+}
+
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) warp_fwd_tiled_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
+                                                             const float* __restrict__ mask, const float* __restrict__ t,
+                                                             const float* __restrict__ R, const float* __restrict__ K,
+                                                             float* __restrict__ warped, float* __restrict__ intersect,
+                                                             int h, int w, int tiles_x, float eps) {
+    using T = WarpTile<TY, TX>;
+    __shared__ Camera cam;
+    __shared__ int s_box[16];
+    __shared__ float s_d[T::BH * T::BW], s_m[T::BH * T::BW];
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int64_t base = static_cast<int64_t>(n) * h * w;
+    const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+    Taps tp[T::kPix];
+    float mpix[T::kPix];
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        tp[k].vw = tp[k].ve = tp[k].vn = tp[k].vs = false;
+        tp[k].x0 = tp[k].y0 = 0;
+        mpix[k] = 0.f;
+        if (yy < h && xx < w) {
+            float qx, qy, qz;
+            ray(cam, static_cast<float>(xx), static_cast<float>(yy), qx, qy, qz);
+            const float m = mask[base + static_cast<int64_t>(yy) * w + xx];
+            const float dm = d1[base + static_cast<int64_t>(yy) * w + xx] * m;
+            float zt = cam.w[2] + dm * qz;
+            zt = (m > 0.5f) ? zt : eps;
+            zt = (zt > 0.0f) ? zt : eps;
+            tp[k] = make_taps((cam.w[0] + dm * qx) / zt, (cam.w[1] + dm * qy) / zt, w, h);
+            mpix[k] = m;
+            if ((tp[k].vw || tp[k].ve) && (tp[k].vn || tp[k].vs)) {
+                minx = min(minx, tp[k].x0); maxx = max(maxx, tp[k].x0);
+                miny = min(miny, tp[k].y0); maxy = max(maxy, tp[k].y0);
+            }
+        }
+    }
+    int bx0, by0, bw, bh;
+    block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
+    const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;          // block-uniform; bw <= 0: no pixel of the block has a tap in range
+    if (staged) {
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const int ry = e / T::BW, rx = e - ry * T::BW;
+            const int sy = by0 + ry, sx = bx0 + rx;
+            float dv = 0.f, mv = 0.f, ss;
+            if (rx < bw && sy >= 0 && sy < h && sx >= 0 && sx < w) dv = depth_in_1(cam, d2, mask, base, w, sx, sy, &mv, &ss);
+            s_d[e] = dv; s_m[e] = mv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        if (yy >= h || xx >= w) continue;
+        const Taps& q = tp[k];
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f}, ss;
+        if (staged) {
+            const int o = (q.y0 - by0) * T::BW + (q.x0 - bx0);
+            if (q.vw && q.vn) { v[0] = s_d[o]; mm[0] = s_m[o]; }
+            if (q.ve && q.vn) { v[1] = s_d[o + 1]; mm[1] = s_m[o + 1]; }
+            if (q.vw && q.vs) { v[2] = s_d[o + T::BW]; mm[2] = s_m[o + T::BW]; }
+            if (q.ve && q.vs) { v[3] = s_d[o + T::BW + 1]; mm[3] = s_m[o + T::BW + 1]; }
+        } else {
+            if (q.vw && q.vn) v[0] = depth_in_1(cam, d2, mask, base, w, q.x0, q.y0, &mm[0], &ss);
+            if (q.ve && q.vn) v[1] = depth_in_1(cam, d2, mask, base, w, q.x0 + 1, q.y0, &mm[1], &ss);
+            if (q.vw && q.vs) v[2] = depth_in_1(cam, d2, mask, base, w, q.x0, q.y0 + 1, &mm[2], &ss);
+            if (q.ve && q.vs) v[3] = depth_in_1(cam, d2, mask, base, w, q.x0 + 1, q.y0 + 1, &mm[3], &ss);
+        }
+        float acc = q.wnw * v[0], macc = q.wnw * mm[0];
+        acc += q.wne * v[1]; macc += q.wne * mm[1];
+        acc += q.wsw * v[2]; macc += q.wsw * mm[2];
+        acc += q.wse * v[3]; macc += q.wse * mm[3];
+        const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
+        warped[o] = acc;
+        intersect[o] = (macc * mpix[k] >= 0.9f) ? 1.0f : 0.0f;
+    }
+}
+
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __restrict__ gw, const float* __restrict__ d1,
+                                                             const float* __restrict__ d2, const float* __restrict__ mask,
+                                                             const float* __restrict__ t, const float* __restrict__ R,
+                                                             const float* __restrict__ K, float* __restrict__ gd1, float* gd2,
+                                                             int h, int w, int tiles_x, float eps) {
+    using T = WarpTile<TY, TX>;
+    __shared__ Camera cam;
+    __shared__ int s_box[16];
+    __shared__ float s_d[T::BH * T::BW], s_m[T::BH * T::BW], s_g[T::BH * T::BW];
+    const int n = blockIdx.y;
+    load_camera(K, R, t, n, &cam);
+    const int64_t base = static_cast<int64_t>(n) * h * w;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    const int tx0 = (blockIdx.x % tiles_x) * TX, ty0 = (blockIdx.x / tiles_x) * TY;
+    Taps tp[T::kPix];
+    float qxs[T::kPix], qys[T::kPix], qzs[T::kPix], zts[T::kPix], nxs[T::kPix], nys[T::kPix], mpix[T::kPix];
+    bool opens[T::kPix];
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        tp[k].vw = tp[k].ve = tp[k].vn = tp[k].vs = false;
+        tp[k].x0 = tp[k].y0 = 0;
+        mpix[k] = 0.f; opens[k] = false;
+        qxs[k] = qys[k] = qzs[k] = nxs[k] = nys[k] = 0.f; zts[k] = 1.f;
+        if (yy < h && xx < w) {
+            ray(cam, static_cast<float>(xx), static_cast<float>(yy), qxs[k], qys[k], qzs[k]);
+            const float m = mask[base + static_cast<int64_t>(yy) * w + xx];
+            const float dm = d1[base + static_cast<int64_t>(yy) * w + xx] * m;
+            const float z2 = cam.w[2] + dm * qzs[k];
+            float zt = (m > 0.5f) ? z2 : eps;
+            opens[k] = (m > 0.5f) && (zt > 0.0f);
+            zt = (zt > 0.0f) ? zt : eps;
+            zts[k] = zt; mpix[k] = m;
+            nxs[k] = cam.w[0] + dm * qxs[k];
+            nys[k] = cam.w[1] + dm * qys[k];
+            tp[k] = make_taps(nxs[k] / zt, nys[k] / zt, w, h);
+            if ((tp[k].vw || tp[k].ve) && (tp[k].vn || tp[k].vs)) {
+                minx = min(minx, tp[k].x0); maxx = max(maxx, tp[k].x0);
+                miny = min(miny, tp[k].y0); maxy = max(maxy, tp[k].y0);
+            }
+        }
+    }
+    int bx0, by0, bw, bh;
+    block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
+    const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
+    if (staged) {
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const int ry = e / T::BW, rx = e - ry * T::BW;
+            const int sy = by0 + ry, sx = bx0 + rx;
+            float dv = 0.f, mv = 0.f, ss;
+            if (rx < bw && sy >= 0 && sy < h && sx >= 0 && sx < w) dv = depth_in_1(cam, d2, mask, base, w, sx, sy, &mv, &ss);
+            s_d[e] = dv; s_m[e] = mv; s_g[e] = 0.f;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        if (yy >= h || xx >= w) continue;
+        const Taps& q = tp[k];
+        const float g = gw[base + static_cast<int64_t>(yy) * w + xx];
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool val[4] = {q.vw && q.vn, q.ve && q.vn, q.vw && q.vs, q.ve && q.vs};
+        const float wt[4] = {q.wnw, q.wne, q.wsw, q.wse};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!val[c]) continue;
+            const int sx = q.x0 + (c & 1), sy = q.y0 + (c >> 1);
+            float mm, ss;
+            if (staged) {
+                const int o = (sy - by0) * T::BW + (sx - bx0);
+                v[c] = s_d[o]; mm = s_m[o];
+                ss = fmaf(cam.m2z[1], static_cast<float>(sy), cam.m2z[0] * static_cast<float>(sx)) + cam.m2z[2];
+                atomicAdd(&s_g[o], g * wt[c] * mm * ss * mm);
+            } else {
+                v[c] = depth_in_1(cam, d2, mask, base, w, sx, sy, &mm, &ss);
+                atomicAdd(gd2 + base + static_cast<int64_t>(sy) * w + sx, g * wt[c] * mm * ss * mm);
+            }
+        }
+        const float sfrac = 1.0f - q.fy, efrac = 1.0f - q.fx;
+        const float gix = ((v[1] - v[0]) * sfrac + (v[3] - v[2]) * q.fy) * g;
+        const float giy = ((v[2] - v[0]) * efrac + (v[3] - v[1]) * q.fx) * g;
+        const float gu = gix * (fw * 0.5f) * 2.0f / fw;
+        const float gv = giy * (fh * 0.5f) * 2.0f / fh;
+        float gdm = gu * qxs[k] / zts[k] + gv * qys[k] / zts[k];
+        if (opens[k]) gdm += -(gu * nxs[k] + gv * nys[k]) / (zts[k] * zts[k]) * qzs[k];
+        gd1[base + static_cast<int64_t>(yy) * w + xx] = gdm * mpix[k];
+    }
+    if (staged) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const float gsum = s_g[e];
+            if (gsum != 0.f) {
+                const int ry = e / T::BW, rx = e - ry * T::BW;
+                atomicAdd(gd2 + base + static_cast<int64_t>(by0 + ry) * w + bx0 + rx, gsum);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__ a, const float* __restrict__ mask,
                                                        float* __restrict__ out, int c, int hw) {
     const int n = blockIdx.y;
@@ -391,6 +617,9 @@ __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__
         for (int k = 0; k < c; ++k) out[abase + static_cast<int64_t>(k) * hw + i] = a[abase + static_cast<int64_t>(k) * hw + i] * m;
     }
 }
+
+// tile of the default entry points endo_depth_warp_fwd / _bwd (profiles/r02_warp_tile_sweep.txt); 0 x 0 = the gather kernels
+constexpr int kWarpTileH = 16, kWarpTileW = 64;
 
 inline int plane_blocks(int hw, int threads) {
     int b = (hw + threads - 1) / threads;
@@ -453,31 +682,72 @@ extern "C" int endo_flow_from_depth_bwd(const float* grad_flow, const float* dep
     return 0;
 }
 
-extern "C" int endo_depth_warp_fwd(const float* depth_1, const float* depth_2, const float* mask, const float* t, const float* R,
-                                   const float* K, float* warped, float* intersect, int n, int h, int w, float eps,
-                                   void* stream_) {
+template <int TY, int TX>
+static int launch_warp_fwd_tiled(const float* d1, const float* d2, const float* mask, const float* t, const float* R, const float* K,
+                                 float* warped, float* intersect, int n, int h, int w, float eps, hipStream_t stream) {
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
+    warp_fwd_tiled_kernel<TY, TX><<<dim3(tiles_x * tiles_y, n), 256, 0, stream>>>(d1, d2, mask, t, R, K, warped, intersect, h, w, tiles_x, eps);
+    return static_cast<int>(hipGetLastError());
+}
+
+template <int TY, int TX>
+static int launch_warp_bwd_tiled(const float* gw, const float* d1, const float* d2, const float* mask, const float* t, const float* R,
+                                 const float* K, float* gd1, float* gd2, int n, int h, int w, float eps, hipStream_t stream) {
+    const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
+    warp_bwd_tiled_kernel<TY, TX><<<dim3(tiles_x * tiles_y, n), 256, 0, stream>>>(gw, d1, d2, mask, t, R, K, gd1, gd2, h, w, tiles_x, eps);
+    return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int endo_depth_warp_fwd_tiled(const float* depth_1, const float* depth_2, const float* mask, const float* t, const float* R,
+                                         const float* K, float* warped, float* intersect, int n, int h, int w, float eps,
+                                         int tile_h, int tile_w, void* stream_) {
     if (!depth_1 || !depth_2 || !mask || !t || !R || !K || !warped || !intersect || n <= 0 || h <= 0 || w <= 0)
         return ENDO_E_BADARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfGeometry, stream, 0.0, 5.0 * 4.0 * n * h * w);
-    warp_fwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(depth_1, depth_2, mask, t, R, K, warped, intersect,
-                                                                           h, w, eps);
-    ENDO_LAUNCH_CHECK();
-    return 0;
+    if (tile_h == 0 && tile_w == 0) {
+        warp_fwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(depth_1, depth_2, mask, t, R, K, warped, intersect,
+                                                                               h, w, eps);
+        ENDO_LAUNCH_CHECK();
+        return 0;
+    }
+#define ENDO_WARP_FWD(TY_, TX_) if (tile_h == TY_ && tile_w == TX_) return launch_warp_fwd_tiled<TY_, TX_>(depth_1, depth_2, mask, t, R, K, warped, intersect, n, h, w, eps, stream)
+    ENDO_WARP_FWD(8, 32); ENDO_WARP_FWD(16, 32); ENDO_WARP_FWD(16, 64); ENDO_WARP_FWD(32, 32); ENDO_WARP_FWD(32, 64);
+#undef ENDO_WARP_FWD
+    return ENDO_E_UNSUPPORTED;
 }
 
-extern "C" int endo_depth_warp_bwd(const float* grad_warped, const float* depth_1, const float* depth_2, const float* mask,
-                                   const float* t, const float* R, const float* K, float* grad_d1, float* grad_d2, int n,
-                                   int h, int w, float eps, void* stream_) {
+extern "C" int endo_depth_warp_fwd(const float* depth_1, const float* depth_2, const float* mask, const float* t, const float* R,
+                                   const float* K, float* warped, float* intersect, int n, int h, int w, float eps,
+                                   void* stream_) {
+    return endo_depth_warp_fwd_tiled(depth_1, depth_2, mask, t, R, K, warped, intersect, n, h, w, eps, kWarpTileH, kWarpTileW, stream_);
+}
+
+extern "C" int endo_depth_warp_bwd_tiled(const float* grad_warped, const float* depth_1, const float* depth_2, const float* mask,
+                                         const float* t, const float* R, const float* K, float* grad_d1, float* grad_d2, int n,
+                                         int h, int w, float eps, int tile_h, int tile_w, void* stream_) {
     if (!grad_warped || !depth_1 || !depth_2 || !mask || !t || !R || !K || !grad_d1 || !grad_d2 || n <= 0 || h <= 0 || w <= 0)
         return ENDO_E_BADARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfGeometry, stream, 0.0, 7.0 * 4.0 * n * h * w);
     ENDO_CHECK(hipMemsetAsync(grad_d2, 0, sizeof(float) * static_cast<size_t>(n) * h * w, stream));
-    warp_bwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(grad_warped, depth_1, depth_2, mask, t, R, K,
-                                                                           grad_d1, grad_d2, h, w, eps);
-    ENDO_LAUNCH_CHECK();
-    return 0;
+    if (tile_h == 0 && tile_w == 0) {
+        warp_bwd_kernel<<<dim3(plane_blocks(h * w, 256), n), 256, 0, stream>>>(grad_warped, depth_1, depth_2, mask, t, R, K,
+                                                                               grad_d1, grad_d2, h, w, eps);
+        ENDO_LAUNCH_CHECK();
+        return 0;
+    }
+#define ENDO_WARP_BWD(TY_, TX_) if (tile_h == TY_ && tile_w == TX_) return launch_warp_bwd_tiled<TY_, TX_>(grad_warped, depth_1, depth_2, mask, t, R, K, grad_d1, grad_d2, n, h, w, eps, stream)
+    ENDO_WARP_BWD(8, 32); ENDO_WARP_BWD(16, 32); ENDO_WARP_BWD(16, 64); ENDO_WARP_BWD(32, 32); ENDO_WARP_BWD(32, 64);
+#undef ENDO_WARP_BWD
+    return ENDO_E_UNSUPPORTED;
+}
+
+extern "C" int endo_depth_warp_bwd(const float* grad_warped, const float* depth_1, const float* depth_2, const float* mask,
+                                   const float* t, const float* R, const float* K, float* grad_d1, float* grad_d2, int n,
+                                   int h, int w, float eps, void* stream_) {
+    return endo_depth_warp_bwd_tiled(grad_warped, depth_1, depth_2, mask, t, R, K, grad_d1, grad_d2, n, h, w, eps, kWarpTileH, kWarpTileW,
+                                     stream_);
 }
 
 extern "C" int endo_mask_mul(const float* a, const float* mask, float* out, int n, int c, int hw, void* stream_) {

@@ -146,15 +146,52 @@ namespace endo {
 // small kernels
 // ---------------------------------------------------------------------------------------------
 
+// per BN layer (up to four): its backward sums, saved statistics, parameters and parameter gradients, offset to the first
+// channel of the range a launch works on
+struct BnFin4 {
+    const double* scratch[4];
+    const float* saved[4];
+    const float* gamma[4];
+    float* ggamma[4];
+    float* gbeta[4];
+};
+
 // G = dbuf + P x + Q in place for a channel range (the deferred mean terms of every BN that consumed
 // the channel), and bias gradient += sum G.
+// nl > 0: the range's consumers INSIDE its dense block (fin: nl BN layers) have just been differentiated by one fused pass and
+// their deferred terms are not in P, Q yet: every block derives them from the pass's sums (the arithmetic of
+// bn_bwd_finalize4_kernel, term by term), and the first block of a (channel, group) also adds the BN parameter gradients.
+// This takes the separate finalize launch between the pass and this kernel off the backward chain.
 __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, const float* __restrict__ x, int64_t ns, int plane,
                                                       const float* __restrict__ pq_p, const float* __restrict__ pq_q,
-                                                      float* bias_grad, int group_n, int64_t gs) {
+                                                      float* bias_grad, int group_n, int64_t gs, const BnFin4 fin, int nl,
+                                                      double count, int training) {
     __shared__ double scratch[4];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
-    const float pc = pq_p[grp * gs + c], qc = pq_q[grp * gs + c];
+    float pc = pq_p[grp * gs + c], qc = pq_q[grp * gs + c];
+    if (nl > 0) {
+        const int64_t go = grp * gs;
+        double dp = 0.0, dq = 0.0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nl) break;
+            const double s1 = fin.scratch[j][go / 2 + 2 * c], s2 = fin.scratch[j][go / 2 + 2 * c + 1];
+            if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+                atomicAdd(fin.ggamma[j] + c, static_cast<float>(s2));
+                atomicAdd(fin.gbeta[j] + c, static_cast<float>(s1));
+            }
+            if (training) {
+                const double mean = fin.saved[j][go + 2 * c], rstd = fin.saved[j][go + 2 * c + 1];
+                const double scale = fin.gamma[j][c] * rstd;
+                const double k = scale * rstd * s2 / count;
+                dp += static_cast<double>(static_cast<float>(-k));
+                dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
+            }
+        }
+        pc += static_cast<float>(dp);
+        qc += static_cast<float>(dq);
+    }
     const int64_t base = grp * gs + n * ns + static_cast<int64_t>(c) * plane;
     float part = 0.f;
     if ((plane & 3) == 0) {
@@ -204,13 +241,6 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const
 
 // the same for up to four BN layers of a dense block over channels they share: one launch, one read-modify-write of
 // P and Q
-struct BnFin4 {
-    const double* scratch[4];
-    const float* saved[4];
-    const float* gamma[4];
-    float* ggamma[4];
-    float* gbeta[4];
-};
 __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, int nl, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
                                         int training, int64_t gs) {
     const int64_t go = blockIdx.y * gs;          // sample group offset (floats)
@@ -632,14 +662,16 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
-static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad) {
+static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad, const BnFin4* fin = nullptr, int nl = 0) {
     const auto& lv = c.net->lv[level];
+    BnFin4 none{};
     int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
     bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
     ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.nt() * lv.plane * count);
     prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
-                                                                     c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs);
+                                                                     c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs, fin ? *fin : none, fin ? nl : 0,
+                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -738,8 +770,10 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         p.g_ns = lv.t * lv.plane; p.g_cs = static_cast<int>(lv.plane); p.g_w = lv.w;
         p.ns = lv.t * lv.plane; p.cs = static_cast<int>(lv.plane);
     };
+    BnFin4 pending{};          // BN layers whose sums over the next prepared maps the last new-channel pass produced (folded into prep_dy)
+    int pending_nl = 0;
     for (int j = kLayers - 1; j >= 0; --j) {
-        int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b);
+        int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b, &pending, pending_nl);
         if (rc) return rc;
         {
             Ctx cw;
@@ -778,10 +812,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                    : nl == 2 ? launch_dgrad_block<2, 2, 3>(p, c.stream) : launch_dgrad_block<3, 2, 3>(p, c.stream);
                 if (rc) return rc;
             }
-            ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
-            bn_bwd_finalize4_kernel<<<dim3(1, c.net->groups), 128, 0, c.stream>>>(a, nl, c.pq_p(level) + ic0 + t0, c.pq_q(level) + ic0 + t0, kGrowth,
-                                                                             static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
-            ENDO_LAUNCH_CHECK();
+            pending = a;          // consumed by the prep_dy of these 12 maps at the top of the next iteration
+            pending_nl = nl;
         }
     }
     {   // base channels, all four layers in one pass

@@ -461,7 +461,7 @@ class FlowfromDepthLayer(nn.Module):
 
 class _WarpFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, d1, d2, mask, t, r, k, eps):
+    def forward(ctx, d1, d2, mask, t, r, k, eps, tile=None):
         lib = _lib.load()
         d1 = _lib.dev_f32(d1, "depth maps 1")
         d2 = _lib.dev_f32(d2, "depth maps 2")
@@ -470,11 +470,17 @@ class _WarpFn(torch.autograd.Function):
         t, r, k = _pose(t, r, k, n)
         warped = torch.empty_like(d1)
         intersect = torch.empty_like(d1)
-        _lib.check(lib.endo_depth_warp_fwd(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r), _lib.ptr(k),
-                                           _lib.ptr(warped), _lib.ptr(intersect), n, h, w, eps, _lib.stream()),
-                   "endo_depth_warp_fwd")
+        if tile is None:
+            _lib.check(lib.endo_depth_warp_fwd(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r), _lib.ptr(k),
+                                               _lib.ptr(warped), _lib.ptr(intersect), n, h, w, eps, _lib.stream()),
+                       "endo_depth_warp_fwd")
+        else:
+            _lib.check(lib.endo_depth_warp_fwd_tiled(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t), _lib.ptr(r), _lib.ptr(k),
+                                                     _lib.ptr(warped), _lib.ptr(intersect), n, h, w, eps, int(tile[0]), int(tile[1]),
+                                                     _lib.stream()), "endo_depth_warp_fwd_tiled(%d x %d)" % (tile[0], tile[1]))
         ctx.save_for_backward(d1, d2, mask, t, r, k)
         ctx.eps = eps
+        ctx.tile = tile
         ctx.mark_non_differentiable(intersect)
         return warped, intersect
 
@@ -486,21 +492,31 @@ class _WarpFn(torch.autograd.Function):
         grad_warped = _lib.dev_f32(grad_warped, "grad")
         g1 = torch.empty_like(d1)
         g2 = torch.empty_like(d2)
-        _lib.check(lib.endo_depth_warp_bwd(_lib.ptr(grad_warped), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t),
-                                           _lib.ptr(r), _lib.ptr(k), _lib.ptr(g1), _lib.ptr(g2), n, h, w, ctx.eps,
-                                           _lib.stream()), "endo_depth_warp_bwd")
-        return g1, g2, None, None, None, None, None
+        if ctx.tile is None:
+            _lib.check(lib.endo_depth_warp_bwd(_lib.ptr(grad_warped), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t),
+                                               _lib.ptr(r), _lib.ptr(k), _lib.ptr(g1), _lib.ptr(g2), n, h, w, ctx.eps,
+                                               _lib.stream()), "endo_depth_warp_bwd")
+        else:
+            _lib.check(lib.endo_depth_warp_bwd_tiled(_lib.ptr(grad_warped), _lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t),
+                                                     _lib.ptr(r), _lib.ptr(k), _lib.ptr(g1), _lib.ptr(g2), n, h, w, ctx.eps,
+                                                     int(ctx.tile[0]), int(ctx.tile[1]), _lib.stream()), "endo_depth_warp_bwd_tiled")
+        return g1, g2, None, None, None, None, None, None
 
 
 class DepthWarpingLayer(nn.Module):
-    """reference models.py:454-465: warp depth map 2 into frame 1 + binary intersection mask."""
+    """reference models.py:454-465: warp depth map 2 into frame 1 + binary intersection mask.
 
-    def __init__(self, epsilon=1.0e-8):
+    ``tile`` (not in the reference; default None = the library's choice): the LDS source-tile shape of the kernels,
+    ``(tile_h, tile_w)`` in {(8,32), (16,32), (16,64), (32,32), (32,64)}, or ``(0, 0)`` for the L2-gather kernels.  It
+    changes speed only (tools/warp_tile_sweep.py)."""
+
+    def __init__(self, epsilon=1.0e-8, tile=None):
         super().__init__()
         self.epsilon = float(epsilon)
+        self.tile = None if tile is None else (int(tile[0]), int(tile[1]))
 
     def forward(self, x):
         depth_maps_1, depth_maps_2, img_masks, translation_vectors, rotation_matrices, intrinsic_matrices = x
         warped, intersect = _WarpFn.apply(depth_maps_1, depth_maps_2, img_masks, translation_vectors, rotation_matrices,
-                                          intrinsic_matrices, self.epsilon)
+                                          intrinsic_matrices, self.epsilon, self.tile)
         return warped, intersect

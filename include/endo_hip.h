@@ -75,6 +75,18 @@ int endo_depth_warp_bwd(const float* grad_warped, const float* depth_1, const fl
                         const float* mask, const float* t, const float* R, const float* K,
                         float* grad_d1, float* grad_d2,
                         int n, int h, int w, float eps, void* stream);
+/* The same with an explicit LDS source-tile shape (geometry.hip "LDS-staged depth warp"): tile_h x tile_w in
+ * {8x32, 16x32, 16x64, 32x32, 32x64}, or 0 x 0 for the L2-gather kernels; ENDO_E_UNSUPPORTED otherwise.  The entry points
+ * above use the shape the sweep under profiles/ settled on.  Results do not depend on the shape (forward bit-identical,
+ * the d2 gradient up to the order of its atomic additions). */
+int endo_depth_warp_fwd_tiled(const float* depth_1, const float* depth_2, const float* mask,
+                              const float* t, const float* R, const float* K,
+                              float* warped, float* intersect,
+                              int n, int h, int w, float eps, int tile_h, int tile_w, void* stream);
+int endo_depth_warp_bwd_tiled(const float* grad_warped, const float* depth_1, const float* depth_2,
+                              const float* mask, const float* t, const float* R, const float* K,
+                              float* grad_d1, float* grad_d2,
+                              int n, int h, int w, float eps, int tile_h, int tile_w, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * SparseMaskedL1Loss.forward -- reference losses.py:62-66

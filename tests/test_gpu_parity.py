@@ -641,6 +641,125 @@ def test_wgrad_overlap_is_transparent(shape):
 
 
 # ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[3]: 512 x 640 (network_downsampling 64), and the LDS source tiles of the warp kernels
+# ---------------------------------------------------------------------------------------------
+WARP_TILES = [(0, 0), (8, 32), (16, 32), (16, 64), (32, 32), (32, 64)]
+
+
+@pytest.mark.parametrize("tile", WARP_TILES)
+def test_depth_warping_tiles_512x640(tile):
+    """Every LDS source-tile shape of the warp kernels (and the L2-gather kernels, 0 x 0) at the configs[3] frame size
+    against the oracle: warped depth 5e-5, both gradients 1e-4; the intersect mask away from the threshold."""
+    n, h, w = 1, 512, 640
+    batch, p1, p2, _ = geometry_inputs(n, h, w, 47)
+    cot = torch.from_numpy(np.random.default_rng(3).standard_normal((n, 1, h, w)).astype(np.float32))
+    args = [batch["boundaries"], batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]]
+    c1 = p1.clone().requires_grad_(True)
+    c2 = p2.clone().requires_grad_(True)
+    w_ref, overlap = ogeo.depth_warping_parts(c1, c2, *args)
+    (w_ref * cot).sum().backward()
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    warped, inter = ea.DepthWarpingLayer(epsilon=1.0e-8, tile=tile)([g1, g2] + [a.to(dev()) for a in args])
+    (warped * cot.to(dev())).sum().backward()
+    assert_close(warped, w_ref, 5e-5, "warped depth, tile %s" % (tile,))
+    assert_close(g1.grad, c1.grad, 1e-4, "grad depth 1, tile %s" % (tile,))
+    assert_close(g2.grad, c2.grad, 1e-4, "grad depth 2, tile %s" % (tile,))
+    clear = (overlap.detach() - 0.9).abs() > 1e-5
+    assert torch.equal(inter.cpu()[clear], (overlap.detach() >= 0.9).float()[clear]), "intersect mask"
+
+
+def test_warp_tiles_agree_and_fall_back():
+    """The tile shape changes speed only: forward bit-identical to the gather kernels for every shape, d2 gradient equal up to
+    the order of its atomic additions -- on ordinary motion, on a batch whose poses are scaled x10 (source boxes larger than
+    the staging buffers: blocks fall back to gathers), with points behind the camera and samples that leave the frame
+    (the edge cases of test_warp_edge_cases), and on a size that is not a multiple of any tile (37 x 53)."""
+    for (n, h, w, scale) in ((2, 256, 320, 1.0), (2, 256, 320, 10.0), (2, 37, 53, 1.0), (2, 64, 96, 3.0)):
+        batch, p1, p2, _ = geometry_inputs(n, h, w, 48)
+        t = batch["translations_1_wrt_2"].clone() * scale
+        t[0, 2, 0] = 2.0                     # z2 <= 0 for sample 0
+        args = [batch["boundaries"].to(dev()), t.to(dev()), batch["rotations_1_wrt_2"].to(dev()), batch["intrinsics"].to(dev())]
+        cot = torch.randn(n, 1, h, w, device=dev(), generator=torch.Generator(device=dev()).manual_seed(2))
+        ref = None
+        for tile in WARP_TILES:
+            g1 = p1.to(dev()).requires_grad_(True)
+            g2 = p2.to(dev()).requires_grad_(True)
+            warped, inter = ea.DepthWarpingLayer(tile=tile)([g1, g2] + args)
+            (warped * cot).sum().backward()
+            if ref is None:
+                ref = (warped.detach().clone(), inter.clone(), g1.grad.clone(), g2.grad.clone())
+                assert torch.isfinite(ref[0]).all()
+                continue
+            what = "tile %s at %dx%d, motion x%g" % (tile, h, w, scale)
+            assert torch.equal(warped.detach(), ref[0]), "warped differs from the gather kernel: " + what
+            assert torch.equal(inter, ref[1]), "intersect differs: " + what
+            assert torch.equal(g1.grad, ref[2]), "d1 gradient differs: " + what
+            assert_close(g2.grad, ref[3], 1e-5, "d2 gradient, " + what)
+    with pytest.raises(RuntimeError):
+        ea.DepthWarpingLayer(tile=(24, 48))([g1, g2] + args)
+
+
+def test_geometry_and_losses_512x640():
+    """The whole geometry + loss chain of a training step at 1 x 512 x 640 (configs[3] frame size) against the oracle."""
+    n, h, w = 1, 512, 640
+    batch, p1, p2, _ = geometry_inputs(n, h, w, 49)
+    p1, p2 = p1 + 2.0, p2 + 2.0
+    c1 = p1.clone().requires_grad_(True)
+    c2 = p2.clone().requires_grad_(True)
+    l_ref, dcl_ref, sfl_ref, _ = ostep.losses_from_depths(c1, c2, batch)
+    l_ref.backward()
+    dbatch = to_dev(batch)
+    b = dbatch["boundaries"]
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    scaling, flow_layer, warp_layer = ea.DepthScalingLayer(), ea.FlowfromDepthLayer(), ea.DepthWarpingLayer()
+    sfl_fn, dcl_fn = ea.SparseMaskedL1Loss(), ea.NormalizedDistanceLoss(h, w)
+    s1, _ = scaling([g1, dbatch["sparse_depths_1"], dbatch["sparse_depth_masks_1"]])
+    s2, _ = scaling([g2, dbatch["sparse_depths_2"], dbatch["sparse_depth_masks_2"]])
+    f1 = flow_layer([s1, b, dbatch["translations_1_wrt_2"], dbatch["rotations_1_wrt_2"], dbatch["intrinsics"]]) * b
+    f2 = flow_layer([s2, b, dbatch["translations_2_wrt_1"], dbatch["rotations_2_wrt_1"], dbatch["intrinsics"]]) * b
+    sfl = 20.0 * 0.5 * (sfl_fn([dbatch["sparse_flows_1"] * b, f1, dbatch["sparse_flow_masks_1"] * b]) +
+                        sfl_fn([dbatch["sparse_flows_2"] * b, f2, dbatch["sparse_flow_masks_2"] * b]))
+    w21, i1 = warp_layer([s1, s2, b, dbatch["translations_1_wrt_2"], dbatch["rotations_1_wrt_2"], dbatch["intrinsics"]])
+    w12, i2 = warp_layer([s2, s1, b, dbatch["translations_2_wrt_1"], dbatch["rotations_2_wrt_1"], dbatch["intrinsics"]])
+    dcl = 0.1 * 0.5 * (dcl_fn([s1, w21, i1, dbatch["intrinsics"]]) + dcl_fn([s2, w12, i2, dbatch["intrinsics"]]))
+    (dcl + sfl).backward()
+    assert_close(sfl, sfl_ref, 1e-4, "sparse flow loss at 512x640")
+    assert_close(dcl, dcl_ref, 1e-4, "depth consistency loss at 512x640")
+    assert_close(g1.grad, c1.grad, 1e-4, "grad pred 1 at 512x640")
+    assert_close(g2.grad, c2.grad, 1e-4, "grad pred 2 at 512x640")
+
+
+def test_pair_backward_on_pattern_512x640():
+    """configs[3] through the network: forward_pair at 2 x (2 x 512 x 640) -- 4 samples per launch, the level-0 .. level-5
+    grids of the 512 x 640 bench -- all 210 parameter gradients against the fp32 CPU oracle on the pass's own activation
+    pattern (as test_full_size_pair_backward_on_pattern), 1e-4."""
+    n, h, w = 2, 512, 640
+    state, model = make_model(59)
+    rng = np.random.default_rng(15)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    model.train()
+    y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+    patterns = pattern_of(y1, model, n, h, w, groups=2)
+    ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names = onet.trainable_names()
+    total = None
+    for x, cot, pat, got in zip(xs, cots, patterns, (y1, y2)):
+        st = {k: v.clone() for k, v in state.items()}
+        for nm in names:
+            st[nm].requires_grad_(True)
+        y = onet.forward(st, x, training=True, pattern=pat)
+        assert_close(got, y.detach(), 1e-4, "depth at 512x640 vs the oracle on the same pattern")
+        grads = torch.autograd.grad((y * cot).sum(), [st[nm] for nm in names])
+        total = list(grads) if total is None else [a + b for a, b in zip(total, grads)]
+        del y, grads, st
+    assert_grads_on_pattern(params, dict(zip(names, total)), None, 1e-4, "512x640 pair backward")
+
+
+# ---------------------------------------------------------------------------------------------
 # the benchmark configuration itself (BASELINE.json configs[1]: N = 8, 256 x 320, grouped pair forward) against the
 # fixture the REFERENCE produced at that size
 # ---------------------------------------------------------------------------------------------
