@@ -268,15 +268,51 @@ __device__ __forceinline__ Taps make_taps(float u2, float v2, int w, int h) {
     return tp;
 }
 
+// (M2 p)_z at frame-2 pixel (xx, yy)
+__device__ __forceinline__ float plane_s(const Camera& c, int xx, int yy) {
+#pragma clang fp contract(off)
+    return fmaf(c.m2z[1], static_cast<float>(yy), c.m2z[0] * static_cast<float>(xx)) + c.m2z[2];
+}
+
 // depth 2 seen from camera 1 at frame-2 pixel (xx, yy):  m * (w2z + (d2 m) * (M2 p)_z)
 __device__ __forceinline__ float depth_in_1(const Camera& c, const float* d2, const float* mask, int64_t base, int w, int xx, int yy,
                                             float* mask_out, float* s_out) {
+#pragma clang fp contract(off)
     const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
     const float m = mask[o];
-    const float s = fmaf(c.m2z[1], static_cast<float>(yy), c.m2z[0] * static_cast<float>(xx)) + c.m2z[2];
+    const float s = plane_s(c, xx, yy);
     *mask_out = m;
     *s_out = s;
-    return m * (c.w2z + (d2[o] * m) * s);
+    return m * fmaf(d2[o] * m, s, c.w2z);
+}
+
+// The tap blend and the d1 gradient, shared by the gather and the LDS-staged kernels so that a tile shape changes speed and
+// nothing else: explicit fused multiply-adds in a fixed order (contraction off), identical in every kernel that inlines them.
+__device__ __forceinline__ void tap_blend(const Taps& q, const float (&v)[4], const float (&mm)[4], float& acc, float& macc) {
+#pragma clang fp contract(off)
+    acc = q.wnw * v[0]; macc = q.wnw * mm[0];
+    acc = fmaf(q.wne, v[1], acc); macc = fmaf(q.wne, mm[1], macc);
+    acc = fmaf(q.wsw, v[2], acc); macc = fmaf(q.wsw, mm[2], macc);
+    acc = fmaf(q.wse, v[3], acc); macc = fmaf(q.wse, mm[3], macc);
+}
+
+__device__ __forceinline__ float warp_grad_d1(const Taps& q, const float (&v)[4], float g, float fw, float fh, float qx, float qy, float qz,
+                                              float zt, float nx, float ny, bool open, float m) {
+#pragma clang fp contract(off)
+    const float sfrac = 1.0f - q.fy, efrac = 1.0f - q.fx;
+    // d out / d ix, d out / d iy, then grid_sample's (W/2, H/2) and the grid's (2/W, 2/H)
+    const float gix = fmaf(v[3] - v[2], q.fy, (v[1] - v[0]) * sfrac) * g;
+    const float giy = fmaf(v[3] - v[1], q.fx, (v[2] - v[0]) * efrac) * g;
+    const float gu = gix * (fw * 0.5f) * 2.0f / fw;
+    const float gv = giy * (fh * 0.5f) * 2.0f / fh;
+    float gdm = fmaf(gv, qy / zt, gu * qx / zt);
+    if (open) gdm = fmaf(-fmaf(gv, ny, gu * nx) / (zt * zt), qz, gdm);
+    return gdm * m;
+}
+
+__device__ __forceinline__ float warp_grad_d2_term(float g, float wt, float mm, float ss) {
+#pragma clang fp contract(off)
+    return g * wt * mm * ss * mm;
 }
 
 __global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__ d1, const float* __restrict__ d2,
@@ -301,27 +337,13 @@ __global__ void __launch_bounds__(256) warp_fwd_kernel(const float* __restrict__
         const float u2 = (cam.w[0] + dm * qx) / zt;
         const float v2 = (cam.w[1] + dm * qy) / zt;
         const Taps tp = make_taps(u2, v2, w, h);
-        float acc = 0.f, macc = 0.f, mm, ss;
-        {
-            float v = 0.f; mm = 0.f;
-            if (tp.vw && tp.vn) v = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0, &mm, &ss);
-            acc = tp.wnw * v; macc = tp.wnw * mm;
-        }
-        {
-            float v = 0.f; mm = 0.f;
-            if (tp.ve && tp.vn) v = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0, &mm, &ss);
-            acc += tp.wne * v; macc += tp.wne * mm;
-        }
-        {
-            float v = 0.f; mm = 0.f;
-            if (tp.vw && tp.vs) v = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0 + 1, &mm, &ss);
-            acc += tp.wsw * v; macc += tp.wsw * mm;
-        }
-        {
-            float v = 0.f; mm = 0.f;
-            if (tp.ve && tp.vs) v = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0 + 1, &mm, &ss);
-            acc += tp.wse * v; macc += tp.wse * mm;
-        }
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f}, ss;
+        if (tp.vw && tp.vn) v[0] = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0, &mm[0], &ss);
+        if (tp.ve && tp.vn) v[1] = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0, &mm[1], &ss);
+        if (tp.vw && tp.vs) v[2] = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0 + 1, &mm[2], &ss);
+        if (tp.ve && tp.vs) v[3] = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0 + 1, &mm[3], &ss);
+        float acc, macc;
+        tap_blend(tp, v, mm, acc, macc);
         warped[base + i] = acc;
         intersect[base + i] = (macc * m >= 0.9f) ? 1.0f : 0.0f;
     }
@@ -352,32 +374,18 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
         const float ny = cam.w[1] + dm * qy;
         const Taps tp = make_taps(nx / zt, ny / zt, w, h);
         const float g = gw[base + i];
-        float vnw = 0.f, vne = 0.f, vsw = 0.f, vse = 0.f, mm, ss;
-        if (tp.vw && tp.vn) {
-            vnw = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0, &mm, &ss);
-            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0) * w + tp.x0, g * tp.wnw * mm * ss * mm);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool val[4] = {tp.vw && tp.vn, tp.ve && tp.vn, tp.vw && tp.vs, tp.ve && tp.vs};
+        const float wt[4] = {tp.wnw, tp.wne, tp.wsw, tp.wse};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!val[c]) continue;
+            const int sx = tp.x0 + (c & 1), sy = tp.y0 + (c >> 1);
+            float mm, ss;
+            v[c] = depth_in_1(cam, d2, mask, base, w, sx, sy, &mm, &ss);
+            atomicAdd(gd2 + base + static_cast<int64_t>(sy) * w + sx, warp_grad_d2_term(g, wt[c], mm, ss));
         }
-        if (tp.ve && tp.vn) {
-            vne = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0, &mm, &ss);
-            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0) * w + tp.x0 + 1, g * tp.wne * mm * ss * mm);
-        }
-        if (tp.vw && tp.vs) {
-            vsw = depth_in_1(cam, d2, mask, base, w, tp.x0, tp.y0 + 1, &mm, &ss);
-            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0 + 1) * w + tp.x0, g * tp.wsw * mm * ss * mm);
-        }
-        if (tp.ve && tp.vs) {
-            vse = depth_in_1(cam, d2, mask, base, w, tp.x0 + 1, tp.y0 + 1, &mm, &ss);
-            atomicAdd(gd2 + base + static_cast<int64_t>(tp.y0 + 1) * w + tp.x0 + 1, g * tp.wse * mm * ss * mm);
-        }
-        const float sfrac = 1.0f - tp.fy, efrac = 1.0f - tp.fx;
-        // d out / d ix, d out / d iy, then grid_sample's (W/2, H/2) and the grid's (2/W, 2/H)
-        float gix = ((vne - vnw) * sfrac + (vse - vsw) * tp.fy) * g;
-        float giy = ((vsw - vnw) * efrac + (vse - vne) * tp.fx) * g;
-        const float gu = gix * (fw * 0.5f) * 2.0f / fw;
-        const float gv = giy * (fh * 0.5f) * 2.0f / fh;
-        float gdm = gu * qx / zt + gv * qy / zt;
-        if (open) gdm += -(gu * nx + gv * ny) / (zt * zt) * qz;
-        gd1[base + i] = gdm * m;
+        gd1[base + i] = warp_grad_d1(tp, v, g, fw, fh, qx, qy, qz, zt, nx, ny, open, m);
     }
 }
 
@@ -493,10 +501,8 @@ __global__ void __launch_bounds__(256) warp_fwd_tiled_kernel(const float* __rest
             if (q.vw && q.vs) v[2] = depth_in_1(cam, d2, mask, base, w, q.x0, q.y0 + 1, &mm[2], &ss);
             if (q.ve && q.vs) v[3] = depth_in_1(cam, d2, mask, base, w, q.x0 + 1, q.y0 + 1, &mm[3], &ss);
         }
-        float acc = q.wnw * v[0], macc = q.wnw * mm[0];
-        acc += q.wne * v[1]; macc += q.wne * mm[1];
-        acc += q.wsw * v[2]; macc += q.wsw * mm[2];
-        acc += q.wse * v[3]; macc += q.wse * mm[3];
+        float acc, macc;
+        tap_blend(q, v, mm, acc, macc);
         const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
         warped[o] = acc;
         intersect[o] = (macc * mpix[k] >= 0.9f) ? 1.0f : 0.0f;
@@ -579,21 +585,14 @@ __global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __rest
             if (staged) {
                 const int o = (sy - by0) * T::BW + (sx - bx0);
                 v[c] = s_d[o]; mm = s_m[o];
-                ss = fmaf(cam.m2z[1], static_cast<float>(sy), cam.m2z[0] * static_cast<float>(sx)) + cam.m2z[2];
-                atomicAdd(&s_g[o], g * wt[c] * mm * ss * mm);
+                ss = plane_s(cam, sx, sy);
+                atomicAdd(&s_g[o], warp_grad_d2_term(g, wt[c], mm, ss));
             } else {
                 v[c] = depth_in_1(cam, d2, mask, base, w, sx, sy, &mm, &ss);
-                atomicAdd(gd2 + base + static_cast<int64_t>(sy) * w + sx, g * wt[c] * mm * ss * mm);
+                atomicAdd(gd2 + base + static_cast<int64_t>(sy) * w + sx, warp_grad_d2_term(g, wt[c], mm, ss));
             }
         }
-        const float sfrac = 1.0f - q.fy, efrac = 1.0f - q.fx;
-        const float gix = ((v[1] - v[0]) * sfrac + (v[3] - v[2]) * q.fy) * g;
-        const float giy = ((v[2] - v[0]) * efrac + (v[3] - v[1]) * q.fx) * g;
-        const float gu = gix * (fw * 0.5f) * 2.0f / fw;
-        const float gv = giy * (fh * 0.5f) * 2.0f / fh;
-        float gdm = gu * qxs[k] / zts[k] + gv * qys[k] / zts[k];
-        if (opens[k]) gdm += -(gu * nxs[k] + gv * nys[k]) / (zts[k] * zts[k]) * qzs[k];
-        gd1[base + static_cast<int64_t>(yy) * w + xx] = gdm * mpix[k];
+        gd1[base + static_cast<int64_t>(yy) * w + xx] = warp_grad_d1(q, v, g, fw, fh, qxs[k], qys[k], qzs[k], zts[k], nxs[k], nys[k], opens[k], mpix[k]);
     }
     if (staged) {
         __syncthreads();
@@ -619,7 +618,7 @@ __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__
 }
 
 // tile of the default entry points endo_depth_warp_fwd / _bwd (profiles/r02_warp_tile_sweep.txt); 0 x 0 = the gather kernels
-constexpr int kWarpTileH = 16, kWarpTileW = 64;
+constexpr int kWarpTileH = 16, kWarpTileW = 32;
 
 inline int plane_blocks(int hw, int threads) {
     int b = (hw + threads - 1) / threads;

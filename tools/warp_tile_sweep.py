@@ -65,7 +65,7 @@ def run(n, h, w, pose_scale, reps=30):
         gerr = float((d1.grad - ref[2]).abs().max() / ref[2].abs().max())
         us_pair = ms / reps / n * 1e3
         mb_pair = 7.9 * (h * w) / (256.0 * 320.0)
-        rows.append((tile, us_pair, mb_pair / us_pair * 1e3 / 1e3, same, gerr))
+        rows.append((tile, us_pair, mb_pair / us_pair * 1e3, same, gerr))
     return rows
 
 
