@@ -212,6 +212,68 @@ __global__ void __launch_bounds__(256) cloud_write_kernel(const CloudParams q) {
 
 }  // namespace endo
 
+// ------------------------------------------------------------------------------------------
+// relative poses of a batch of frame pairs (reference dataset.py:384-399), one thread per pair:
+//   relative = E_1 inv(E_2) in fp64; R_1wrt2 = fp32(relative[:3,:3]); t_1wrt2 = fp32(relative[:3,3] / scale);
+//   R_2wrt1 = R_1wrt2^T; t_2wrt1 = -R_1wrt2^T t_1wrt2 formed in fp32 from the fp32 values.
+// inv(E_2): Gauss-Jordan with partial pivoting on the 4x4 (the reference calls numpy.linalg.inv = LU with partial pivoting;
+// both are accurate to a few ulp of fp64, far inside the fp32 rounding of the outputs).
+// ------------------------------------------------------------------------------------------
+namespace endo {
+__global__ void relative_poses_kernel(const double* __restrict__ ext, int batch, double scale, float* __restrict__ r12, float* __restrict__ t12,
+                                      float* __restrict__ r21, float* __restrict__ t21) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double* e1 = ext + static_cast<int64_t>(b) * 32;
+    const double* e2 = e1 + 16;
+    double a[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { a[i][j] = e2[i * 4 + j]; a[i][4 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        double best = fabs(a[col][col]);
+        for (int r = col + 1; r < 4; ++r)
+            if (fabs(a[r][col]) > best) { best = fabs(a[r][col]); piv = r; }
+        if (piv != col)
+            for (int j = 0; j < 8; ++j) { const double tmp = a[col][j]; a[col][j] = a[piv][j]; a[piv][j] = tmp; }
+        const double inv = 1.0 / a[col][col];
+        for (int j = 0; j < 8; ++j) a[col][j] *= inv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            for (int j = 0; j < 8; ++j) a[r][j] -= f * a[col][j];
+        }
+    }
+    float rot[3][3], tr[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 4; ++j) {
+            double v = 0.0;
+            for (int k = 0; k < 4; ++k) v += e1[i * 4 + k] * a[k][4 + j];
+            if (j < 3) rot[i][j] = static_cast<float>(v);
+            else tr[i] = static_cast<float>(v / scale);
+        }
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) { r12[b * 9 + i * 3 + j] = rot[i][j]; r21[b * 9 + i * 3 + j] = rot[j][i]; }
+        t12[b * 3 + i] = tr[i];
+        // row i of -R^T times t, accumulated left to right in fp32 without contraction (numpy.matmul on float32 operands)
+        float acc = __fmul_rn(-rot[0][i], tr[0]);
+        acc = __fadd_rn(acc, __fmul_rn(-rot[1][i], tr[1]));
+        acc = __fadd_rn(acc, __fmul_rn(-rot[2][i], tr[2]));
+        t21[b * 3 + i] = acc;
+    }
+}
+}  // namespace endo
+
+extern "C" int endo_relative_poses(const double* pair_extrinsics, int batch, double scale, float* r_1_wrt_2, float* t_1_wrt_2,
+                                   float* r_2_wrt_1, float* t_2_wrt_1, void* stream_) {
+    if (!pair_extrinsics || !r_1_wrt_2 || !t_1_wrt_2 || !r_2_wrt_1 || !t_2_wrt_1 || batch <= 0 || !(scale != 0.0)) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    endo::relative_poses_kernel<<<(batch + 63) / 64, 64, 0, stream>>>(pair_extrinsics, batch, scale, r_1_wrt_2, t_1_wrt_2, r_2_wrt_1, t_2_wrt_1);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int endo_point_cloud(const float* depth, const uint8_t* color_bgr, const float* mask, const float* intrinsics, int height,
                                 int width, int downsampling, int use_threshold, float min_threshold, float max_threshold,
                                 int32_t* row_offsets, float* points, int32_t* count_out, void* stream_) {

@@ -17,7 +17,12 @@ from . import _lib
 class SequenceScatter:
     """Device-resident SfM data of one sequence (reference utils.py:234-409 loads these per sequence)."""
 
-    def __init__(self, point_cloud, mask_boundary, view_indexes_per_point, clean_point_list, visible_view_indexes, device="cuda"):
+    def __init__(self, point_cloud, mask_boundary, view_indexes_per_point, clean_point_list, visible_view_indexes, device="cuda",
+                 extrinsics=None, projections=None, intrinsic_matrix=None, estimated_scale=None):
+        """The first five arguments are those of reference utils.get_torch_training_data.  With the per-view ``extrinsics``
+        (views x 4 x 4), ``projections`` (views x 3 x 4), the sequence's ``intrinsic_matrix`` and ``estimated_scale``
+        (dataset.py:353-356, 386, 421) resident as well, ``training_batch`` assembles everything of a batch but the colour
+        images on the device."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("SequenceScatter needs a GPU device: the MI355X path has no CPU fallback")
@@ -33,6 +38,18 @@ class SequenceScatter:
         clean = np.asarray(clean_point_list, dtype=np.float32).reshape(-1)
         self.clean = torch.from_numpy(clean).to(self.device) if clean.size else None           # utils.py:496: empty list = no filter
         self.view_column = {int(v): i for i, v in enumerate(visible_view_indexes)}
+        self.visible_view_indexes = [int(v) for v in visible_view_indexes]
+        as64 = lambda a, shape: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(shape))).to(self.device)
+        self.extrinsics = None if extrinsics is None else as64(extrinsics, (-1, 4, 4))
+        self.projections = None if projections is None else as64(projections, (-1, 3, 4))
+        self.estimated_scale = None if estimated_scale is None else float(estimated_scale)
+        self.intrinsics = None
+        if intrinsic_matrix is not None:          # dataset.py:421-423
+            k = np.asarray(intrinsic_matrix)[:3, :3].astype(np.float32).reshape(3, 3)
+            self.intrinsics = torch.from_numpy(np.ascontiguousarray(k)).to(self.device)
+        # dataset.py:427-430: the endoscope boundary as a {0, 1} plane
+        boundary = self.mask.float() / 255.0
+        self.boundary = (boundary > 0.9).float().reshape(1, 1, self.height, self.width)
 
     def planes(self, pair_extrinsics, pair_projections, pair_indexes, depth_multiplier=1.0):
         """pair_extrinsics (B,2,4,4), pair_projections (B,2,3,4), pair_indexes (B,2) frame indices.
@@ -40,8 +57,10 @@ class SequenceScatter:
         Returns dict of fp32 device tensors: ``depth_masks``, ``depths``, ``flow_masks`` (2,B,1,H,W) and
         ``flows`` (2,B,2,H,W); index 0 / 1 of the first axis = frame 1 / 2 of every pair.
         """
-        ext = torch.as_tensor(np.asarray(pair_extrinsics, dtype=np.float64)).reshape(-1, 2, 4, 4).contiguous().to(self.device)
-        proj = torch.as_tensor(np.asarray(pair_projections, dtype=np.float64)).reshape(-1, 2, 3, 4).contiguous().to(self.device)
+        to64 = lambda a, shape: (a.to(device=self.device, dtype=torch.float64) if torch.is_tensor(a)
+                                 else torch.as_tensor(np.asarray(a, dtype=np.float64)).to(self.device)).reshape(shape).contiguous()
+        ext = to64(pair_extrinsics, (-1, 2, 4, 4))
+        proj = to64(pair_projections, (-1, 2, 3, 4))
         batch = int(ext.shape[0])
         if int(proj.shape[0]) != batch:
             raise ValueError("pair_extrinsics and pair_projections disagree on the batch size")
@@ -62,6 +81,50 @@ class SequenceScatter:
                                          _lib.ptr(out["flow_masks"]), _lib.ptr(out["flows"]), _lib.stream())
         _lib.check(rc, "endo_sparse_scatter")
         return out
+
+
+    def relative_poses(self, pair_extrinsics):
+        """dataset.py:384-399 on the device (endo_relative_poses): pair_extrinsics (B,2,4,4) fp64 device tensor ->
+        rotations_1_wrt_2, rotations_2_wrt_1 (B,3,3), translations_1_wrt_2, translations_2_wrt_1 (B,3,1), fp32."""
+        if self.estimated_scale is None:
+            raise RuntimeError("SequenceScatter was built without estimated_scale")
+        ext = pair_extrinsics.to(device=self.device, dtype=torch.float64).reshape(-1, 2, 4, 4).contiguous()
+        batch = int(ext.shape[0])
+        opts = dict(dtype=torch.float32, device=self.device)
+        r12, r21 = torch.empty((batch, 3, 3), **opts), torch.empty((batch, 3, 3), **opts)
+        t12, t21 = torch.empty((batch, 3, 1), **opts), torch.empty((batch, 3, 1), **opts)
+        lib = _lib.load()
+        with torch.cuda.device(self.device):
+            rc = lib.endo_relative_poses(_lib.ptr(ext), batch, self.estimated_scale, _lib.ptr(r12), _lib.ptr(t12), _lib.ptr(r21),
+                                         _lib.ptr(t21), _lib.stream())
+        _lib.check(rc, "endo_relative_poses")
+        return r12, r21, t12, t21
+
+    def training_batch(self, positions):
+        """Everything of a training batch except the two colour images, built on the device from the resident sequence
+        (reference dataset.py:351-404, 419-430 for every sample of the batch): ``positions`` is a list of
+        ``(pos, increment)`` as ``utils.generating_pos_and_increment`` returns them.  Returns the 14 tensors
+        ``train_step.TrainingStep`` consumes besides ``colors_1`` / ``colors_2``, keyed as ``synthetic.BATCH_KEYS``; nothing is
+        copied from the host but the position list."""
+        if self.extrinsics is None or self.projections is None or self.intrinsics is None:
+            raise RuntimeError("SequenceScatter was built without extrinsics / projections / intrinsic_matrix")
+        first = torch.tensor([int(p) for p, _ in positions], dtype=torch.long, device=self.device)
+        second = torch.tensor([int(p) + int(inc) for p, inc in positions], dtype=torch.long, device=self.device)
+        batch = int(first.numel())
+        pair_ext = torch.stack([self.extrinsics[first], self.extrinsics[second]], dim=1)           # (B,2,4,4)
+        pair_proj = torch.stack([self.projections[first], self.projections[second]], dim=1)       # (B,2,3,4)
+        pair_idx = [[self.visible_view_indexes[int(p)], self.visible_view_indexes[int(p) + int(inc)]] for p, inc in positions]
+        planes = self.planes(pair_ext, pair_proj, pair_idx)
+        scale = torch.tensor(self.estimated_scale, dtype=torch.float32, device=self.device)
+        depths = planes["depths"] / scale          # dataset.py:391-392: float32 planes divided in place by the scale
+        r12, r21, t12, t21 = self.relative_poses(pair_ext)
+        return {"sparse_depths_1": depths[0], "sparse_depths_2": depths[1],
+                "sparse_depth_masks_1": planes["depth_masks"][0], "sparse_depth_masks_2": planes["depth_masks"][1],
+                "sparse_flows_1": planes["flows"][0], "sparse_flows_2": planes["flows"][1],
+                "sparse_flow_masks_1": planes["flow_masks"][0], "sparse_flow_masks_2": planes["flow_masks"][1],
+                "boundaries": self.boundary.expand(batch, 1, self.height, self.width).contiguous(),
+                "rotations_1_wrt_2": r12, "rotations_2_wrt_1": r21, "translations_1_wrt_2": t12, "translations_2_wrt_1": t21,
+                "intrinsics": self.intrinsics.reshape(1, 3, 3).expand(batch, 3, 3).contiguous()}
 
 
 def get_torch_training_data(pair_extrinsics, pair_projections, pair_indexes, point_cloud, mask_boundary,

@@ -32,6 +32,29 @@ def init_net(net, type="kaiming", mode="fan_in", activation_mode="relu", distrib
     return net
 
 
+def generating_pos_and_increment(idx, visible_view_indexes, adjacent_range):
+    """reference utils.py:412-438 (called dataset.py:346-350): position of the first frame of a training pair inside the
+    sequence's visible views and the signed gap to its partner, drawn from ``adjacent_range`` = (min gap, max gap) -- the
+    "adjacent range 5-30" of BASELINE.json configs[4].  Host-side pair selection: it consumes Python's ``random`` exactly as the
+    reference does (same calls in the same order), so a seeded run picks the same pairs."""
+    import random
+    visible_view_idx = idx % len(visible_view_indexes)
+    low, high = adjacent_range[0], adjacent_range[1]
+    count = len(visible_view_indexes)
+    if count <= 2 * low:
+        low = count // 2
+    if visible_view_idx <= low - 1:
+        increment = random.randint(low, min(high, count - 1 - visible_view_idx))
+    elif visible_view_idx >= count - low:
+        increment = -random.randint(low, min(high, visible_view_idx))
+    else:
+        if random.randint(0, 1) == 1:
+            increment = random.randint(low, min(high, count - 1 - visible_view_idx))
+        else:
+            increment = -random.randint(low, min(high, visible_view_idx))
+    return [visible_view_idx, increment]
+
+
 def save_model(model, optimizer, epoch, step, model_path, validation_loss, module_prefix=True):
     """reference utils.py:674-682 wire format {model, optimizer, epoch, step, validation}; keys carry
     the 'module.' prefix the reference's DataParallel wrapper adds (train.py:197)."""

@@ -219,6 +219,14 @@ int endo_sparse_scatter(const double* points, int n_points, const double* projec
                         float depth_multiplier, int32_t* winner_scratch, float* depth_masks, float* depths, float* flow_masks,
                         float* flows, void* stream);
 
+/* Relative camera motion of a batch of frame pairs -- reference dataset.py:384-399, on the device.
+ * pair_extrinsics [B][2][4][4] fp64 (world-to-camera of frame 1 and frame 2); scale = the sequence's estimated global scale.
+ * relative = E_1 inv(E_2) in fp64;  r_1_wrt_2 [B][3][3] = fp32(relative[:3,:3]);  t_1_wrt_2 [B][3] = fp32(relative[:3,3] / scale);
+ * r_2_wrt_1 = r_1_wrt_2^T;  t_2_wrt_1 = -r_1_wrt_2^T t_1_wrt_2 in fp32 -- the four pose tensors of a training batch, with no
+ * host arithmetic and no host-to-device copy per sample. */
+int endo_relative_poses(const double* pair_extrinsics, int batch, double scale,
+                        float* r_1_wrt_2, float* t_1_wrt_2, float* r_2_wrt_1, float* t_2_wrt_1, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Coloured point cloud of one depth map -- reference utils.py:823-852 (point_cloud_from_depth), the per-frame
  * back-projection of evaluate.py:272,340.  depth, mask [H][W] fp32; color_bgr [H][W][3] uint8 (cv2 order);

@@ -424,10 +424,28 @@ def point_cloud_case(ref, path):
     print("wrote", path, {k: v.shape for k, v in out.items()})
 
 
+def pair_selection_case(ref, path):
+    """utils.generating_pos_and_increment (utils.py:412-438) of the reference under seeded ``random``: for every configuration
+    (views in the sequence, adjacent range, seed) the (position, increment) it returns for idx = 0 .. 199."""
+    import random
+    rows = []
+    for views, low, high, seed in ((85, 5, 30, 1), (85, 1, 5, 2), (40, 5, 30, 3), (9, 5, 30, 4), (12, 1, 3, 5), (200, 10, 20, 6)):
+        visible = list(range(100, 100 + views))
+        random.seed(seed)
+        for idx in range(200):
+            pos, inc = ref["utils"].generating_pos_and_increment(idx=idx, visible_view_indexes=visible, adjacent_range=(low, high))
+            rows.append((views, low, high, seed, idx, pos, inc))
+    np.savez_compressed(path, table=np.array(rows, dtype=np.int64))
+    print("wrote", path, len(rows), "rows")
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
+    if "--pair-selection-only" in sys.argv:
+        pair_selection_case(ref, os.path.join(HERE, "pair_selection.npz"))
+        return
     if "--full-only" in sys.argv:          # the benchmark-size case alone (minutes of CPU, ~25 GB with the fp64 yardstick)
         train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
         return
@@ -441,6 +459,7 @@ def main():
     cyclic_lr_case(ref, os.path.join(HERE, "cyclic_lr.npz"))
     scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
     point_cloud_case(ref, os.path.join(HERE, "point_cloud.npz"))
+    pair_selection_case(ref, os.path.join(HERE, "pair_selection.npz"))
     train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
 
 

@@ -135,3 +135,53 @@ def test_shard_range():
     assert ea.distributed.shard_range(64, 3, 8) == (24, 32)
     with pytest.raises(ValueError):
         ea.distributed.shard_range(10, 0, 4)
+
+
+def test_pair_selection_matches_reference(pkg, golden):
+    """utils.generating_pos_and_increment against the table the reference produced under seeded ``random``
+    (tests/golden/make_golden.py: pair_selection_case) -- the same draws in the same order, so the same pairs."""
+    import random
+    table = golden("pair_selection.npz")["table"]
+    configs = []
+    for row in table:
+        key = tuple(int(v) for v in row[:4])
+        if key not in configs:
+            configs.append(key)
+    for views, low, high, seed in configs:
+        rows = [r for r in table if tuple(int(v) for v in r[:4]) == (views, low, high, seed)]
+        visible = list(range(100, 100 + views))
+        random.seed(seed)
+        for r in rows:
+            pos, inc = pkg.utils.generating_pos_and_increment(idx=int(r[4]), visible_view_indexes=visible, adjacent_range=(low, high))
+            assert (pos, inc) == (int(r[5]), int(r[6])), (views, low, high, seed, int(r[4]))
+            assert 0 <= pos + inc < views and (abs(inc) >= min(low, views // 2))
+
+
+def test_oracle_relative_poses_identities():
+    """oracle/poses.py (numpy restatement of dataset.py:384-399): R_2wrt1 R_1wrt2 = I, the translation round trip, and a
+    hand-computed case (pure translation between two axis-aligned cameras)."""
+    import numpy as np
+    from oracle import poses
+    rng = np.random.default_rng(3)
+
+    def rigid():
+        q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        e = np.eye(4)
+        e[:3, :3] = q
+        e[:3, 3] = rng.standard_normal(3)
+        return e
+    for _ in range(5):
+        e1, e2 = rigid(), rigid()
+        r12, r21, t12, t21 = poses.relative_poses(e1, e2, 2.5)
+        assert r12.dtype == np.float32 and t21.shape == (3, 1)
+        assert np.abs(r21 @ r12 - np.eye(3)).max() < 1e-6
+        assert np.abs(r12 @ t21 + t12).max() < 1e-6
+    e1, e2 = np.eye(4), np.eye(4)
+    e1[:3, 3] = [1.0, 2.0, 3.0]
+    r12, r21, t12, t21 = poses.relative_poses(e1, e2, 2.0)
+    assert np.array_equal(r12, np.eye(3, dtype=np.float32)) and np.array_equal(t12.reshape(-1), np.float32([0.5, 1.0, 1.5]))
+    assert np.array_equal(t21.reshape(-1), np.float32([-0.5, -1.0, -1.5]))
+    mask = np.array([[0, 255, 229], [230, 128, 255]], dtype=np.uint8)
+    assert np.array_equal(poses.boundary_plane(mask), np.float32([[0, 1, 0], [1, 0, 1]]))

@@ -584,6 +584,48 @@ def test_train_step_golden(golden):
         np.testing.assert_allclose(norms, g[tag + "param_norms"], rtol=1e-4, atol=1e-5)
 
 
+def test_level1_dropin_stock_optimizer(golden):
+    """INTEGRATION.md level 1: the new modules under the reference's OWN optimizer calls -- torch.optim.SGD(momentum 0.9),
+    optimizer.zero_grad() (set_to_none, which detaches the .grad views), loss.backward(), clip_grad_norm_(parameters, 10),
+    optimizer.step() (reference train.py:202, 323-328) -- against the two reference iterations of train_step_2x64x96.npz,
+    and against FusedClipSGD on a twin model (the parameters of the two optimizers must agree after each step)."""
+    g = golden("train_step_2x64x96.npz")
+    n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(seed), seed + 1))
+
+    def build():
+        m = ea.FCDenseNet57(1)
+        m.load_state_dict(state)
+        return m.to(dev()).train()
+    model, twin = build(), build()
+    stock = torch.optim.SGD(model.parameters(), lr=float(g["max_lr"]), momentum=0.9)
+    sched = ea.scheduler.CyclicLR(stock, base_lr=float(g["base_lr"]), max_lr=float(g["max_lr"]), step_size=int(g["step_size"]))
+    fused = ea.optim.FusedClipSGD(twin, lr=float(g["max_lr"]))
+    fused_sched = ea.scheduler.CyclicLR(fused, base_lr=float(g["base_lr"]), max_lr=float(g["max_lr"]), step_size=int(g["step_size"]))
+    step = ea.train_step.TrainingStep(model, fused, h, w)          # only its losses(): the optimizer calls below are the reference's
+    twin_step = ea.train_step.TrainingStep(twin, fused, h, w)
+    for it in range(2):
+        batch = to_dev(synthetic.make_batch(n, h, w, seed=seed + 10 + it, sparse_points=min(500, h * w // 6)))
+        sched.batch_step(batch_iteration=it)
+        fused_sched.batch_step(batch_iteration=it)
+        loss, _, _, _ = step.losses(batch)
+        stock.zero_grad()                                           # torch >= 2.0: .grad = None for every parameter
+        loss.backward()
+        assert all(p.grad is not None for p in model.parameters())
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 10.0)
+        stock.step()
+        out = twin_step(batch)
+        tag = "step%d_" % it
+        tol = 1e-4 if it == 0 else 1e-3          # see test_train_step_vs_oracle
+        assert abs(float(loss) - float(g[tag + "loss"])) <= tol * abs(float(g[tag + "loss"]))
+        assert_close(gnorm, torch.from_numpy(g[tag + "grad_norm"]), 5e-3, "grad norm (stock clip_grad_norm_)")
+        assert_close(gnorm, out["grad_norm"], 1e-5, "grad norm, stock vs fused")
+        norms = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+        np.testing.assert_allclose(norms, g[tag + "param_norms"], rtol=1e-4, atol=1e-5)
+        assert_close(model.flat_parameters(), twin.flat_parameters(), 1e-6, "parameters after iteration %d, stock vs fused optimizer" % it)
+        assert model._views_intact()
+
+
 def test_nonfinite_guard():
     n, h, w = 1, 32, 32
     _, model = make_model(54)

@@ -126,3 +126,58 @@ def test_point_cloud_golden_and_oracle(pkg, golden):
         np.testing.assert_array_equal(got, want, err_msg="downsampling %d" % ds)
     empty = pkg.utils.point_cloud_from_depth(depth, color, np.zeros_like(mask), k, 1)
     assert empty.shape == (0, 6)
+
+
+def test_training_batch_on_device(pkg, golden):
+    """SequenceScatter.training_batch: the 14 non-image tensors of a training batch assembled on the device from the resident
+    example sequence -- sparse planes as the reference fixture (depths divided by the sequence's scale as dataset.py:391-392
+    does, in fp32), relative poses bit-exact against oracle/poses.py (numpy restatement of dataset.py:384-399), boundary
+    plane and intrinsics as dataset.py:421-430 -- and a TrainingStep consumes them as they are."""
+    from oracle import poses as oposes
+    g = golden("scatter_example.npz")
+    n_pairs = len(g["pairs"])
+    vis = np.concatenate([g["pair%d_visibility" % i] for i in range(n_pairs)], axis=1)
+    ext = np.concatenate([g["pair%d_extrinsics" % i] for i in range(n_pairs)])           # views: a0, b0, a1, b1, ...
+    proj = np.concatenate([g["pair%d_projections" % i] for i in range(n_pairs)])
+    scale = float(g["scale"])
+    seq = pkg.scatter.SequenceScatter(g["points"], g["mask"], vis, g["clean"], list(range(2 * n_pairs)), extrinsics=ext,
+                                      projections=proj, intrinsic_matrix=g["intrinsics"], estimated_scale=scale)
+    positions = [(2 * i, 1) for i in range(n_pairs)]
+    batch = seq.training_batch(positions)
+    torch.cuda.synchronize()
+    assert sorted(batch) == sorted(k for k in pkg.synthetic.BATCH_KEYS if not k.startswith("colors"))
+    h, w = seq.height, seq.width
+    for i in range(n_pairs):
+        tag = "pair%d_" % i
+        want_depth = _dense(g, tag, "depths")
+        want_depth /= scale                                              # float32 array /= python float, as the reference
+        for f, sfx in ((0, "_1"), (1, "_2")):
+            np.testing.assert_array_equal(batch["sparse_depths" + sfx][i, 0].cpu().numpy(), want_depth[f, :, :, 0])
+            np.testing.assert_array_equal(batch["sparse_depth_masks" + sfx][i, 0].cpu().numpy(), _dense(g, tag, "depth_masks")[f, :, :, 0])
+            np.testing.assert_array_equal(batch["sparse_flow_masks" + sfx][i, 0].cpu().numpy(), _dense(g, tag, "flow_masks")[f, :, :, 0])
+            np.testing.assert_array_equal(batch["sparse_flows" + sfx][i].permute(1, 2, 0).cpu().numpy(), _dense(g, tag, "flows")[f])
+        r12, r21, t12, t21 = oposes.relative_poses(ext[2 * i], ext[2 * i + 1], scale)
+        np.testing.assert_array_equal(batch["rotations_1_wrt_2"][i].cpu().numpy(), r12)
+        np.testing.assert_array_equal(batch["rotations_2_wrt_1"][i].cpu().numpy(), r21)
+        np.testing.assert_array_equal(batch["translations_1_wrt_2"][i].cpu().numpy(), t12)
+        got_t21 = batch["translations_2_wrt_1"][i].cpu().numpy()
+        # the last product is a float32 3x3 . 3x1 whose summation order / fusion BLAS is free to choose: one ulp
+        assert np.abs(got_t21 - t21).max() <= 1.2e-7 * max(np.abs(t21).max(), 1e-30), (got_t21, t21)
+    np.testing.assert_array_equal(batch["boundaries"][0, 0].cpu().numpy(), oposes.boundary_plane(g["mask"]))
+    np.testing.assert_array_equal(batch["intrinsics"][1].cpu().numpy(), np.asarray(g["intrinsics"])[:3, :3].astype(np.float32))
+    assert batch["boundaries"].shape == (n_pairs, 1, h, w) and batch["translations_2_wrt_1"].shape == (n_pairs, 3, 1)
+    # straight into a training step (the example frames are 256 x 320)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    model = pkg.models.FCDenseNet57(1)
+    pkg.utils.kaiming_weight_zero_bias(model, distribution="normal")
+    with torch.no_grad():
+        model.finalConv.bias.add_(4.0)
+    model = model.to(dev).train()
+    opt = pkg.optim.FusedClipSGD(model, lr=1.0e-4)
+    step = pkg.train_step.TrainingStep(model, opt, h, w)
+    gen = torch.Generator(device=dev).manual_seed(2)
+    batch["colors_1"] = torch.rand(n_pairs, 3, h, w, device=dev, generator=gen) * 2 - 1
+    batch["colors_2"] = torch.rand(n_pairs, 3, h, w, device=dev, generator=gen) * 2 - 1
+    out = step(batch)
+    assert not out["skipped"] and np.isfinite(out["loss"]) and float(out["grad_norm"]) > 0.0
