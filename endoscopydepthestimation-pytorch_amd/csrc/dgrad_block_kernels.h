@@ -52,13 +52,18 @@ struct DgradBlockParams {
     int64_t gs;
 };
 
-template <int NL, int WX, int R, int GP>
+// VEC = 4: the G tile starts 4 pixels left of the output tile so that its rows are whole aligned float4s and arrive by 16-byte
+// LDS-DMA (4x fewer DMA instructions: the tile load is most of a new-channel pass, which runs only NL steps on it).
+template <int NL, int WX, int R, int GP, int VEC = 1>
 struct DgradBlockGeom {
     static constexpr int kTileX = 16 * WX;
     static constexpr int kTileY = R * (4 / WX);
     static constexpr int kRows = kTileY + 2;
-    static constexpr int kCols = kTileX + 2;
+    static constexpr int kLeft = VEC == 4 ? 4 : 1;
+    static constexpr int kCols = kTileX + 2 * kLeft;
+    static constexpr int kColOff = kLeft - 1;          // fragment column = x - x0 + dx + kColOff
     static constexpr int kPlane = kRows * kCols;
+    static constexpr int kUnits = kPlane / VEC;
     static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;
     static constexpr int kPos = (kPlane + kConvThreads - 1) / kConvThreads;
     static constexpr int kNB = 16 * GP;                 // output channels per step
@@ -74,9 +79,9 @@ struct DgradBlockGeom {
 // the library instantiates GP = 1.
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x / dbuf loads, 2 = no stores,
 // 4 = weight slice loaded once, 8 = no BN-sum reduction, 16 = no dY tile load, 32 = epilogue reduced to an add
-template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1>
+template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1, int VEC = 1>
 __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBlockParams p0) {
-    using G = DgradBlockGeom<NL, WX, R, GP>;
+    using G = DgradBlockGeom<NL, WX, R, GP, VEC>;
     const int grp = p0.group_n > 0 ? blockIdx.z / p0.group_n : 0;
     const int n = blockIdx.z - grp * p0.group_n;
     const DgradBlockParams& p = p0;
@@ -106,8 +111,29 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
     if (gs_begin >= gs_end) return;
     const int nsteps = (gs_end - gs_begin) * NL;
 
-    // ---- G tiles: NL*12 maps with a 1-pixel halo, dword DMA (once per block) ----
-    {
+    // ---- G tiles: NL*12 maps with a 1-pixel halo (once per block) ----
+    if constexpr (VEC == 4) {
+        // 16-byte DMA: a map is kUnits float4 units; wave w takes maps w, w + 4, ...: one full instruction (64 units) and one for
+        // the rest of the map, each writing contiguous LDS
+        static_assert(G::kUnits > 64 && G::kUnits <= 128, "two DMA instructions per map");
+        int off[2];
+        bool ok[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int u = lane + 64 * k;
+            const int ry = u / (G::kCols / 4), rx = (u - ry * (G::kCols / 4)) * 4;
+            const int gy = y0 - 1 + ry, gx = x0 - G::kLeft + rx;
+            ok[k] = u < G::kUnits && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;          // W % 4 == 0: a unit is all in or all out
+            off[k] = ok[k] ? gy * p.g_w + gx : 0;
+        }
+        const float* g_n = p.g + grp_off + n * p.g_ns;
+        for (int c = wave; c < ((EXP & 16) ? 0 : NL * 12); c += 4) {
+            const float* plane = g_n + static_cast<int64_t>(c) * p.g_cs;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ok[0] ? plane + off[0] : g_pad_consts + 4), (lptr_t)(s_g + c * G::kCS), 16, 0, 0);
+            if (lane + 64 < G::kUnits)
+                __builtin_amdgcn_global_load_lds((gptr_t)(ok[1] ? plane + off[1] : g_pad_consts + 4), (lptr_t)(s_g + c * G::kCS + 256), 16, 0, 0);
+        }
+    } else {
         int goff[G::kPos];
         unsigned ok = 0;
 #pragma unroll
@@ -252,7 +278,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
             // before the 3 MFMAs that use it and stalls on lgkmcnt(0) every ~100 cycles)
             float av[2][3][R + 2], bw[2][9][GP];
             auto load_quad = [&](int quad, int set) {
-                const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
+                const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li + G::kColOff;
                 const float* b_base = wb + (quad * 4 + lk) * G::kNB + li;
 #pragma unroll
                 for (int r = 0; r < R + 2; ++r)
@@ -285,7 +311,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
         } else {
 #pragma unroll
         for (int quad = 0; quad < 3; ++quad) {
-            const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li;
+            const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li + G::kColOff;
             const float* b_base = wb + (quad * 4 + lk) * G::kNB + li;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
@@ -365,14 +391,14 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
     if (po_gs >= 0) store_pending();
 }
 
-template <int NL, int WX, int R, int GP = 1, int EXP = 0, int PIPE = 1>
+template <int NL, int WX, int R, int GP = 1, int EXP = 0, int PIPE = 1, int VEC = 1>
 inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
-    using G = DgradBlockGeom<NL, WX, R, GP>;
+    using G = DgradBlockGeom<NL, WX, R, GP, VEC>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     static bool configured = false;
     if (!configured && G::kBytes > 48 * 1024) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
@@ -382,7 +408,7 @@ inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
     int ysplit = (768 + tiles - 1) / tiles;
     if (ysplit > gsets) ysplit = gsets;
     if (ysplit < 1) ysplit = 1;
-    dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), kConvThreads, G::kBytes, stream>>>(p);
+    dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), kConvThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -630,6 +656,11 @@ inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
     dgrad_block8_kernel<NL><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), G::kThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
+}
+
+// 16-byte DMA of the G tile: float4-aligned rows of the gradient maps
+inline bool dgrad_block_vec_ok(const DgradBlockParams& p) {
+    return (p.g_w % 4 == 0) && (p.g_cs % 4 == 0) && (p.g_ns % 4 == 0) && (p.gs % 4 == 0) && (reinterpret_cast<uintptr_t>(p.g) % 16 == 0);
 }
 
 // float4 epilogue: W % 4 == 0 and 16-byte aligned planes

@@ -24,6 +24,7 @@
 #include "wgrad_nsplit_kernels.h"
 #include "wgrad_subpix_kernels.h"
 #include "wino_fwd_kernels.h"
+#include "dgrad_wino_kernels.h"
 
 #include <cstdlib>
 
@@ -39,7 +40,7 @@ constexpr float kBnMomentum = 0.1f;
 constexpr int kSideStreamFromLevel = 0;      // weight gradients of levels >= this run on the side stream (in-job A/B: 0 -> -4.7 %, 1 -> -3 %, 2 -> -1.8 % step time)
 static int g_wgrad_overlap = 1;              // endo_set_wgrad_overlap: 0 = weight gradients in line on the caller's stream
 
-struct ConvP { int64_t w, b; int cout, cin, ks; int64_t u; };      // u: offset of the layer's Winograd-domain weights (dense layers), floats
+struct ConvP { int64_t w, b; int cout, cin, ks; int64_t u; int64_t ud; };      // u / ud: offsets of the layer's Winograd-domain forward / data-gradient weights (dense layers), floats
 struct BnP { int64_t g, b; int c; int64_t run; int64_t saved; };   // run: offset in bn_running; saved: offset (pairs) in saved/scratch
 
 struct Table {
@@ -51,6 +52,8 @@ struct Table {
     int64_t param_floats = 0, bn_floats = 0, bn_width_total = 0;
     WinoWeightTable wino;                 // the 44 dense layers' forward weights in Winograd form (wino_fwd_kernels.h)
     int64_t wino_floats = 0;
+    WinoDgradTable wino_dgrad;            // and their data-gradient weights over the base channels of their block (dgrad_wino_kernels.h)
+    int64_t wino_dgrad_floats = 0;
 };
 
 inline int down_in(int level) { return kFirst + kNew * level; }          // C_L
@@ -61,7 +64,7 @@ static const Table& table() {
         Table* tb = new Table();
         int64_t off = 0;
         auto conv = [&](ConvP& c, int cout, int cin, int ks) {
-            c.cout = cout; c.cin = cin; c.ks = ks; c.u = -1;
+            c.cout = cout; c.cin = cin; c.ks = ks; c.u = -1; c.ud = -1;
             c.w = off; tb->param_offsets.push_back(off); off += static_cast<int64_t>(cout) * cin * ks * ks;
             c.b = off; tb->param_offsets.push_back(off); off += cout;
         };
@@ -104,6 +107,22 @@ static const Table& table() {
             for (int i = 0; i < kLevels; ++i) for (int j = 0; j < kLayers; ++j) add(tb->up_conv[i][j]);
             tb->wino_floats = uoff;
         }
+        {   // data-gradient weights in Winograd form: per dense block, the 16-channel groups of its base channels, for each of its layers
+            WinoDgradTable& wd = tb->wino_dgrad;
+            wd.layers = 0; wd.start[0] = 0;
+            int64_t uoff = 0;
+            auto add = [&](ConvP& c, int base) {
+                const int l = wd.layers++;
+                c.ud = uoff;
+                wd.cin[l] = c.cin; wd.groups[l] = base / 16; wd.w_off[l] = c.w; wd.u_off[l] = uoff;
+                wd.start[l + 1] = wd.start[l] + 16 * wd.groups[l] * 12;
+                uoff += static_cast<int64_t>(wd.groups[l]) * kWinoDgradSlice;
+            };
+            for (int l = 0; l < kLevels; ++l) for (int j = 0; j < kLayers; ++j) add(tb->down_conv[l][j], down_in(l));
+            for (int j = 0; j < kLayers; ++j) add(tb->bott_conv[j], 288);
+            for (int i = 0; i < kLevels; ++i) for (int j = 0; j < kLayers; ++j) add(tb->up_conv[i][j], 96 + down_in(kLevels - 1 - i));
+            tb->wino_dgrad_floats = uoff;
+        }
         return tb;
     }();
     return *t;
@@ -132,6 +151,7 @@ struct endo_net {
     int64_t scratch_bytes;
     int64_t wg_scratch_off;   // float offset in gradws of the weight-gradient partial sums (wgrad_nsplit_kernels.h)
     int64_t tuw_scratch_off;  // float offset in gradws of the transition-up data-gradient weights (tu_subpix_dgrad_weights_kernel)
+    int64_t wd_off;           // float offset in gradws of the Winograd-domain data-gradient weights (group 0's copy serves all groups)
     int64_t gradws_floats;
     // Weight gradients run on a side stream: a layer's wgrad depends only on its prepared dY and the forward tape, nothing on the
     // backward chain depends on it (it only adds into the flat gradient), so it overlaps the data-gradient chain -- which at the
@@ -514,13 +534,30 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
     return 2.0 * net->n * net->groups * net->lv[level].plane * cin * cout * ks * ks;
 }
 
-// ENDO_WINO_FWD=0 keeps the dense-layer forward on the direct convolution (A/B runs of the two forms inside one job)
-// (2 = 32 x 8 tiles at every eligible level)
-static int wino_fwd_mode() {
-    static const int mode = [] { const char* e = std::getenv("ENDO_WINO_FWD"); return e ? std::atoi(e) : 1; }();
-    return mode;
+// Tuning options (endo_set_option; defaults from the environment at first use, for in-job A/B runs of one build):
+//   ENDO_OPT_WINO_FWD    / ENDO_WINO_FWD     dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd (2 LDS stages),
+//                                            3 / 4 = Winograd with 3 / 4 stages
+//   ENDO_OPT_WINO_DGRAD  / ENDO_WINO_DGRAD   fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd
+//   ENDO_OPT_DGRAD_VEC   / ENDO_DGRAD_VEC    new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
+//   ENDO_OPT_WINO_MIN_TILES / ENDO_WINO_MIN_TILES   a Winograd kernel is used from this many tiles per launch on (default 1024: the
+//                                            levels whose launches fill the chip several times; tests set 1 to reach the kernels at small sizes)
+static int g_options[ENDO_OPT_COUNT];
+static bool g_options_init = false;
+static int option(int id) {
+    if (!g_options_init) {
+        auto env = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+        g_options[ENDO_OPT_WINO_FWD] = env("ENDO_WINO_FWD", 1);
+        g_options[ENDO_OPT_WINO_DGRAD] = env("ENDO_WINO_DGRAD", 1);
+        g_options[ENDO_OPT_DGRAD_VEC] = env("ENDO_DGRAD_VEC", 1);
+        g_options[ENDO_OPT_WINO_MIN_TILES] = env("ENDO_WINO_MIN_TILES", 1024);
+        g_options_init = true;
+    }
+    return g_options[id];
 }
+static int wino_fwd_mode() { return option(ENDO_OPT_WINO_FWD); }
 static bool wino_fwd_enabled() { return wino_fwd_mode() != 0; }
+static bool wino_dgrad_enabled() { return option(ENDO_OPT_WINO_DGRAD) != 0; }
+static bool dgrad_vec_enabled() { return option(ENDO_OPT_DGRAD_VEC) != 0; }
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
@@ -543,34 +580,31 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         const long t8 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
         if (wino_fwd_ok(pw)) {
             const int mode = wino_fwd_mode();          // in-job A/B: 1 = 2 LDS stages (default), 3 = 3 stages, 4 = 4 stages
+            const long min_tiles = option(ENDO_OPT_WINO_MIN_TILES);
+            const bool big = t16 >= min_tiles, small = t8 >= (min_tiles * 3) / 4;
             if (mode == 4) {
-                if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 4>(pw, c.stream);
-                if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 4>(pw, c.stream);
+                if (big) return launch_wino_fwd<2, 4, 2, 4>(pw, c.stream);
+                if (small) return launch_wino_fwd<1, 4, 3, 4>(pw, c.stream);
             }
             if (mode == 3) {
-                if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 3>(pw, c.stream);
-                if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 3>(pw, c.stream);
+                if (big) return launch_wino_fwd<2, 4, 2, 3>(pw, c.stream);
+                if (small) return launch_wino_fwd<1, 4, 3, 3>(pw, c.stream);
             }
 #ifdef ENDO_WINO_DIAG          // stub-out timing variants of the level-0 kernel (wrong results): -DENDO_WINO_DIAG, ENDO_WINO_EXP=<mask>
-            if (t16 >= 1024) {
+            if (big) {
                 static const int exp = [] { const char* e = std::getenv("ENDO_WINO_EXP"); return e ? std::atoi(e) : 0; }();
                 switch (exp) {
-                    case 1: return launch_wino_fwd<2, 4, 2, 2, 1>(pw, c.stream);
-                    case 2: return launch_wino_fwd<2, 4, 2, 2, 2>(pw, c.stream);
-                    case 6: return launch_wino_fwd<2, 4, 2, 2, 6>(pw, c.stream);
                     case 14: return launch_wino_fwd<2, 4, 2, 2, 14>(pw, c.stream);
                     case 30: return launch_wino_fwd<2, 4, 2, 2, 30>(pw, c.stream);
                     case 31: return launch_wino_fwd<2, 4, 2, 2, 31>(pw, c.stream);
                     case 63: return launch_wino_fwd<2, 4, 2, 2, 63>(pw, c.stream);
-                    case 33: return launch_wino_fwd<2, 4, 2, 2, 33>(pw, c.stream);
                     case 64: return launch_wino_fwd<2, 4, 2, 2, 64>(pw, c.stream);
-                    case 65: return launch_wino_fwd<2, 4, 2, 2, 65>(pw, c.stream);
                     default: break;
                 }
             }
 #endif
-            if (t16 >= 1024) return launch_wino_fwd<2, 4, 2, 2>(pw, c.stream);
-            if (t8 >= 768) return launch_wino_fwd<1, 4, 3, 2>(pw, c.stream);
+            if (big) return launch_wino_fwd<2, 4, 2, 2>(pw, c.stream);
+            if (small) return launch_wino_fwd<1, 4, 3, 2>(pw, c.stream);
         }
     }
     // Coarse levels have too few 16x8 tiles to fill 256 CUs and a long K loop (Cin up to 372): slice K over
@@ -808,8 +842,12 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             {
                 ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * kGrowth * kGrowth * 9 * nl,
                                4.0 * c.nt() * lv.plane * (3.0 * kGrowth + kGrowth * nl));
-                rc = nl == 1 ? launch_dgrad_block<1, 2, 3>(p, c.stream)
-                   : nl == 2 ? launch_dgrad_block<2, 2, 3>(p, c.stream) : launch_dgrad_block<3, 2, 3>(p, c.stream);
+                if (dgrad_block_vec_ok(p) && dgrad_vec_enabled())
+                    rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4>(p, c.stream)
+                       : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4>(p, c.stream);
+                else
+                    rc = nl == 1 ? launch_dgrad_block<1, 2, 3>(p, c.stream)
+                       : nl == 2 ? launch_dgrad_block<2, 2, 3>(p, c.stream) : launch_dgrad_block<3, 2, 3>(p, c.stream);
                 if (rc) return rc;
             }
             pending = a;          // consumed by the prep_dy of these 12 maps at the top of the next iteration
@@ -832,7 +870,16 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         }
         ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * c0 * kGrowth * 9 * kLayers,
                        4.0 * c.nt() * lv.plane * (3.0 * c0 + kGrowth * kLayers));
-        int rc = launch_dgrad_block8<4>(p, c.stream);       // 512-thread blocks: +15 % over the 4-wave kernel (tools/conv_bench)
+        int rc;
+        const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
+        if (wino_dgrad_enabled() && dgrad_wino_ok(p) && wtiles >= option(ENDO_OPT_WINO_MIN_TILES) && cv[0].ud >= 0) {
+            // fine levels: Winograd F(2x2, 3x3), 48 instead of 108 MFMAs per 64 pixels and step (dgrad_wino_kernels.h)
+            const float* ub = c.gradws + c.net->wd_off;
+            const float* const u[4] = {ub + cv[0].ud, ub + cv[1].ud, ub + cv[2].ud, ub + cv[3].ud};
+            rc = launch_dgrad_wino8<4>(p, u, c.stream);
+        } else {
+            rc = launch_dgrad_block8<4>(p, c.stream);       // 512-thread blocks: +15 % over the 4-wave kernel (tools/conv_bench)
+        }
         if (rc) return rc;
     }
     {
@@ -983,7 +1030,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->scratch_bytes = tb.bn_width_total * 2 * 8;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
     net->tuw_scratch_off = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
-    net->gradws_floats = net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16);
+    net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
+    net->gradws_floats = net->wd_off + tb.wino_dgrad_floats;
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
@@ -996,6 +1044,13 @@ extern "C" int endo_net_create(endo_net** out, int n, int h, int w) { return end
 extern "C" int endo_set_wgrad_overlap(int enable) {
     const int old = g_wgrad_overlap;
     g_wgrad_overlap = enable ? 1 : 0;
+    return old;
+}
+
+extern "C" int endo_set_option(int option_id, int value) {
+    if (option_id < 0 || option_id >= ENDO_OPT_COUNT) return -1;
+    const int old = option(option_id);
+    g_options[option_id] = value;
     return old;
 }
 
@@ -1115,6 +1170,12 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(gradws + g * net->gs + net->pq_off, 0,
                                   static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
+    if (wino_dgrad_enabled()) {          // data-gradient weights of the dense layers in Winograd form, one launch
+        ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * 2.0 * tb.wino_dgrad_floats);
+        dgrad_wino_weights_kernel<<<(tb.wino_dgrad.start[tb.wino_dgrad.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino_dgrad, params,
+                                                                                                                 gradws + net->wd_off);
+        ENDO_LAUNCH_CHECK();
+    }
     int rc;
     {
         const auto& lv = net->lv[0];

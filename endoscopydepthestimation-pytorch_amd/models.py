@@ -347,6 +347,17 @@ class FCDenseNet(nn.Module):
         n = x1.shape[0]
         return out[:n], out[n:]
 
+    def forward_pair_packed(self, x1, x2):
+        """``forward_pair`` returning ONE tensor of 2N samples (frame 1's predictions first): the caller that differentiates
+        both halves at once (``train_step.TrainingStep``'s fused loss head) hands back one gradient tensor instead of having
+        autograd assemble it from two slices."""
+        if x1.shape != x2.shape:
+            raise RuntimeError("forward_pair needs two batches of the same shape")
+        x = torch.cat([_lib.dev_f32(x1, "FCDenseNet57 input"), _lib.dev_f32(x2, "FCDenseNet57 input")], dim=0)
+        if torch.is_grad_enabled():
+            return _NetFunction.apply(x, self._anchor, self, 2)
+        return self._run_forward(x, 2)[0]
+
     def level_buffers(self, x):
         """Debug/test hook: run a forward and return the six level buffers (views of the tape)."""
         lib = _lib.load()

@@ -44,8 +44,14 @@ def mask_mul(a, mask):
 
 
 class TrainingStep(object):
-    def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8, pair_forward=True):
+    def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8, pair_forward=True,
+                 fused_head=True):
         self.model = model
+        self.epsilon = float(epsilon)
+        # everything between the network outputs and d loss / d prediction as one library call (endo_loss_head: the modules'
+        # kernels, composed in C) instead of ~60 autograd nodes; needs the grouped pair forward
+        self.fused_head = bool(fused_head) and bool(pair_forward) and hasattr(model, "forward_pair_packed")
+        self._head_ws = None
         # both frames of the pair through the network as one grouped batch (FCDenseNet.forward_pair): same values as the
         # reference's two calls (train.py:276-277), half the kernel launches
         self.pair_forward = bool(pair_forward) and hasattr(model, "forward_pair")
@@ -99,10 +105,52 @@ class TrainingStep(object):
                   "std_1": std_1, "std_2": std_2}
         return dcl + sfl, dcl, sfl, extras
 
+    def _fused_iteration(self, batch):
+        """Network forward (autograd on) -> endo_loss_head (loss values and d loss / d prediction) -> the caller's guard ->
+        network backward with that gradient.  Returns (loss value, dcl, sfl tensors, backward closure)."""
+        lib = _lib.load()
+        b = _lib.dev_f32(batch["boundaries"], "boundaries")
+        colors_1 = mask_mul(batch["colors_1"], b)
+        colors_2 = mask_mul(batch["colors_2"], b)
+        pred = self.model.forward_pair_packed(colors_1, colors_2)          # (2N, 1, H, W)
+        n, _, h, w = colors_1.shape
+        need = int(lib.endo_loss_head_workspace_floats(n, h, w))
+        if self._head_ws is None or self._head_ws.numel() < need or self._head_ws.device != pred.device:
+            self._head_ws = torch.empty(need, dtype=torch.float32, device=pred.device)
+        losses_t = torch.empty(3, dtype=torch.float32, device=pred.device)
+        grad_pred = torch.empty_like(pred)
+        f = lambda key: _lib.ptr(_lib.dev_f32(batch[key], key))
+        pose = lambda key, cols: _lib.ptr(_lib.dev_f32(batch[key], key).reshape(n, cols))
+        with torch.no_grad():
+            p = pred.detach()
+            _lib.check(lib.endo_loss_head(
+                _lib.ptr(p[:n]), _lib.ptr(p[n:]), _lib.ptr(b), f("sparse_depths_1"), f("sparse_depths_2"),
+                f("sparse_depth_masks_1"), f("sparse_depth_masks_2"), f("sparse_flows_1"), f("sparse_flows_2"),
+                f("sparse_flow_masks_1"), f("sparse_flow_masks_2"), pose("translations_1_wrt_2", 3), pose("rotations_1_wrt_2", 9),
+                pose("translations_2_wrt_1", 3), pose("rotations_2_wrt_1", 9), pose("intrinsics", 9),
+                self.sfl_weight, self.dcl_weight, self.epsilon, _lib.ptr(losses_t), _lib.ptr(grad_pred[:n]), _lib.ptr(grad_pred[n:]),
+                _lib.ptr(self._head_ws), n, h, w, _lib.stream()), "endo_loss_head")
+        return losses_t, pred, grad_pred
+
     def __call__(self, batch, lr=None):
         if lr is not None:
             for group in self.optimizer.param_groups:
                 group["lr"] = lr
+        if self.fused_head:
+            losses_t, pred, grad_pred = self._fused_iteration(batch)
+            host = losses_t.tolist()                  # the reference syncs here too (train.py:317)
+            value = host[0]
+            bad = math.isnan(value) or math.isinf(value)
+            if distributed.world_size() > 1:
+                flag = torch.tensor([1.0 if bad else 0.0], device=pred.device)
+                bad = bool(distributed.agree_nonfinite(flag).item() > 0)
+            self.optimizer.zero_grad()
+            if bad:
+                return {"loss": value, "dcl": float("nan"), "sfl": float("nan"), "skipped": True}
+            pred.backward(grad_pred)
+            scale = self.bucket.all_reduce()
+            norm = self.optimizer.step(grad_scale=scale)
+            return {"loss": value, "dcl": losses_t[1], "sfl": losses_t[2], "grad_norm": norm, "skipped": False}
         loss, dcl, sfl, _ = self.losses(batch)
         value = loss.item()                       # the reference syncs here too (train.py:317)
         bad = math.isnan(value) or math.isinf(value)

@@ -122,6 +122,27 @@ int endo_scale_inv_bwd(const float* grad_loss, const float* pred, const float* g
                        float* grad_pred, float* grad_goal, int n, int hw, float eps, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The loss head of a training iteration in one call -- reference train.py:279-315 (depth scaling, flow from depth, boundary
+ * masking, sparse-flow loss, depth warping both ways, depth-consistency loss, weighted sum) AND its backward down to
+ * d loss / d prediction, composed from the entry points above (same kernels, same arithmetic; the modules remain for callers
+ * that want the pieces).  pred_*: n x 1 x H x W network outputs; the other inputs are the batch tensors of train.py:245-270
+ * (sparse flows n x 2 x H x W; t n x 3, R / K n x 9).  losses: 3 fp32 on the device = total, depth-consistency, sparse-flow
+ * (weights applied: w * 0.5 * (term_1 + term_2)).  grad_pred_*: n x 1 x H x W, written.  workspace: 16-byte aligned,
+ * endo_loss_head_workspace_floats(n, h, w) floats.  The caller reads losses[0] for the non-finite guard (train.py:317) and
+ * then feeds grad_pred_* to endo_net_bwd.
+ * ------------------------------------------------------------------------------------------- */
+int64_t endo_loss_head_workspace_floats(int n, int h, int w);
+int endo_loss_head(const float* pred_1, const float* pred_2, const float* boundaries,
+                   const float* sparse_depths_1, const float* sparse_depths_2,
+                   const float* sparse_depth_masks_1, const float* sparse_depth_masks_2,
+                   const float* sparse_flows_1, const float* sparse_flows_2,
+                   const float* sparse_flow_masks_1, const float* sparse_flow_masks_2,
+                   const float* t_1_wrt_2, const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1,
+                   const float* intrinsics, float sfl_weight, float dcl_weight, float eps,
+                   float* losses, float* grad_pred_1, float* grad_pred_2, float* workspace,
+                   int n, int h, int w, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * train.py glue that is pure elementwise work between the modules
  *   endo_mask_mul: out[n,c,hw] = a[n,c,hw] * mask[n,0,hw]   (train.py:272-273, 293-298)
  * ------------------------------------------------------------------------------------------- */
@@ -155,6 +176,19 @@ int endo_net_groups(const endo_net* net);
  * before it returns.  0 puts them back in line on the caller's stream (clean per-kernel timings);
  * returns the previous setting.  Process-wide. */
 int endo_set_wgrad_overlap(int enable);
+/* Kernel-selection options, process-wide like the above; defaults come from the environment variable of the same name (without
+ * the OPT_) at first use, so one build can be A/B-timed inside one job.  Returns the previous value, -1 for an unknown option.
+ * Every setting computes the same function; tests use ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
+ *   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 direct convolution, 1 Winograd F(2x2,3x3) (default), 3 / 4 = with 3 / 4 LDS stages
+ *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd (default)
+ *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 1 = 16-byte DMA of the gradient tiles (default), 0 = dword
+ *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024) */
+#define ENDO_OPT_WINO_FWD 0
+#define ENDO_OPT_WINO_DGRAD 1
+#define ENDO_OPT_DGRAD_VEC 2
+#define ENDO_OPT_WINO_MIN_TILES 3
+#define ENDO_OPT_COUNT 4
+int endo_set_option(int option_id, int value);
 int64_t endo_net_group_stride(const endo_net* net);
 void endo_net_destroy(endo_net* net);
 int64_t endo_net_param_floats(void);                 /* 1 374 865 */

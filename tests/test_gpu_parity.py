@@ -380,6 +380,55 @@ def test_network_backward(shape):
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
 
 
+OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES = 0, 1, 2, 3
+
+
+class kernel_options(object):
+    """``with kernel_options({id: value}):`` -- endo_set_option for the duration of a block (include/endo_hip.h)."""
+
+    def __init__(self, values):
+        self.values, self.old = values, {}
+
+    def __enter__(self):
+        lib = ea._lib.load()
+        for k, v in self.values.items():
+            self.old[k] = lib.endo_set_option(k, v)
+            assert self.old[k] != -1 or v == -1
+        return self
+
+    def __exit__(self, *exc):
+        lib = ea._lib.load()
+        for k, v in self.old.items():
+            lib.endo_set_option(k, v)
+        return False
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160), (1, 64, 128)])
+@pytest.mark.parametrize("which", ["winograd", "direct"])
+def test_network_backward_kernel_forms(shape, which):
+    """The Winograd kernels (dense-layer forward, fused base-channel data gradient) are chosen by launch size and the parity
+    tests above are too small to reach them: here they are forced on (ENDO_OPT_WINO_MIN_TILES = 1) or off for every eligible
+    level and all 210 gradients are checked on the pass's own activation pattern as in test_network_backward -- so both forms
+    of every such layer are held to the same 3e-5, at sizes the fp64 oracle finishes in seconds."""
+    n, h, w = shape
+    opts = {OPT_WINO_MIN_TILES: 1} if which == "winograd" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0}
+    with kernel_options(opts):
+        state, model = make_model(62)
+        rng = np.random.default_rng(16)
+        x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+        cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+        model.train()
+        y = model(x.to(dev()))
+        (pattern,) = pattern_of(y, model, n, h, w)
+        (y * cot.to(dev())).sum().backward()
+        torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    g64p = reference_grads(state, x, cot, torch.float64, pattern)
+    y64 = onet.forward(state_as(state, torch.float64), x.double(), training=True, pattern=pattern)
+    assert_close(y, y64, 1e-5, "depth, %s kernels" % which)
+    assert_grads_on_pattern(params, g64p, None, GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
+
+
 def reference_pattern(state64, x64):
     """The fp64 oracle's own ReLU pattern (for counting how many bits a HIP pass flips)."""
     import torch.nn.functional as F
@@ -624,6 +673,54 @@ def test_level1_dropin_stock_optimizer(golden):
         np.testing.assert_allclose(norms, g[tag + "param_norms"], rtol=1e-4, atol=1e-5)
         assert_close(model.flat_parameters(), twin.flat_parameters(), 1e-6, "parameters after iteration %d, stock vs fused optimizer" % it)
         assert model._views_intact()
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 256, 320), (3, 32, 64)])
+def test_fused_loss_head_matches_modules(shape):
+    """endo_loss_head (the whole loss head and its backward as one library call, what TrainingStep runs by default) against the
+    same step assembled from the drop-in modules and autograd (fused_head=False): the three loss values, d loss / d prediction
+    for both frames, and the parameters after one full iteration.  Same kernels underneath, so the bounds are summation-order
+    tight; the oracle comparisons of the step (test_train_step_vs_oracle, the goldens) run through the fused head."""
+    n, h, w = shape
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=90, sparse_points=min(500, h * w // 6)))
+    _, fused_model = make_model(63, positive_depth=True)
+    _, module_model = make_model(63, positive_depth=True)
+    fused_model.train()
+    module_model.train()
+    fused = ea.train_step.TrainingStep(fused_model, ea.optim.FusedClipSGD(fused_model, lr=1.0e-3), h, w)
+    modular = ea.train_step.TrainingStep(module_model, ea.optim.FusedClipSGD(module_model, lr=1.0e-3), h, w, fused_head=False)
+    assert fused.fused_head and not modular.fused_head
+    # the head alone, on the same predictions
+    losses_t, pred, grad_pred = fused._fused_iteration(batch)
+    b = batch["boundaries"]
+    p1 = pred[:n].detach().clone().requires_grad_(True)
+    p2 = pred[n:].detach().clone().requires_grad_(True)
+    s1, _ = modular.depth_scaling_layer([p1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    s2, _ = modular.depth_scaling_layer([p2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+    mm = ea.train_step.mask_mul
+    f1 = mm(modular.flow_from_depth_layer([s1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]]), b)
+    f2 = mm(modular.flow_from_depth_layer([s2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]]), b)
+    sfl = 20.0 * 0.5 * (modular.sparse_flow_loss_function([mm(batch["sparse_flows_1"], b), f1, mm(batch["sparse_flow_masks_1"], b)]) +
+                        modular.sparse_flow_loss_function([mm(batch["sparse_flows_2"], b), f2, mm(batch["sparse_flow_masks_2"], b)]))
+    w21, i1 = modular.depth_warping_layer([s1, s2, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
+    w12, i2 = modular.depth_warping_layer([s2, s1, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]])
+    dcl = 0.1 * 0.5 * (modular.depth_consistency_loss_function([s1, w21, i1, batch["intrinsics"]]) +
+                       modular.depth_consistency_loss_function([s2, w12, i2, batch["intrinsics"]]))
+    total = dcl + sfl
+    g1, g2 = torch.autograd.grad(total, [p1, p2])
+    assert_close(losses_t[0], total, 1e-6, "total loss, fused head vs modules")
+    assert_close(losses_t[1], dcl, 1e-6, "depth consistency loss")
+    assert_close(losses_t[2], sfl, 1e-6, "sparse flow loss")
+    assert_close(grad_pred[:n], g1, 2e-6, "d loss / d prediction 1")
+    assert_close(grad_pred[n:], g2, 2e-6, "d loss / d prediction 2")
+    # a whole iteration each way (fresh forward passes)
+    fused.optimizer.zero_grad()
+    out_f = fused(batch)
+    out_m = modular(batch)
+    assert not out_f["skipped"] and not out_m["skipped"]
+    assert abs(out_f["loss"] - out_m["loss"]) <= 1e-6 * abs(out_m["loss"])
+    assert_close(out_f["grad_norm"], out_m["grad_norm"], 1e-5, "gradient norm")
+    assert_close(fused_model.flat_parameters(), module_model.flat_parameters(), 1e-6, "parameters after one iteration")
 
 
 def test_nonfinite_guard():
