@@ -550,7 +550,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             }
         }
         __syncthreads();
-        if (tid < 2 * 16 * QH) {
+        if (p.out_sums && tid < 2 * 16 * QH) {          // no statistics in inference mode
             const int j = tid >> 1, which = tid & 1;
             if (j < p.cout) {
                 double t = 0.0;

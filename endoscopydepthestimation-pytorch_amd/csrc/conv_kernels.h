@@ -280,7 +280,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             }
         }
         __syncthreads();
-        if (tid < 2 * NB) {
+        if (p.out_sums && tid < 2 * NB) {          // no statistics in inference mode
             const int j = tid >> 1, which = tid & 1;
             if (co_base + j < p.cout) {
                 double t = 0.0;

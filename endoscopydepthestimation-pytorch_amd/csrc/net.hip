@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __re
     __shared__ double scratch[2 * 4];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;
-    partial += grp * gs; out += grp * gs; out_sums += grp * (gs / 2);
+    partial += grp * gs; out += grp * gs;
+    if (out_sums) out_sums += grp * (gs / 2);
     const float b = bias[c];
     float part[2] = {0.f, 0.f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
@@ -363,7 +364,7 @@ __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __re
         part[0] += v;
         part[1] += v * v;
     }
-    block_sum_atomic<2>(part, out_sums + 2 * c, scratch);
+    if (out_sums) block_sum_atomic<2>(part, out_sums + 2 * c, scratch);          // (block-uniform) no statistics in inference mode
 }
 
 // final 1x1 conv 192 -> 1 and |.| (reference models.py:186).  HBM-bound: reads each plane once.
@@ -485,6 +486,9 @@ struct Ctx {
     float* act(int level) const { return tape + net->lv[level].act; }
     float* gbuf(int level) const { return gradws + net->lv[level].grad; }
     double* sums(int level) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(tape) + net->sums_off) + net->lv[level].sums; }
+    // where a kernel accumulates the per-channel sum / sum^2 of what it stores: nowhere in inference mode (running statistics are
+    // used, reference evaluate.py:317-345), which drops the reductions and their atomics from every epilogue
+    double* out_sums(int level, int channel) const { return training ? sums(level) + 2 * channel : nullptr; }
     float* saved(const BnP& b) const { return tape + net->saved_off + 2 * b.saved; }
     double* scratch(const BnP& b) const { return reinterpret_cast<double*>(reinterpret_cast<char*>(gradws) + net->scratch_off) + 2 * b.saved; }
     float* pq_p(int level) const { return gradws + net->pq_off + 2 * net->lv[level].pq; }
@@ -568,7 +572,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     fill_bn_in(c, p, b, level, ic0);
     p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.act(level), level, oc0, cv.cout);
-    p.out_sums = c.sums(level) + 2 * oc0;
+    p.out_sums = c.out_sums(level, oc0);
     ProfScope prof(kProfConv3x3Dense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
@@ -630,7 +634,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         bx = bx > 8 ? 8 : bx;
         finalize_partial_kernel<<<dim3(bx, cv.cout, c.nt()), 256, 0, c.stream>>>(
             partial, p.split_stride, ksplit, p.out_ns, static_cast<int>(lv.plane), c.params + cv.b, c.act(level) + oc0 * lv.plane,
-            lv.t * lv.plane, c.sums(level) + 2 * oc0, c.net->n, c.net->gs);
+            lv.t * lv.plane, c.out_sums(level, oc0), c.net->n, c.net->gs);
         ENDO_LAUNCH_CHECK();
         return 0;
     }
@@ -656,7 +660,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     fill_out(c, p, c.act(next), next, oc0, cv.cout);
     p.out_idx = c.idx(level);      // [n][cout][pooled plane] bytes, channel index relative to `out`
     p.idx_ns = static_cast<int64_t>(cv.cout) * c.net->lv[next].plane;
-    p.out_sums = c.sums(next) + 2 * oc0;
+    p.out_sums = c.out_sums(next, oc0);
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
     return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower)
@@ -680,7 +684,7 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
             p.wgt = w3 + static_cast<int64_t>(a) * cv.cin * 400; p.w_cout = 2 * cv.cout; p.w_cin = cv.cin;
             p.bias = c.params + cv.b;
             fill_out(c, p, c.act(level), level, 0, cv.cout);
-            p.out_sums = c.sums(level);
+            p.out_sums = c.out_sums(level, 0);
             int rc = a == 0 ? launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 0>(p, c.stream)
                             : launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 1>(p, c.stream);
             if (rc) return rc;
@@ -692,7 +696,7 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     fill_in(c, p, c.act(src_level), src_level, src_c0, cv.cin);
     p.wgt = c.params + cv.w; p.bias = c.params + cv.b; p.w_cout = cv.cout; p.w_cin = cv.cin;
     fill_out(c, p, c.act(level), level, 0, cv.cout);
-    p.out_sums = c.sums(level);
+    p.out_sums = c.out_sums(level, 0);
     return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
@@ -1115,7 +1119,7 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
         p.in_gs = net->n * p.in_ns;                 // x is the caller's [groups * n][3][H][W] tensor
         p.wgt = params + tb.first.w; p.bias = params + tb.first.b; p.w_cout = kFirst; p.w_cin = 3;
         fill_out(c, p, c.act(0), 0, 48, kFirst);
-        p.out_sums = c.sums(0) + 2 * 48;
+        p.out_sums = c.out_sums(0, 48);
         ProfScope prof(kProfConvFirst, c.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * net->lv[0].plane * (3 + kFirst));
         rc = launch_conv_dma_auto<3, 4, 3, IN_PLAIN, EPI_FWD>(p, c.stream);
         if (rc) return rc;
