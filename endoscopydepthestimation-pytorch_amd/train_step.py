@@ -137,6 +137,9 @@ class TrainingStep(object):
             for group in self.optimizer.param_groups:
                 group["lr"] = lr
         if self.fused_head:
+            # the previous iteration's gradients were consumed by its optimizer step: clear the flat buffer now, ahead of the
+            # host synchronisation below, so that the first backward kernel follows the guard without a memset in between
+            self.optimizer.zero_grad()
             losses_t, pred, grad_pred = self._fused_iteration(batch)
             host = losses_t.tolist()                  # the reference syncs here too (train.py:317)
             value = host[0]
@@ -144,7 +147,6 @@ class TrainingStep(object):
             if distributed.world_size() > 1:
                 flag = torch.tensor([1.0 if bad else 0.0], device=pred.device)
                 bad = bool(distributed.agree_nonfinite(flag).item() > 0)
-            self.optimizer.zero_grad()
             if bad:
                 return {"loss": value, "dcl": float("nan"), "sfl": float("nan"), "skipped": True}
             pred.backward(grad_pred)

@@ -19,7 +19,7 @@ import sqlite3
 import sys
 
 FAMILIES = [
-    ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,")),
+    ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_wino8_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,")),
     ("conv3x3_dense_fwd", re.compile(r"wino_fwd_kernel|conv_dma_kernel<3, \d+, 1, 1, 0,|finalize_partial_kernel")),
     ("wgrad_dense", re.compile(r"wgrad_nsplit_kernel|wgrad_nsplit_reduce_kernel|wgrad_taps_kernel<12, 1>|wgrad_mfma_kernel<3, 1, 1, 0>")),
 ]
