@@ -691,7 +691,7 @@ def test_fused_loss_head_matches_modules(shape):
     modular = ea.train_step.TrainingStep(module_model, ea.optim.FusedClipSGD(module_model, lr=1.0e-3), h, w, fused_head=False)
     assert fused.fused_head and not modular.fused_head
     # the head alone, on the same predictions
-    losses_t, pred, grad_pred = fused._fused_iteration(batch)
+    losses_t, _, _, pred, grad_pred = fused._fused_iteration(batch)
     b = batch["boundaries"]
     p1 = pred[:n].detach().clone().requires_grad_(True)
     p2 = pred[n:].detach().clone().requires_grad_(True)
