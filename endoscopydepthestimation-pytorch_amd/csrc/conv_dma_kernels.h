@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 if (co_base + j < p.cout) {
                     double t = 0.0;
                     for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
-                    atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
+                    atomicAdd(p.bn_scratch + bn_slot_offset(p.bn_slot_stride) + 2 * (co_base + j) + which, t);
                 }
             }
             return;

@@ -78,6 +78,7 @@ struct ConvParams {
     const float* bn_gamma;
     const float* bn_beta;
     double* bn_scratch;      // [cout][2] sum dz, sum dz*xhat
+    int64_t bn_slot_stride;  // copies of bn_scratch, this many doubles apart (common.h: kBnSlots); 0 = one copy
     int acc_from;            // output channels >= acc_from accumulate into `out`, others overwrite
     int bn_cap;              // LDS-DMA kernels: capacity (channels) of the BN constant tables, set by the launcher
     // split-K (coarse levels): blockIdx.y = slice of the input channels; slice s writes its raw partial sums at
@@ -345,7 +346,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x4 (&acc)[
             if (co_base + j < p.cout) {
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(s_red[(wv * NB + j) * 2 + which]);
-                atomicAdd(p.bn_scratch + 2 * (co_base + j) + which, t);
+                atomicAdd(p.bn_scratch + bn_slot_offset(p.bn_slot_stride) + 2 * (co_base + j) + which, t);
             }
         }
     } else {   // EPI_DGRAD_SUMPOOL

@@ -47,6 +47,7 @@ struct DgradBlockParams {
     const float* gamma[kMaxFusedLayers];
     const float* beta[kMaxFusedLayers];
     double* scratch[kMaxFusedLayers];
+    int64_t slot_stride;      // copies of the sums, this many doubles apart (common.h: kBnSlots); 0 = one copy
     // grouped batch (see ConvParams): blockIdx.z = group * group_n + sample; g, x, out, saved, scratch move by group * gs floats
     int group_n;
     int64_t gs;
@@ -384,7 +385,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
                 const float* red = s_red + buf * G::kRed + a * (4 * 16 * 2);
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
-                atomicAdd(p.scratch[l] + grp_off / 2 + 2 * co + which, t);
+                atomicAdd(p.scratch[l] + bn_slot_offset(p.slot_stride) + grp_off / 2 + 2 * co + which, t);
             }
         }
     }
@@ -631,7 +632,7 @@ __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockPa
                 const float* red = s_red + (buf * 2 + half) * G::kRed;
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
-                atomicAdd(p.scratch[l] + grp_off / 2 + 2 * cj + which, t);
+                atomicAdd(p.scratch[l] + bn_slot_offset(p.slot_stride) + grp_off / 2 + 2 * cj + which, t);
             }
         }
     }

@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_dense_kernel(const ConvPar
                 const float* red = s_red + buf * (4 * 16 * 2);
                 double t = 0.0;
                 for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
-                atomicAdd(p.bn_scratch + 2 * co + which, t);
+                atomicAdd(p.bn_scratch + bn_slot_offset(p.bn_slot_stride) + 2 * co + which, t);
             }
         }
     }

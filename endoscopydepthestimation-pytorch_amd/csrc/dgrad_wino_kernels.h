@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
             const float* red = s_red + (buf * 2 + half) * G::kRed;
             double t = 0.0;
             for (int wv = 0; wv < 4; ++wv) t += static_cast<double>(red[(wv * 16 + j) * 2 + which]);
-            atomicAdd(p.scratch[l] + grp_off / 2 + 2 * cj + which, t);
+            atomicAdd(p.scratch[l] + bn_slot_offset(p.slot_stride) + grp_off / 2 + 2 * cj + which, t);
         }
     }
 }

@@ -149,6 +149,7 @@ struct endo_net {
     int64_t pq_floats;
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
     int64_t scratch_bytes;
+    int64_t slot_stride;   // doubles between the kBnSlots copies of the BN scratch (common.h)
     int64_t wg_scratch_off;   // float offset in gradws of the weight-gradient partial sums (wgrad_nsplit_kernels.h)
     int64_t tuw_scratch_off;  // float offset in gradws of the transition-up data-gradient weights (tu_subpix_dgrad_weights_kernel)
     int64_t wd_off;           // float offset in gradws of the Winograd-domain data-gradient weights (group 0's copy serves all groups)
@@ -185,32 +186,47 @@ struct BnFin4 {
 __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, const float* __restrict__ x, int64_t ns, int plane,
                                                       const float* __restrict__ pq_p, const float* __restrict__ pq_q,
                                                       float* bias_grad, int group_n, int64_t gs, const BnFin4 fin, int nl,
-                                                      double count, int training) {
+                                                      double count, int training, int64_t slot_stride) {
     __shared__ double scratch[4];
+    __shared__ float s_pq[2];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
     float pc = pq_p[grp * gs + c], qc = pq_q[grp * gs + c];
     if (nl > 0) {
-        const int64_t go = grp * gs;
-        double dp = 0.0, dq = 0.0;
+        if (threadIdx.x < 64) {
+            // wave 0: lane (which, slot) reads one copy of one sum (common.h: kBnSlots copies); xor-shuffles below 32 add up the
+            // slots of each half, lane 0 / 32 then hold sum dz / sum dz*xhat
+            static_assert(kBnSlots == 32, "one half-wave per sum");
+            const int slot = threadIdx.x & 31, which = threadIdx.x >> 5;
+            const int64_t go = grp * gs;
+            double dp = 0.0, dq = 0.0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (j >= nl) break;
-            const double s1 = fin.scratch[j][go / 2 + 2 * c], s2 = fin.scratch[j][go / 2 + 2 * c + 1];
-            if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
-                atomicAdd(fin.ggamma[j] + c, static_cast<float>(s2));
-                atomicAdd(fin.gbeta[j] + c, static_cast<float>(s1));
+            for (int j = 0; j < 4; ++j) {
+                if (j >= nl) break;
+                double v = (slot == 0 || slot_stride != 0) ? fin.scratch[j][slot * slot_stride + go / 2 + 2 * c + which] : 0.0;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                const double s1 = __shfl(v, 0, 64), s2 = __shfl(v, 32, 64);
+                if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+                    atomicAdd(fin.ggamma[j] + c, static_cast<float>(s2));
+                    atomicAdd(fin.gbeta[j] + c, static_cast<float>(s1));
+                }
+                if (training) {
+                    const double mean = fin.saved[j][go + 2 * c], rstd = fin.saved[j][go + 2 * c + 1];
+                    const double scale = fin.gamma[j][c] * rstd;
+                    const double k = scale * rstd * s2 / count;
+                    dp += static_cast<double>(static_cast<float>(-k));
+                    dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
+                }
             }
-            if (training) {
-                const double mean = fin.saved[j][go + 2 * c], rstd = fin.saved[j][go + 2 * c + 1];
-                const double scale = fin.gamma[j][c] * rstd;
-                const double k = scale * rstd * s2 / count;
-                dp += static_cast<double>(static_cast<float>(-k));
-                dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
+            if (threadIdx.x == 0) {
+                s_pq[0] = pc + static_cast<float>(dp);
+                s_pq[1] = qc + static_cast<float>(dq);
             }
         }
-        pc += static_cast<float>(dp);
-        qc += static_cast<float>(dq);
+        __syncthreads();
+        pc = s_pq[0];
+        qc = s_pq[1];
     }
     const int64_t base = grp * gs + n * ns + static_cast<int64_t>(c) * plane;
     float part = 0.f;
@@ -242,11 +258,11 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
 __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const float* __restrict__ saved,
                                        const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                        float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count, int training,
-                                       int64_t gs) {
+                                       int64_t gs, int64_t slot_stride) {
     // blockIdx.y = sample group: its own sums, statistics and deferred terms; the parameter gradients add up over groups
     scratch += blockIdx.y * (gs / 2); saved += blockIdx.y * gs; pq_p += blockIdx.y * gs; pq_q += blockIdx.y * gs;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
-        const double s1 = scratch[2 * c], s2 = scratch[2 * c + 1];
+        const double s1 = bn_slot_sum(scratch + 2 * c, slot_stride), s2 = bn_slot_sum(scratch + 2 * c + 1, slot_stride);
         atomicAdd(ggamma + c, static_cast<float>(s2));
         atomicAdd(gbeta + c, static_cast<float>(s1));
         if (training) {
@@ -262,7 +278,7 @@ __global__ void bn_bwd_finalize_kernel(const double* __restrict__ scratch, const
 // the same for up to four BN layers of a dense block over channels they share: one launch, one read-modify-write of
 // P and Q
 __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, int nl, float* __restrict__ pq_p, float* __restrict__ pq_q, int c_count, double count,
-                                        int training, int64_t gs) {
+                                        int training, int64_t gs, int64_t slot_stride) {
     const int64_t go = blockIdx.y * gs;          // sample group offset (floats)
     pq_p += go; pq_q += go;
     for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < c_count; c += gridDim.x * blockDim.x) {
@@ -270,7 +286,8 @@ __global__ void bn_bwd_finalize4_kernel(const BnFin4 a, int nl, float* __restric
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (j >= nl) break;          // nl = layers in use (block-uniform)
-            const double s1 = a.scratch[j][go / 2 + 2 * c], s2 = a.scratch[j][go / 2 + 2 * c + 1];
+            const double s1 = bn_slot_sum(a.scratch[j] + go / 2 + 2 * c, slot_stride);
+            const double s2 = bn_slot_sum(a.scratch[j] + go / 2 + 2 * c + 1, slot_stride);
             atomicAdd(a.ggamma[j] + c, static_cast<float>(s2));
             atomicAdd(a.gbeta[j] + c, static_cast<float>(s1));
             if (training) {
@@ -709,7 +726,7 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad,
     prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
                                                                      c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs, fin ? *fin : none, fin ? nl : 0,
-                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training);
+                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->slot_stride);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -724,7 +741,7 @@ static int bn_finalize(const Ctx& c, const BnP& b, int level, int ic0, int first
     bn_bwd_finalize_kernel<<<dim3((count + 127) / 128, c.net->groups), 128, 0, c.stream>>>(c.scratch(b) + 2 * first, c.saved(b) + 2 * first, c.params + b.g + first,
                                                                        c.grads + b.g + first, c.grads + b.b + first,
                                                                        c.pq_p(level) + ic0 + first, c.pq_q(level) + ic0 + first, count,
-                                                                       static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
+                                                                       static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs, c.net->slot_stride);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -770,7 +787,7 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         fill_out(c, p, c.gbuf(level), level, ic0, cv.cin);
         p.x = c.act(level) + ic0 * lv.plane; p.x_ns = lv.t * lv.plane; p.x_cs = static_cast<int>(lv.plane);
         p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
-        p.bn_scratch = c.scratch(b);
+        p.bn_scratch = c.scratch(b); p.bn_slot_stride = c.net->slot_stride;
         p.acc_from = acc_from - ic0;
         ProfScope prof(kProfDgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (3.0 * cv.cin + cv.cout));
         rc = launch_dgrad_dense_auto(p, c.stream);
@@ -804,7 +821,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     }
     auto fill_common = [&](DgradBlockParams& p) {
         p.n = c.nt(); p.h = lv.h; p.w = lv.w;
-        p.group_n = c.net->n; p.gs = c.net->gs;
+        p.group_n = c.net->n; p.gs = c.net->gs; p.slot_stride = c.net->slot_stride;
         p.g_ns = lv.t * lv.plane; p.g_cs = static_cast<int>(lv.plane); p.g_w = lv.w;
         p.ns = lv.t * lv.plane; p.cs = static_cast<int>(lv.plane);
     };
@@ -894,7 +911,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         }
         ProfScope prof(kProfSmall, c.stream, 0.0, 0.0);
         bn_bwd_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(a, kLayers, c.pq_p(level) + ic0, c.pq_q(level) + ic0, c0,
-                                                                         static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs);
+                                                                         static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->gs,
+                                                                         c.net->slot_stride);
         ENDO_LAUNCH_CHECK();
     }
     return 0;
@@ -931,7 +949,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         fill_out(c, p, c.gbuf(level), level, 48, cv.cin);
         p.x = c.act(level) + 48 * lv.plane; p.x_ns = lv.t * lv.plane; p.x_cs = static_cast<int>(lv.plane);
         p.bn_saved = c.saved(b); p.bn_gamma = c.params + b.g; p.bn_beta = c.params + b.b;
-        p.bn_scratch = c.scratch(b);
+        p.bn_scratch = c.scratch(b); p.bn_slot_stride = c.net->slot_stride;
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
@@ -1031,7 +1049,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->pq_off = acts;
     net->pq_floats = 2 * pq;
     net->scratch_off = align_up((acts + net->pq_floats) * 4, 256);
-    net->scratch_bytes = tb.bn_width_total * 2 * 8;
+    net->slot_stride = align_up(tb.bn_width_total * 2, 32);
+    net->scratch_bytes = net->slot_stride * 8 * kBnSlots;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
     net->tuw_scratch_off = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
     net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
