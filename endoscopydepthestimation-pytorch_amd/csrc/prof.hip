@@ -57,7 +57,7 @@ extern "C" int endo_abi_version(void) { return 1; }
 extern "C" const char* endo_error_string(int code) {
     if (code == 0) return "ok";
     if (code == ENDO_E_BADARG) return "endo: bad argument (null pointer or non-positive size)";
-    if (code == ENDO_E_UNSUPPORTED) return "endo: unsupported shape (H and W must be multiples of 32)";
+    if (code == ENDO_E_UNSUPPORTED) return "endo: unsupported shape or format (network: H and W must be multiples of 32; JPEG: sequential Huffman, 8 bit, grey / 4:4:4 / 4:2:2 / 4:2:0)";
     if (code > 0) return hipGetErrorString(static_cast<hipError_t>(code));
     return "endo: unknown error";
 }

@@ -273,6 +273,32 @@ int endo_point_cloud(const float* depth, const uint8_t* color_bgr, const float* 
                      int width, int downsampling, int use_threshold, float min_threshold, float max_threshold,
                      int32_t* row_offsets, float* points, int32_t* count_out, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Colour frames from the sequence folder's .jpg files -- reference utils.py:441-457 (get_pair_color_imgs: cv2.imread,
+ * cv2.resize(img, (0, 0), fx = fy = 1 / downsampling), crop [start_h:end_h, start_w:end_w], BGR2RGB), utils.py:72-83
+ * (get_test_color_img) and dataset.py:148,446-451 (albumentations Normalize(0.5, 0.5) + img_to_tensor).
+ * Baseline / extended-sequential Huffman JPEG, 8 bit, one interleaved scan; grey, 4:4:4, 4:2:2 (h2v1) and 4:2:0 (h2v2);
+ * restart intervals.  Anything else (progressive, arithmetic, 12 bit, CMYK) returns ENDO_E_UNSUPPORTED.
+ *   endo_jpeg_info            host only.  info[16]: width, height, components, hmax, vmax, MCUs across, MCUs down,
+ *                             (blocks across, blocks down) per component, total 8x8 blocks, restart interval, 0.
+ *   endo_jpeg_entropy_decode  host only: the coefficient blocks the device stage starts from -- total_blocks x 64 int16,
+ *                             component planes one after the other, blocks row-major inside a plane, coefficients in
+ *                             natural (row-major, de-zigzagged) order, not dequantised; quant: [3][64] uint16, natural order.
+ *   endo_jpeg_workspace_bytes bytes of `staging` (host; pinned for an asynchronous copy) and of `workspace` (device).
+ *   endo_jpeg_decode_crop     parses and Huffman-decodes on the calling thread into `staging`, copies to `workspace` on
+ *                             `stream` and launches the inverse DCT and the resize/crop kernels there.  out_hwc: device
+ *                             uint8 [H][W][3] (rgb_order != 0: R,G,B as rgb_mode "rgb"; 0: B,G,R as cv2.imread) or NULL;
+ *                             out_chw: device fp32 [3][H][W] = (v - 127.5) * (1 / 127.5) or NULL.  `staging` must stay
+ *                             untouched until `stream` has passed the call.  Pixel values are those of libjpeg's default
+ *                             decoder (JDCT_ISLOW, fancy upsampling) followed by cv2's 8-bit INTER_LINEAR arithmetic.
+ * ------------------------------------------------------------------------------------------- */
+int endo_jpeg_info(const uint8_t* data, int64_t size, int32_t* info);
+int endo_jpeg_entropy_decode(const uint8_t* data, int64_t size, int16_t* blocks, int64_t capacity_blocks, uint16_t* quant);
+int64_t endo_jpeg_workspace_bytes(const uint8_t* data, int64_t size);
+int endo_jpeg_decode_crop(const uint8_t* data, int64_t size, double downsampling, int start_h, int end_h, int start_w,
+                          int end_w, int rgb_order, uint8_t* out_hwc, float* out_chw, void* staging, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f
  * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read

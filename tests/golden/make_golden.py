@@ -439,12 +439,76 @@ def pair_selection_case(ref, path):
     print("wrote", path, len(rows), "rows")
 
 
+def reader_case(ref, path):
+    """Sequence reader.  Expected values: the reference's own precompute file for the shipped example sequence
+    (written by the reference with the real cv2 / plyfile), plus -- for the text readers that import without cv2 -- the
+    reference's functions run here on the same files.  The input files themselves (small text files, the mask as .bmp.gz and
+    two of the .jpg frames) are copied as DATA into tests/golden/example_sequence/ so that the readers run on a real folder
+    where /root/reference does not exist.  Colour frames: the reference tree holds no decoded image; the expected crops are
+    libjpeg-turbo's decode (Pillow) followed by the oracle's cv2.resize restatement (itself pinned by the mask)."""
+    import gzip
+    import shutil
+    import yaml
+    from oracle import reader as oreader
+    with open(os.path.join(REF, "example_training_data_root", "precompute_4.0_64_0.99.pkl"), "rb") as f:
+        data = pickle.load(f)
+    key = list(data[0].keys())[0]
+    seq = os.path.join(REF, "example_training_data_root", "bag_1", os.path.basename(key))
+    dst = os.path.join(HERE, "example_sequence", "bag_1", os.path.basename(key))
+    os.makedirs(dst, exist_ok=True)
+    frames = [4584, 4594]
+    for name in ("camera_intrinsics_per_view", "motion.yaml", "selected_indexes", "visible_view_indexes", "view_indexes_per_point",
+                 "structure.ply") + tuple("%08d.jpg" % i for i in frames):
+        shutil.copyfile(os.path.join(seq, name), os.path.join(dst, name))
+        os.chmod(os.path.join(dst, name), 0o644)
+    with open(os.path.join(seq, "undistorted_mask.bmp"), "rb") as src, gzip.GzipFile(os.path.join(dst, "undistorted_mask.bmp.gz"), "wb", mtime=0) as out:
+        out.write(src.read())
+    # the reference's own text readers on the same folder (no cv2 needed); yaml.load without a Loader is PyYAML < 6 usage
+    real_load = yaml.load
+    yaml.load = lambda stream, Loader=None: real_load(stream, Loader=Loader or yaml.SafeLoader)
+    try:
+        from pathlib import Path
+        u = ref["utils"]
+        stride, selected = u.read_selected_indexes(Path(seq))
+        visible = u.read_visible_view_indexes(Path(seq))
+        intr = u.read_camera_intrinsic_per_view(Path(seq))
+        vpp = u.read_view_indexes_per_point(Path(seq), visible, len(data[3][key]))
+        vpp_overlap = u.overlapping_visible_view_indexes_per_point(np.copy(vpp), 30)
+        poses = u.read_pose_data(Path(seq))
+        crop = [int(v) for v in data[0][key]]
+        k_mod = u.modify_camera_intrinsic_matrix(intr[0], start_h=crop[0], start_w=crop[2], downsampling_factor=4.0)
+        ext, proj = u.get_extrinsic_matrix_and_projection_matrix(poses, intrinsic_matrix=k_mod, visible_view_count=len(visible))
+        scale = u.global_scale_estimation(ext, data[3][key])
+    finally:
+        yaml.load = real_load
+    assert selected == list(data[1][key]) and visible == list(data[2][key])
+    assert np.array_equal(vpp_overlap, data[6][key]) and np.array_equal(k_mod, data[4][key])
+    out = {"crop_positions": np.array(crop), "stride": np.array(stride), "selected_indexes": np.array(selected),
+           "visible_view_indexes": np.array(visible), "intrinsics_per_view0": np.asarray(intr[0]), "intrinsic_matrix": np.asarray(data[4][key]),
+           "point_cloud": np.asarray(data[3][key], dtype=np.float64), "mask_boundary": data[5][key],
+           "view_indexes_per_point_raw": vpp.astype(np.uint8), "view_indexes_per_point": np.asarray(data[6][key]),
+           "visible_interval": np.array(30), "extrinsics": np.stack([np.asarray(m) for m in data[7][key]]),
+           "projection": np.stack([np.asarray(m) for m in data[8][key]]), "extrinsics_here": np.stack([np.asarray(m) for m in ext]),
+           "projection_here": np.stack([np.asarray(m) for m in proj]), "estimated_scale": np.array(float(data[13][key])),
+           "estimated_scale_here": np.array(float(scale)), "downsampling": np.array(float(data[10])),
+           "network_downsampling": np.array(int(data[11])), "frames": np.array(frames)}
+    out["color_imgs"] = oreader.get_pair_color_imgs(seq, frames, crop[0], crop[1], crop[2], crop[3], 4.0, False, "rgb")
+    full = oreader.decode_jpeg_pil(os.path.join(seq, "%08d.jpg" % frames[0]))
+    out["full_frame0_row_sums"] = full.astype(np.int64).sum(axis=(1, 2))          # a fingerprint of the library's full decode
+    out["full_frame0_col_sums"] = full.astype(np.int64).sum(axis=(0, 2))
+    np.savez_compressed(path, **out)
+    print("wrote", path, {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim > 1})
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
     ref = import_reference()
     if "--pair-selection-only" in sys.argv:
         pair_selection_case(ref, os.path.join(HERE, "pair_selection.npz"))
+        return
+    if "--reader-only" in sys.argv:
+        reader_case(ref, os.path.join(HERE, "reader_example.npz"))
         return
     if "--full-only" in sys.argv:          # the benchmark-size case alone (minutes of CPU, ~25 GB with the fp64 yardstick)
         train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
@@ -460,6 +524,7 @@ def main():
     scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
     point_cloud_case(ref, os.path.join(HERE, "point_cloud.npz"))
     pair_selection_case(ref, os.path.join(HERE, "pair_selection.npz"))
+    reader_case(ref, os.path.join(HERE, "reader_example.npz"))
     train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
 
 
