@@ -34,8 +34,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 // data-gradient kernel.  Atomics on ONE address are served one after the other (~8 ns each on this part: thousands of blocks of
 // a full-resolution launch queue up behind each other, and a block's next s_waitcnt vmcnt(0) waits for its own to be
 // acknowledged -- 40 % of the new-channel passes' time, tools/nl_bench).  So the sums live in kBnSlots copies, `slot_stride`
-// doubles apart (0 = a single copy): a block adds to the copy its index selects, the readers add the copies up.
-constexpr int kBnSlots = 32;
+// doubles apart (0 = a single copy): a block adds to the copy its index selects, the readers add the copies up.  Eight copies
+// bring a full-resolution launch down to a few hundred atomics per address (a few us) and keep the readers' prologue short.
+constexpr int kBnSlots = 8;
 
 __device__ __forceinline__ int64_t bn_slot_offset(int64_t slot_stride) {
     return static_cast<int64_t>((blockIdx.x + 11 * blockIdx.z) & (kBnSlots - 1)) * slot_stride;
@@ -44,7 +45,7 @@ __device__ __forceinline__ int64_t bn_slot_offset(int64_t slot_stride) {
 __device__ __forceinline__ double bn_slot_sum(const double* __restrict__ s, int64_t slot_stride) {
     if (slot_stride == 0) return s[0];
     double t = 0.0;
-#pragma unroll 8
+#pragma unroll
     for (int k = 0; k < kBnSlots; ++k) t += s[k * slot_stride];
     return t;
 }

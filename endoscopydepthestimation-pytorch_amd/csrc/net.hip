@@ -188,45 +188,31 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
                                                       float* bias_grad, int group_n, int64_t gs, const BnFin4 fin, int nl,
                                                       double count, int training, int64_t slot_stride) {
     __shared__ double scratch[4];
-    __shared__ float s_pq[2];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
     float pc = pq_p[grp * gs + c], qc = pq_q[grp * gs + c];
     if (nl > 0) {
-        if (threadIdx.x < 64) {
-            // wave 0: lane (which, slot) reads one copy of one sum (common.h: kBnSlots copies); xor-shuffles below 32 add up the
-            // slots of each half, lane 0 / 32 then hold sum dz / sum dz*xhat
-            static_assert(kBnSlots == 32, "one half-wave per sum");
-            const int slot = threadIdx.x & 31, which = threadIdx.x >> 5;
-            const int64_t go = grp * gs;
-            double dp = 0.0, dq = 0.0;
+        const int64_t go = grp * gs;
+        double dp = 0.0, dq = 0.0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j >= nl) break;
-                double v = (slot == 0 || slot_stride != 0) ? fin.scratch[j][slot * slot_stride + go / 2 + 2 * c + which] : 0.0;
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                const double s1 = __shfl(v, 0, 64), s2 = __shfl(v, 32, 64);
-                if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
-                    atomicAdd(fin.ggamma[j] + c, static_cast<float>(s2));
-                    atomicAdd(fin.gbeta[j] + c, static_cast<float>(s1));
-                }
-                if (training) {
-                    const double mean = fin.saved[j][go + 2 * c], rstd = fin.saved[j][go + 2 * c + 1];
-                    const double scale = fin.gamma[j][c] * rstd;
-                    const double k = scale * rstd * s2 / count;
-                    dp += static_cast<double>(static_cast<float>(-k));
-                    dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
-                }
+        for (int j = 0; j < 4; ++j) {
+            if (j >= nl) break;
+            const double s1 = bn_slot_sum(fin.scratch[j] + go / 2 + 2 * c, slot_stride);          // block-uniform addresses
+            const double s2 = bn_slot_sum(fin.scratch[j] + go / 2 + 2 * c + 1, slot_stride);
+            if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) {
+                atomicAdd(fin.ggamma[j] + c, static_cast<float>(s2));
+                atomicAdd(fin.gbeta[j] + c, static_cast<float>(s1));
             }
-            if (threadIdx.x == 0) {
-                s_pq[0] = pc + static_cast<float>(dp);
-                s_pq[1] = qc + static_cast<float>(dq);
+            if (training) {
+                const double mean = fin.saved[j][go + 2 * c], rstd = fin.saved[j][go + 2 * c + 1];
+                const double scale = fin.gamma[j][c] * rstd;
+                const double k = scale * rstd * s2 / count;
+                dp += static_cast<double>(static_cast<float>(-k));
+                dq += static_cast<double>(static_cast<float>(-scale * s1 / count + k * mean));
             }
         }
-        __syncthreads();
-        pc = s_pq[0];
-        qc = s_pq[1];
+        pc += static_cast<float>(dp);
+        qc += static_cast<float>(dq);
     }
     const int64_t base = grp * gs + n * ns + static_cast<int64_t>(c) * plane;
     float part = 0.f;
