@@ -55,6 +55,12 @@ CONFIGS = {
             metric="train frame-pairs/sec at 256x320 bs=8",
             workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
                      "256x320, batch 8 per GPU, fp32 (BASELINE.json configs[1])"),
+    2: dict(height=256, width=320, batch=8, gap=None, bf16_operands=True,
+            metric="train frame-pairs/sec at 256x320 bs=8, bf16 MFMA operands",
+            workload="full training step, 256x320, batch 8 per GPU, MIXED PRECISION: the dense layers' forward / data-gradient / "
+                     "weight-gradient kernels round their MFMA operands to bf16 (fp32 accumulation; tensors in memory, BN, reductions, "
+                     "geometry, losses and optimizer fp32) -- the per-GPU half of BASELINE.json configs[2] (bs 64 over 8 GPUs) "
+                     "without bf16 storage; NOT comparable with the fp32 line of configs[1]"),
     3: dict(height=512, width=640, batch=4, gap=None,
             metric="train frame-pairs/sec at 512x640 bs=4",
             workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
@@ -246,6 +252,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     lib = pkg._lib.load()
+    bf16 = bool(cfg.get("bf16_operands"))
+    lib.endo_set_option(4, 1 if bf16 else 0)                            # ENDO_OPT_MFMA_BF16 (include/endo_hip.h)
 
     torch.manual_seed(10085)                                            # reference train.py:80
     model = pkg.models.FCDenseNet57(n_classes=1)
@@ -395,7 +403,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16 MFMA operands, f32 accumulate, f32 storage" if bf16 else "f32",
         "data": "synthetic",
         "config": {"workload": cfg["workload"], "baseline_config_index": args.config,
                    "global_batch": batch_size * world, "height": height, "width": width, "parallelism": "dp%d" % world},
@@ -426,6 +434,15 @@ def main():
             "host_inclusive_ms_per_pair": warp_ms_per_pair,
             "note": "latency/launch bound at this size: %.0f KB per launch" % (warp_bytes / max(geo[1] + los[1], 1) * reps / 1e3)},
     }
+    if bf16:
+        # with bf16 operands the matrix work is ~1/8 of the fp32 kernels' and the dense-layer families are bound by HBM / LDS / VALU:
+        # the roofline that applies is HBM (~90 FLOP/B against a bf16 ridge of ~310)
+        r = result["roofline"]
+        gbs = r["algorithmic_gbs"] or 0.0
+        r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                  "mfma_tflops_for_reference": achieved})
+        result["conv_roofline_frac_whole_step"] = None
+        result["roofline_serial"] = None
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(result))

@@ -50,6 +50,21 @@ __device__ __forceinline__ double bn_slot_sum(const double* __restrict__ s, int6
     return t;
 }
 
+// bf16 operands for v_mfma_f32_16x16x16_bf16 (the "bf16 operands" mode, ENDO_OPT_MFMA_BF16): four consecutive k values of a lane,
+// rounded to nearest even by v_cvt_pk_bf16_f32 (gfx950), two per dword.  One such MFMA replaces four v_mfma_f32_16x16x4_f32 whose
+// k-steps hold the same 16 k values: lane group lk carries k = 4 lk + i in both forms.
+typedef short bf16x4_bits __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x4_bits pack_bf16x4(float a, float b, float c, float d) {
+    // through the compiler's own conversion (one v_cvt_pk_bf16_f32 per pair), NOT inline assembly: the hazard recogniser must see
+    // the VALU write to insert the wait states an MFMA needs before it reads those registers
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t lo = __builtin_convertvector(f32x2_t{a, b}, bf16x2_t), hi = __builtin_convertvector(f32x2_t{c, d}, bf16x2_t);
+    return __builtin_bit_cast(bf16x4_bits, u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
+}
+
 // Block-wide sum of K per-thread partials, one fp64 atomic per value per block.
 // scratch: K * (blockDim/64) doubles of LDS.  All threads must call.
 template <int K>

@@ -55,8 +55,12 @@ struct ConvDmaSmem {
 // kernel runs on the low-resolution grid, its 16*Q "output channels" are [b = 0 | b = 1] x Q/2 tiles of real channels
 // (weights pre-summed by tu_phase_weights_kernel), the taps a phase does not use are skipped at compile time (16 of 36
 // tap-phase pairs remain: 4/9 of the MACs) and the epilogue interleaves the two column phases into full-resolution rows.
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0, int PH = -1>
+// BF: 1 = bf16 MFMA operands (ENDO_OPT_MFMA_BF16; 3x3, ordinary inputs only): the three row taps (dy = 0..2) of one input channel
+// and column tap are the k = 4 lk .. 4 lk + 2 of ONE v_mfma_f32_16x16x16_bf16 (the fourth k is a zero), so a channel quad costs
+// 3 of those instead of 9 v_mfma_f32_16x16x4_f32; operands are rounded to bf16 after BN + ReLU, accumulation stays fp32.
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0, int PH = -1, int BF = 0>
 __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p0) {
+    static_assert(BF == 0 || (KS == 3 && PH < 0 && (IN == IN_BNRELU || IN == IN_PLAIN)), "bf16 operands: the ordinary 3x3 convolution");
     static_assert(PH < 0 || (KS == 3 && (Q % 2) == 0 && IN == IN_PLAIN && EPI == EPI_FWD), "phase mode is the transition-up forward");
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");      // (three buffers, DMA two chunks ahead: 7 % slower in the in-job A/B)
@@ -386,6 +390,24 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
 #pragma unroll
             for (int dx = 0; dx < KS; ++dx) {
                 float a[R + KS - 1];
+                if constexpr (BF != 0) {
+#pragma unroll
+                    for (int r = 0; r < R + 2; ++r) {
+                        const float v = a_base[r * G::kCols + dx];
+                        a[r] = (IN == IN_BNRELU && !kInPlace) ? __builtin_fmaxf(fmaf(v - mn, sc, bt), 0.f) : v;
+                    }
+                    bf16x4_bits ap[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ap[r] = pack_bf16x4(a[r], a[r + 1], a[r + 2], 0.f);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const bf16x4_bits bp = pack_bf16x4(b_base[(0 * KS + dx) * KC * NB + q * 16], b_base[(1 * KS + dx) * KC * NB + q * 16],
+                                                           b_base[(2 * KS + dx) * KC * NB + q * 16], 0.f);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap[r], bp, acc[r][q], 0, 0, 0);
+                    }
+                    continue;
+                }
                 if constexpr (IN == IN_BNRELU && !kInPlace && !(EXP & 2)) {
                     // BN + ReLU two rows at a time: v_pk_add_f32 / v_pk_fma_f32 do the subtract and the fma of both values
                     // in one instruction each (same roundings as the scalar fmaf), so 4 VALU per pair instead of 6
@@ -563,7 +585,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     conv_epilogue<Q, EPI, R>(po, acc, s_aux + 3 * cap, s_aux + 3 * cap + 4 * NB, x0, y0, wx, wy, co_base, n);
 }
 
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0, int EXP = 0, int PH = -1>
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF = 0, int EXP = 0, int PH = -1, int BF = 0>
 inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     static_assert(XF == 0 || NBUF == 2 || IN != IN_BNRELU, "the in-place transform pipeline is written for two buffers");
     using G = ConvGeom<KS, KC, WX, R, VEC>;
@@ -575,35 +597,35 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     const size_t smem = S::bytes(p.bn_cap);
     static size_t configured = 0;
     if (smem > 48 * 1024 && smem > configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH>),
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         configured = smem;
     }
-    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH><<<grid, kConvThreads, smem, stream>>>(p);
+    conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH, BF><<<grid, kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
 // 16-byte DMA whenever the input rows are float4-aligned, dword DMA otherwise
-template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW = 1>
+template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW = 1, int BF = 0>
 inline int launch_conv_dma(const ConvParams& p, hipStream_t stream) {
     if constexpr (IN != IN_UPSAMPLE && IN != IN_UNPOOL) {
         const bool aligned = (p.w % 4 == 0) && (p.in_w % 4 == 0) && (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) &&
                              (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
-        if (aligned) return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 4>(p, stream);
+        if (aligned) return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 4, 0, 0, -1, BF>(p, stream);
     }
-    return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 1>(p, stream);
+    return launch_conv_dma_vec<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, 1, 0, 0, -1, BF>(p, stream);
 }
 
 // tile-shape choice as launch_conv_auto; KC is the per-chunk depth of the double-buffered pipeline
-template <int KS, int KC, int Q, int IN, int EPI, int BIG_R = 8, int NBUF = 2, int BIG_MINW = 1>
+template <int KS, int KC, int Q, int IN, int EPI, int BIG_R = 8, int NBUF = 2, int BIG_MINW = 1, int BF = 0>
 inline int launch_conv_dma_auto(const ConvParams& p, hipStream_t stream) {
     const long tiles_big = static_cast<long>((p.w + 31) / 32) * ((p.h + 15) / 16) * p.n;
-    if (tiles_big >= 512) return launch_conv_dma<KS, KC, Q, IN, EPI, 2, BIG_R, NBUF, BIG_MINW>(p, stream);
+    if (tiles_big >= 512) return launch_conv_dma<KS, KC, Q, IN, EPI, 2, BIG_R, NBUF, BIG_MINW, BF>(p, stream);
     const long tiles_mid = static_cast<long>((p.w + 15) / 16) * ((p.h + 15) / 16) * p.n;
-    if (tiles_mid >= 384) return launch_conv_dma<KS, KC, Q, IN, EPI, 1, 4, NBUF>(p, stream);
+    if (tiles_mid >= 384) return launch_conv_dma<KS, KC, Q, IN, EPI, 1, 4, NBUF, 1, BF>(p, stream);
     constexpr int KCS = (NBUF == 2 && KS == 3 && KC <= 8) ? 16 : KC;
-    return launch_conv_dma<KS, KCS, Q, IN, EPI, 1, 2, NBUF>(p, stream);
+    return launch_conv_dma<KS, KCS, Q, IN, EPI, 1, 2, NBUF, 1, BF>(p, stream);
 }
 
 }  // namespace endo

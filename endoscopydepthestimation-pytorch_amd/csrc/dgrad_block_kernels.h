@@ -80,7 +80,9 @@ struct DgradBlockGeom {
 // the library instantiates GP = 1.
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x / dbuf loads, 2 = no stores,
 // 4 = weight slice loaded once, 8 = no BN-sum reduction, 16 = no dY tile load, 32 = epilogue reduced to an add
-template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1, int VEC = 1>
+// BF: 1 = bf16 MFMA operands (ENDO_OPT_MFMA_BF16): the three row taps of a map and column tap in one v_mfma_f32_16x16x16_bf16
+// (conv_dma_kernels.h, BF), fp32 accumulation and epilogue
+template <int NL, int WX, int R, int GP, int EXP = 0, int PIPE = 1, int VEC = 1, int BF = 0>
 __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBlockParams p0) {
     using G = DgradBlockGeom<NL, WX, R, GP, VEC>;
     const int grp = p0.group_n > 0 ? blockIdx.z / p0.group_n : 0;
@@ -296,6 +298,21 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
                 const int set = quad & 1;
                 if (quad + 1 < 3) load_quad(quad + 1, set ^ 1);
                 __builtin_amdgcn_sched_barrier(0);        // keep the reads above, the MFMAs below
+                if constexpr (BF != 0) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        bf16x4_bits ap[R];
+#pragma unroll
+                        for (int r = 0; r < R; ++r) ap[r] = pack_bf16x4(av[set][dx][r], av[set][dx][r + 1], av[set][dx][r + 2], 0.f);
+#pragma unroll
+                        for (int a = 0; a < GP; ++a)
+                            if (a == 0 || second) {
+                                const bf16x4_bits bp = pack_bf16x4(bw[set][dx][a], bw[set][3 + dx][a], bw[set][6 + dx][a], 0.f);
+#pragma unroll
+                                for (int r = 0; r < R; ++r) acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap[r], bp, acc[a][r], 0, 0, 0);
+                            }
+                    }
+                } else
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
@@ -392,14 +409,14 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
     if (po_gs >= 0) store_pending();
 }
 
-template <int NL, int WX, int R, int GP = 1, int EXP = 0, int PIPE = 1, int VEC = 1>
+template <int NL, int WX, int R, int GP = 1, int EXP = 0, int PIPE = 1, int VEC = 1, int BF = 0>
 inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
     using G = DgradBlockGeom<NL, WX, R, GP, VEC>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     static bool configured = false;
     if (!configured && G::kBytes > 48 * 1024) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
@@ -409,7 +426,7 @@ inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
     int ysplit = (768 + tiles - 1) / tiles;
     if (ysplit > gsets) ysplit = gsets;
     if (ysplit < 1) ysplit = 1;
-    dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), kConvThreads, G::kBytes, stream>>>(p);
+    dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC, BF><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), kConvThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -436,7 +453,7 @@ struct DgradBlock8Geom {
     static_assert(kBytes <= 80 * 1024, "two blocks per CU");
 };
 
-template <int NL>
+template <int NL, int BF = 0>
 __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockParams p0) {
     using G = DgradBlock8Geom<NL>;
     constexpr int R = G::R;
@@ -571,6 +588,13 @@ __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockPa
                     float av[R + 2];
 #pragma unroll
                     for (int r = 0; r < R + 2; ++r) av[r] = a_base[r * G::kCols + dx];
+                    if constexpr (BF != 0) {
+                        const bf16x4_bits bp = pack_bf16x4(b_base[dx * 12 * 16], b_base[(3 + dx) * 12 * 16], b_base[(6 + dx) * 12 * 16], 0.f);
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            acc[r] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16x4(av[r], av[r + 1], av[r + 2], 0.f), bp, acc[r], 0, 0, 0);
+                        continue;
+                    }
 #pragma unroll
                     for (int dy = 0; dy < 3; ++dy) {
                         const float b = b_base[(dy * 3 + dx) * 12 * 16];
@@ -638,14 +662,14 @@ __global__ void __launch_bounds__(512, 4) dgrad_block8_kernel(const DgradBlockPa
     }
 }
 
-template <int NL>
+template <int NL, int BF = 0>
 inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
     using G = DgradBlock8Geom<NL>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     static bool configured = false;
     if (!configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block8_kernel<NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block8_kernel<NL, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
@@ -654,7 +678,7 @@ inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
     int ysplit = (1024 + tiles - 1) / tiles;          // 4 blocks per CU at the coarse levels (in-job A/B: -1.5 % on the family vs 512)
     if (ysplit > pairs) ysplit = pairs;
     if (ysplit < 1) ysplit = 1;
-    dgrad_block8_kernel<NL><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), G::kThreads, G::kBytes, stream>>>(p);
+    dgrad_block8_kernel<NL, BF><<<dim3(p.tiles_x * tiles_y, ysplit, p.n), G::kThreads, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

@@ -546,6 +546,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //                                            3 / 4 = Winograd with 3 / 4 stages
 //   ENDO_OPT_WINO_DGRAD  / ENDO_WINO_DGRAD   fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd
 //   ENDO_OPT_DGRAD_VEC   / ENDO_DGRAD_VEC    new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
+//   ENDO_OPT_MFMA_BF16   / ENDO_MFMA_BF16    1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
 //   ENDO_OPT_WINO_MIN_TILES / ENDO_WINO_MIN_TILES   a Winograd kernel is used from this many tiles per launch on (default 1024: the
 //                                            levels whose launches fill the chip several times; tests set 1 to reach the kernels at small sizes)
 static int g_options[ENDO_OPT_COUNT];
@@ -557,6 +558,7 @@ static int option(int id) {
         g_options[ENDO_OPT_WINO_DGRAD] = env("ENDO_WINO_DGRAD", 1);
         g_options[ENDO_OPT_DGRAD_VEC] = env("ENDO_DGRAD_VEC", 1);
         g_options[ENDO_OPT_WINO_MIN_TILES] = env("ENDO_WINO_MIN_TILES", 1024);
+        g_options[ENDO_OPT_MFMA_BF16] = env("ENDO_MFMA_BF16", 0);
         g_options_init = true;
     }
     return g_options[id];
@@ -565,6 +567,11 @@ static int wino_fwd_mode() { return option(ENDO_OPT_WINO_FWD); }
 static bool wino_fwd_enabled() { return wino_fwd_mode() != 0; }
 static bool wino_dgrad_enabled() { return option(ENDO_OPT_WINO_DGRAD) != 0; }
 static bool dgrad_vec_enabled() { return option(ENDO_OPT_DGRAD_VEC) != 0; }
+// bit 0: weight gradients, bit 1: forward, bit 2: data gradients of the dense layers (1 = all three)
+static int mfma_bf16_mask() { const int v = option(ENDO_OPT_MFMA_BF16); return v == 1 ? 7 : (v >> 1); }
+static bool mfma_bf16_wgrad() { return (mfma_bf16_mask() & 1) != 0; }
+static bool mfma_bf16_fwd() { return (mfma_bf16_mask() & 2) != 0; }
+static bool mfma_bf16_dgrad() { return (mfma_bf16_mask() & 4) != 0; }
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
@@ -580,7 +587,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
     // 32 x 16 pixel tiles while they fill the chip several times over, 32 x 8 below that.
-    if (wino_fwd_enabled() && cv.u >= 0) {
+    if (wino_fwd_enabled() && cv.u >= 0 && !mfma_bf16_fwd()) {
         ConvParams pw = p;
         pw.wgt = c.tape + c.net->wino_off + cv.u;          // group 0's tape: weights are shared by the groups
         const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
@@ -631,7 +638,8 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;      // inside one group's tape
         p.out = partial; p.out_ns = static_cast<int64_t>(cv.cout) * lv.plane;
         p.bias = nullptr; p.out_sums = nullptr;
-        int rc = launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
+        int rc = mfma_bf16_fwd() ? launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream)
+                             : launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
         if (rc) return rc;
         int bx = static_cast<int>((lv.plane + 255) / 256);
         bx = bx > 8 ? 8 : bx;
@@ -646,6 +654,11 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     const long tiles_wide = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
     // level 0 stays on 32x16: in the training step (A/B of two library builds inside one job) it is 5 % faster than 32x8,
     // although the isolated microbenchmark prefers 32x8 by 5 %
+    if (mfma_bf16_fwd()) {          // bf16 MFMA operands (ENDO_OPT_MFMA_BF16): the same tile shapes
+        if (tiles_big < 1024 && tiles_wide >= 1024) return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 1>(p, c.stream);
+        if (tiles_big < 1024 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream);
+        return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1, 1>(p, c.stream);
+    }
     if (tiles_big < 1024 && tiles_wide >= 1024) return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1>(p, c.stream);
     if (tiles_big < 1024 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
     return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
@@ -749,7 +762,7 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
-    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream);
+    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, mfma_bf16_wgrad());
     return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }
 
@@ -849,7 +862,10 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             {
                 ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * kGrowth * kGrowth * 9 * nl,
                                4.0 * c.nt() * lv.plane * (3.0 * kGrowth + kGrowth * nl));
-                if (dgrad_block_vec_ok(p) && dgrad_vec_enabled())
+                if (mfma_bf16_dgrad() && dgrad_block_vec_ok(p))
+                    rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4, 1>(p, c.stream)
+                       : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4, 1>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4, 1>(p, c.stream);
+                else if (dgrad_block_vec_ok(p) && dgrad_vec_enabled())
                     rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4>(p, c.stream)
                        : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4>(p, c.stream);
                 else
@@ -879,7 +895,9 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                        4.0 * c.nt() * lv.plane * (3.0 * c0 + kGrowth * kLayers));
         int rc;
         const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
-        if (wino_dgrad_enabled() && dgrad_wino_ok(p) && wtiles >= option(ENDO_OPT_WINO_MIN_TILES) && cv[0].ud >= 0) {
+        if (mfma_bf16_dgrad()) {
+            rc = launch_dgrad_block8<4, 1>(p, c.stream);
+        } else if (wino_dgrad_enabled() && dgrad_wino_ok(p) && wtiles >= option(ENDO_OPT_WINO_MIN_TILES) && cv[0].ud >= 0) {
             // fine levels: Winograd F(2x2, 3x3), 48 instead of 108 MFMAs per 64 pixels and step (dgrad_wino_kernels.h)
             const float* ub = c.gradws + c.net->wd_off;
             const float* const u[4] = {ub + cv[0].ud, ub + cv[1].ud, ub + cv[2].ud, ub + cv[3].ud};

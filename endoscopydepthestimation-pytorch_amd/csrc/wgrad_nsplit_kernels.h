@@ -35,7 +35,8 @@ constexpr int kNsMG = 7;
 constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
 
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x loads, 2 = no dY DMA, 4 = no barrier
-template <int NG, int EXP = 0>
+// BF: 1 = bf16 MFMA operands (fp32 accumulation, fp32 memory): the 4 k-steps of a float4 become one v_mfma_f32_16x16x16_bf16
+template <int NG, int EXP = 0, int BF = 0>
 __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradParams p, float* __restrict__ partial,
                                                                     int chunks_per_block) {
     __shared__ __attribute__((aligned(16))) float smem[3 * kNsBuf];      // dY windows of the chunk computed and the two in flight
@@ -204,6 +205,22 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         if (chunk + 2 < c_end) issue(buf == 0 ? 2 : buf - 1, slot_c);          // the buffer computed last iteration
 
         const float* s_dy = smem + buf * kNsBuf;
+        if constexpr (BF != 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x4_bits bq[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) bq[g] = pack_bf16x4(bv[g][q][0], bv[g][q][1], bv[g][q][2], bv[g][q][3]);
+#pragma unroll
+                for (int m = 0; m < kNsMG; ++m) {
+                    const float* ap = s_dy + aoff[m] + 16 * q;
+                    const bf16x4_bits aq = pack_bf16x4(ap[0], ap[1], ap[2], ap[3]);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bq[g], acc[g][m], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -274,14 +291,14 @@ inline bool wgrad_nsplit_ok(const WgradParams& p) {
     return aligned && p.cout == 12 && chunks >= 4 * kNsMaxBlocks;
 }
 
-template <int NG, int EXP = 0>
+template <int NG, int EXP = 0, int BF = 0>
 inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int passes, hipStream_t stream) {
     const int chunks_total = ((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
     int blocks = (NG == 3 ? 512 : NG == 2 ? 768 : 1024) / passes;   // resident blocks per CU by register count: 2 / 3 / 4
     const int per = (chunks_total + blocks - 1) / blocks;
     blocks = (chunks_total + per - 1) / per;
     const int groups_total = (p.cin + 15) / 16;
-    wgrad_nsplit_kernel<NG, EXP><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
+    wgrad_nsplit_kernel<NG, EXP, BF><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
     ENDO_LAUNCH_CHECK();
     wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 8), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();
@@ -289,11 +306,16 @@ inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int pass
 }
 
 // scratch: kNsScratchFloats floats
-inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream) {
+inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream, bool bf16_operands = false) {
     const int groups = (p.cin + 15) / 16;
     const int passes = (groups + 11) / 12;                       // at most 3 groups per wave
     const int per_pass = (groups + passes - 1) / passes;
     const int ng = (per_pass + 3) / 4;
+    if (bf16_operands) {
+        if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 1>(p, scratch, passes, stream);
+        if (ng == 2) return launch_wgrad_nsplit_ng<2, 0, 1>(p, scratch, passes, stream);
+        return launch_wgrad_nsplit_ng<3, 0, 1>(p, scratch, passes, stream);
+    }
     if (ng <= 1) return launch_wgrad_nsplit_ng<1>(p, scratch, passes, stream);
     if (ng == 2) return launch_wgrad_nsplit_ng<2>(p, scratch, passes, stream);
     return launch_wgrad_nsplit_ng<3>(p, scratch, passes, stream);

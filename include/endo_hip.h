@@ -178,16 +178,21 @@ int endo_net_groups(const endo_net* net);
 int endo_set_wgrad_overlap(int enable);
 /* Kernel-selection options, process-wide like the above; defaults come from the environment variable of the same name (without
  * the OPT_) at first use, so one build can be A/B-timed inside one job.  Returns the previous value, -1 for an unknown option.
- * Every setting computes the same function; tests use ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
+ * Every setting but ENDO_OPT_MFMA_BF16 computes the same function; tests use ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
  *   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 direct convolution, 1 Winograd F(2x2,3x3) (default), 3 / 4 = with 3 / 4 LDS stages
  *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd (default)
  *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 1 = 16-byte DMA of the gradient tiles (default), 0 = dword
- *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024) */
+ *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024)
+ *   ENDO_OPT_MFMA_BF16       NOT the same function: 1 = the dense layers' convolution kernels round their MFMA operands to bf16
+ *                            (v_mfma_f32_16x16x16_bf16; fp32 accumulation, fp32 tensors in memory) -- the mixed-precision mode of
+ *                            BASELINE configs[2], with its own tolerance; default 0 = fp32 operands.
+ *                            Development values 2 * mask (mask bit 0 weight gradients, 1 forward, 2 data gradients) select families */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2
 #define ENDO_OPT_WINO_MIN_TILES 3
-#define ENDO_OPT_COUNT 4
+#define ENDO_OPT_MFMA_BF16 4
+#define ENDO_OPT_COUNT 5
 int endo_set_option(int option_id, int value);
 int64_t endo_net_group_stride(const endo_net* net);
 void endo_net_destroy(endo_net* net);

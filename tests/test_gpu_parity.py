@@ -380,7 +380,7 @@ def test_network_backward(shape):
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
 
 
-OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES = 0, 1, 2, 3
+OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES, OPT_MFMA_BF16 = 0, 1, 2, 3, 4
 
 
 class kernel_options(object):
@@ -427,6 +427,62 @@ def test_network_backward_kernel_forms(shape, which):
     y64 = onet.forward(state_as(state, torch.float64), x.double(), training=True, pattern=pattern)
     assert_close(y, y64, 1e-5, "depth, %s kernels" % which)
     assert_grads_on_pattern(params, g64p, None, GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
+
+
+BF16_FWD_TOL = 2e-2       # bf16-operand mode (ENDO_OPT_MFMA_BF16): depth against the fp64 oracle on the pass's own pattern, max error / max
+BF16_GRAD_TOL = 1e-1      # ... and every parameter gradient, max error / the tensor's max (operands carry 8 significant bits;
+                          # measured: depth 6e-3 / 7e-3, gradient tensors median 9.5e-3 / 5.6e-3, worst 6.0e-2 / 4.9e-2 -- the
+                          # bottleneck layers, whose BN normalises over 2 x (2 x 3) and 2 x (8 x 10) values)
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 256, 320)])
+def test_bf16_operand_mode_on_pattern(shape):
+    """ENDO_OPT_MFMA_BF16 = 1 (the mixed-precision mode behind bench.py --config 2): the dense layers' forward, data-gradient and
+    weight-gradient kernels round their MFMA operands to bf16 and accumulate in fp32; tensors in memory, BN statistics, the
+    BN / ReLU / pooling arithmetic, reductions and the optimizer stay fp32.  It is a different function from the fp32 path, so it
+    has its own stated tolerance: depth and all 210 gradients against the fp64 oracle evaluated on the activation pattern this
+    very pass took (the comparison that is meaningful for a piecewise-linear network, see test_network_backward).  The second
+    shape is large enough for the n-split weight gradient and the fused data-gradient kernels of the benchmark."""
+    n, h, w = shape
+    with kernel_options({OPT_MFMA_BF16: 1}):
+        state, model = make_model(65)
+        rng = np.random.default_rng(17)
+        x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+        cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+        model.train()
+        y = model(x.to(dev()))
+        (pattern,) = pattern_of(y, model, n, h, w)
+        (y * cot.to(dev())).sum().backward()
+        torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    g64p = reference_grads(state, x, cot, torch.float64, pattern)
+    y64 = onet.forward(state_as(state, torch.float64), x.double(), training=True, pattern=pattern)
+    assert_close(y, y64, BF16_FWD_TOL, "depth, bf16 operands")
+    report = assert_grads_on_pattern(params, g64p, None, BF16_GRAD_TOL, "network backward %s, bf16 operands" % (shape,))
+    errors = sorted(r[0] for r in report)
+    print("bf16 operands %s: depth err %.2e, gradient errors median %.2e, max %.2e" % (
+        shape, float((y.detach().double().cpu() - y64).abs().max() / y64.abs().max()), errors[len(errors) // 2], errors[-1]))
+    assert errors[len(errors) // 2] <= 1.5e-2
+    assert errors[-1] > 1e-4, "the bf16 kernels did not run"
+
+
+def test_bf16_operand_training_iterations():
+    """A few fused training iterations in bf16-operand mode: first-iteration loss within 1 % of the fp32 path on the same batch,
+    every iteration finite and not skipped."""
+    n, h, w = 2, 128, 160
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=92, sparse_points=800))
+    losses = {}
+    for mode in (0, 1):
+        with kernel_options({OPT_MFMA_BF16: mode}):
+            _, model = make_model(66, positive_depth=True)
+            model.train()
+            step = ea.train_step.TrainingStep(model, ea.optim.FusedClipSGD(model, lr=1.0e-4), h, w)
+            outs = [step(batch) for _ in range(4)]
+            torch.cuda.synchronize()
+        assert all(not o["skipped"] and np.isfinite(o["loss"]) for o in outs)
+        losses[mode] = [o["loss"] for o in outs]
+    assert abs(losses[1][0] - losses[0][0]) <= 1e-2 * abs(losses[0][0]), losses
+    assert abs(losses[1][0] - losses[0][0]) > 0.0
 
 
 def reference_pattern(state64, x64):
