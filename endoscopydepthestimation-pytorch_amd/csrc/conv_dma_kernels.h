@@ -60,7 +60,8 @@ struct ConvDmaSmem {
 // 3 of those instead of 9 v_mfma_f32_16x16x4_f32; operands are rounded to bf16 after BN + ReLU, accumulation stays fp32.
 template <int KS, int KC, int Q, int IN, int EPI, int WX, int R, int NBUF, int MINW, int VEC, int XF, int EXP = 0, int PH = -1, int BF = 0>
 __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const ConvParams p0) {
-    static_assert(BF == 0 || (KS == 3 && PH < 0 && (IN == IN_BNRELU || IN == IN_PLAIN)), "bf16 operands: the ordinary 3x3 convolution");
+    static_assert(BF == 0 || (PH < 0 && (KS == 3 || KS == 1) && (IN == IN_BNRELU || IN == IN_PLAIN || (IN == IN_UNPOOL && KS == 1))),
+                  "bf16 operands: the ordinary 3x3 convolution and the 1x1 convolutions of the transition-down layers");
     static_assert(PH < 0 || (KS == 3 && (Q % 2) == 0 && IN == IN_PLAIN && EPI == EPI_FWD), "phase mode is the transition-up forward");
     static_assert(IN != IN_UNPOOL || (KS == 1 && R % 2 == 0), "UNPOOL is the transition-down data gradient (1x1)");
     static_assert(NBUF == 1 || NBUF == 2, "one or two LDS buffers");      // (three buffers, DMA two chunks ahead: 7 % slower in the in-job A/B)
@@ -356,6 +357,47 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
             const int pcol = (wx + li) >> 1;
             const unsigned sh = 8u * (pcol & 3);
             const unsigned want = li & 1;
+            if constexpr (BF != 0) {
+                // 1x1: the channel quads of a chunk are the k = 4 lk + i of one bf16 instruction (missing quads are zeros)
+                constexpr int NQ = KC / 4;
+#pragma unroll
+                for (int qg = 0; qg < (NQ + 3) / 4; ++qg) {
+                    float a[4][R], b[4][Q];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int quad = qg * 4 + i;
+                        if (quad < NQ) {
+                            const float* g_base = s_in + (quad * 4 + lk) * S::kUStride + (wy >> 1) * PC + pcol;
+                            const unsigned* i_base = reinterpret_cast<const unsigned*>(s_in + (quad * 4 + lk) * S::kUStride + S::kUG);
+                            const float* b_base = s_w + (quad * 4 + lk) * NB + li;
+#pragma unroll
+                            for (int rr = 0; rr < R / 2; ++rr) {
+                                const float g = g_base[rr * PC];
+                                const unsigned code = (i_base[(((wy >> 1) + rr) * PC + pcol) >> 2] >> sh) & 0xffu;
+                                a[i][2 * rr] = code == want ? g : 0.f;
+                                a[i][2 * rr + 1] = code == want + 2u ? g : 0.f;
+                            }
+#pragma unroll
+                            for (int q = 0; q < Q; ++q) b[i][q] = b_base[q * 16];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < R; ++r) a[i][r] = 0.f;
+#pragma unroll
+                            for (int q = 0; q < Q; ++q) b[i][q] = 0.f;
+                        }
+                    }
+                    bf16x4_bits ap[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) ap[r] = pack_bf16x4(a[0][r], a[1][r], a[2][r], a[3][r]);
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) {
+                        const bf16x4_bits bp = pack_bf16x4(b[0][q], b[1][q], b[2][q], b[3][q]);
+#pragma unroll
+                        for (int r = 0; r < R; ++r) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap[r], bp, acc[r][q], 0, 0, 0);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int quad = 0; quad < KC / 4; ++quad) {
                 const float* g_base = s_in + (quad * 4 + lk) * S::kUStride + (wy >> 1) * PC + pcol;
@@ -374,6 +416,48 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                     const float b = b_base[q * 16];
 #pragma unroll
                     for (int r = 0; r < R; ++r) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], b, acc[r][q], 0, 0, 0);
+                }
+            }
+            return;
+        }
+        if constexpr (BF != 0 && KS == 1) {
+            constexpr int NQ = KC / 4;
+#pragma unroll
+            for (int qg = 0; qg < (NQ + 3) / 4; ++qg) {
+                float a[4][R], b[4][Q];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int quad = qg * 4 + i;
+                    if (quad < NQ) {
+                        const float* a_base = s_in + (quad * 4 + lk) * G::kCS + wy * G::kCols + wx + li + G::kColOff;
+                        const float* b_base = s_w + (quad * 4 + lk) * NB + li;
+                        float sc = 1.f, mn = 0.f, bt = 0.f;
+                        if constexpr (IN == IN_BNRELU && !kInPlace) {
+                            const int ch = chunk * KC + quad * 4 + lk;
+                            sc = s_aux[ch]; mn = s_aux[cap + ch]; bt = s_aux[2 * cap + ch];
+                        }
+#pragma unroll
+                        for (int r = 0; r < R; ++r) {
+                            const float v = a_base[r * G::kCols];
+                            a[i][r] = (IN == IN_BNRELU && !kInPlace) ? __builtin_fmaxf(fmaf(v - mn, sc, bt), 0.f) : v;
+                        }
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) b[i][q] = b_base[q * 16];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < R; ++r) a[i][r] = 0.f;
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) b[i][q] = 0.f;
+                    }
+                }
+                bf16x4_bits ap[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) ap[r] = pack_bf16x4(a[0][r], a[1][r], a[2][r], a[3][r]);
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const bf16x4_bits bp = pack_bf16x4(b[0][q], b[1][q], b[2][q], b[3][q]);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) acc[r][q] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap[r], bp, acc[r][q], 0, 0, 0);
                 }
             }
             return;

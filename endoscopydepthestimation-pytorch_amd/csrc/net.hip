@@ -679,6 +679,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.out_sums = c.out_sums(next, oc0);
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
+    if (mfma_bf16_fwd()) return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 2, 1, 1>(p, c.stream);
     return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower)
 }
 
@@ -763,7 +764,8 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, mfma_bf16_wgrad());
-    return wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_BNRELU>(p, c.stream) : launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
+    if (wgrad_taps_ok(p)) return mfma_bf16_wgrad() ? launch_wgrad_taps<12, IN_BNRELU, 1>(p, c.stream) : launch_wgrad_taps<12, IN_BNRELU>(p, c.stream);
+    return launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }
 
 // dense layer backward: bias grad + deferred-term fold, wgrad, dgrad fused with ReLU/BN backward
@@ -941,7 +943,8 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         rc = c.fork_wgrad(cw, level);
         if (rc) return rc;
         ProfScope prof(kProfWgradOther, cw.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * cv.cin);
-        rc = wgrad1x1_dma_ok(p) ? launch_wgrad1x1_dma(p, cw.stream) : launch_wgrad1x1(p, cw.stream);
+        rc = wgrad1x1_dma_ok(p) ? (mfma_bf16_wgrad() ? launch_wgrad1x1_dma<1>(p, cw.stream) : launch_wgrad1x1_dma<0>(p, cw.stream))
+                                : launch_wgrad1x1(p, cw.stream);
         if (rc) return rc;
     }
     {
@@ -957,7 +960,8 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
-        rc = (nx.w % 4 == 0) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream)
+        rc = (nx.w % 4 == 0) ? (mfma_bf16_dgrad() ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4, 2, 1, 1>(p, c.stream)
+                                                  : launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream))
                              : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
         if (rc) return rc;
     }

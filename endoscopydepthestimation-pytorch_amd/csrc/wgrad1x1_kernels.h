@@ -25,6 +25,9 @@ constexpr int kP1DyStride = kP1Seg / 2 + kP1Seg / 8 + 1;
 constexpr int kP1Buf = kP1Tile * (kP1ActStride + kP1DyStride);     // floats per buffer
 constexpr size_t kP1Bytes = 2 * kP1Buf * sizeof(float);
 
+// BF: 1 = bf16 MFMA operands (ENDO_OPT_MFMA_BF16): four consecutive k-steps (pixels 4 ks + lk, ks = 4 g .. 4 g + 3) form the
+// k = 4 lk + i of one v_mfma_f32_16x16x16_bf16; un-routing and BN + ReLU stay fp32
+template <int BF = 0>
 __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x;
@@ -115,12 +118,10 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int d = 0; d < 4; ++d) cw[i][d] = __float_as_uint(g_base[i * 16 * kP1DyStride + kP1Seg / 2 + d]);
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
+        auto operands = [&](int ks, float (&a)[3], float (&b)[3]) {
             // k = pixel 4*ks + lk of the chunk: row ks>>3, x = 4*(ks&7) + lk; pooled column x>>1, code 2*row + (x&1)
             const int pc = 2 * (ks & 7) + (lk >> 1);
             const unsigned want = 2u * (ks >> 3) + lane_want;
-            float a[3], b[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float g = g_base[i * 16 * kP1DyStride + pc];
@@ -129,10 +130,34 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
                 const float v = b_base[i * 16 * kP1ActStride + 4 * ks];
                 b[i] = __builtin_fmaxf(fmaf(v - mn[i], sc[i], bt[i]), 0.f);
             }
+        };
+        if constexpr (BF != 0) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int g4 = 0; g4 < 4; ++g4) {
+                float a[4][3], b[4][3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) operands(4 * g4 + i, a[i], b[i]);
+                bf16x4_bits ap[3], bp[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    ap[i] = pack_bf16x4(a[0][i], a[1][i], a[2][i], a[3][i]);
+                    bp[i] = pack_bf16x4(b[0][i], b[1][i], b[2][i], b[3][i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ap[i], bp[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                float a[3], b[3];
+                operands(ks, a, b);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     };
 
@@ -166,6 +191,7 @@ inline bool wgrad1x1_dma_ok(const WgradParams& p) {
            (reinterpret_cast<uintptr_t>(p.dy_idx) % 4 == 0);
 }
 
+template <int BF = 0>
 inline int launch_wgrad1x1_dma(const WgradParams& p, hipStream_t stream) {
     const int tiles_co = (p.cout + kP1Tile - 1) / kP1Tile;
     const int tiles_ci = (p.cin + kP1Tile - 1) / kP1Tile;
@@ -175,11 +201,11 @@ inline int launch_wgrad1x1_dma(const WgradParams& p, hipStream_t stream) {
     if (splits > chunks_total) splits = chunks_total;
     static bool configured = false;
     if (!configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_dma_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(kP1Bytes)));
         configured = true;
     }
-    wgrad1x1_dma_kernel<<<dim3(splits, tiles_co, tiles_ci), kConvThreads, kP1Bytes, stream>>>(p);
+    wgrad1x1_dma_kernel<BF><<<dim3(splits, tiles_co, tiles_ci), kConvThreads, kP1Bytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

@@ -41,7 +41,8 @@ struct WgradTapsGeom {
     static_assert(kBytes <= 160 * 1024, "two tile buffers must fit the 160 KiB LDS");
 };
 
-template <int COUT, int IN>
+// BF: 1 = bf16 MFMA operands (ENDO_OPT_MFMA_BF16): four consecutive k-steps of a row (pixels 4 x4 + lk) in one v_mfma_f32_16x16x16_bf16
+template <int COUT, int IN, int BF = 0>
 __global__ void __launch_bounds__(512, 4) wgrad_taps_kernel(const WgradParams p) {
     using G = WgradTapsGeom<COUT>;
     static_assert(IN == IN_BNRELU || IN == IN_PLAIN || IN == IN_UPSAMPLE, "supported activation load paths");
@@ -186,6 +187,25 @@ __global__ void __launch_bounds__(512, 4) wgrad_taps_kernel(const WgradParams p)
 #pragma unroll
         for (int rr = 0; rr < rows_per_wave; ++rr) {
             const int row = wave * rows_per_wave + rr;
+            if constexpr (BF != 0) {
+                static_assert(G::kTX % 16 == 0, "whole groups of four k-steps");
+#pragma unroll
+                for (int xg = 0; xg < G::kTX / 16; ++xg) {
+                    float b[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        b[i] = s_in[li * G::kCS + row * G::kTX + (4 * xg + i) * 4 + lk];
+                        if constexpr (IN == IN_BNRELU) b[i] = __builtin_fmaxf(fmaf(b[i] - bmn, bsc, bbt), 0.f);
+                    }
+                    const bf16x4_bits bp = pack_bf16x4(b[0], b[1], b[2], b[3]);
+                    const int abase = row * G::kDyCols + 16 * xg + lk;
+#pragma unroll
+                    for (int g = 0; g < MG; ++g) {
+                        const float* ap = s_dy + aoff[g] + abase;
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pack_bf16x4(ap[0], ap[4], ap[8], ap[12]), bp, acc[g], 0, 0, 0);
+                    }
+                }
+            } else
 #pragma unroll 2
             for (int x4 = 0; x4 < G::kTX / 4; ++x4) {
                 const int pix = row * G::kTX + x4 * 4 + lk;
@@ -226,7 +246,7 @@ __global__ void __launch_bounds__(512, 4) wgrad_taps_kernel(const WgradParams p)
     }
 }
 
-template <int COUT, int IN>
+template <int COUT, int IN, int BF = 0>
 inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
     using G = WgradTapsGeom<COUT>;
     p.tiles_x = (p.w + G::kTX - 1) / G::kTX;
@@ -241,11 +261,11 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
     if (groups >= 16) groups &= ~7;            // multiple of 8: enables the XCD-local block order
     static bool configured = false;
     if (!configured && G::kBytes > 48 * 1024) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<COUT, IN>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<COUT, IN, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
-    wgrad_taps_kernel<COUT, IN><<<dim3(ci_chunks, groups, co_sets), 64 * G::kWaves, G::kBytes, stream>>>(p);
+    wgrad_taps_kernel<COUT, IN, BF><<<dim3(ci_chunks, groups, co_sets), 64 * G::kWaves, G::kBytes, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
