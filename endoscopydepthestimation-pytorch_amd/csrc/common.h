@@ -65,6 +65,15 @@ __device__ __forceinline__ bf16x4_bits pack_bf16x4(float a, float b, float c, fl
     return __builtin_bit_cast(bf16x4_bits, u32x2_t{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
 }
 
+// eight consecutive k values of a lane for v_mfma_f32_16x16x32_bf16 (gfx950: twice the k of the x16 form in the same 16-18 cycles,
+// tools/mfma_rate_probe)
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8_t pack_bf16x8(float a, float b, float c, float d, float e, float f, float g, float h) {
+    typedef float f32x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_convertvector(f32x8_t{a, b, c, d, e, f, g, h}, bf16x8_t);
+}
+
 // Block-wide sum of K per-thread partials, one fp64 atomic per value per block.
 // scratch: K * (blockDim/64) doubles of LDS.  All threads must call.
 template <int K>

@@ -206,19 +206,18 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
 
         const float* s_dy = smem + buf * kNsBuf;
         if constexpr (BF != 0) {
+            // the lane's 8 pixels of the chunk (two float4s) are the k = 8 lk + i of ONE v_mfma_f32_16x16x32_bf16 per (row group, channel group)
+            bf16x8_t bq[NG];
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bf16x4_bits bq[NG];
+            for (int g = 0; g < NG; ++g)
+                bq[g] = pack_bf16x8(bv[g][0][0], bv[g][0][1], bv[g][0][2], bv[g][0][3], bv[g][1][0], bv[g][1][1], bv[g][1][2], bv[g][1][3]);
 #pragma unroll
-                for (int g = 0; g < NG; ++g) bq[g] = pack_bf16x4(bv[g][q][0], bv[g][q][1], bv[g][q][2], bv[g][q][3]);
+            for (int m = 0; m < kNsMG; ++m) {
+                const float* ap = s_dy + aoff[m];
+                const bf16x8_t aq = pack_bf16x8(ap[0], ap[1], ap[2], ap[3], ap[16], ap[17], ap[18], ap[19]);
 #pragma unroll
-                for (int m = 0; m < kNsMG; ++m) {
-                    const float* ap = s_dy + aoff[m] + 16 * q;
-                    const bf16x4_bits aq = pack_bf16x4(ap[0], ap[1], ap[2], ap[3]);
-#pragma unroll
-                    for (int g = 0; g < NG; ++g)
-                        if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bq[g], acc[g][m], 0, 0, 0);
-                }
+                for (int g = 0; g < NG; ++g)
+                    if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[g], acc[g][m], 0, 0, 0);
             }
         } else
 #pragma unroll
