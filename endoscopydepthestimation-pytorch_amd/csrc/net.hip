@@ -1133,7 +1133,7 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape + g * net->gs) + net->sums_off, 0, net->sums_bytes, c.stream));
-    if (wino_fwd_enabled()) {          // dense-layer weights in Winograd form, all 44 layers in one launch
+    if (wino_fwd_enabled() && !mfma_bf16_fwd()) {          // dense-layer weights in Winograd form, all 44 layers in one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * (tb.wino_floats + tb.wino_floats * 9 / 16));
         wino_fwd_weights_kernel<<<(tb.wino.start[tb.wino.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino, params, tape + net->wino_off);
         ENDO_LAUNCH_CHECK();
@@ -1201,7 +1201,7 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(gradws + g * net->gs + net->pq_off, 0,
                                   static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
-    if (wino_dgrad_enabled()) {          // data-gradient weights of the dense layers in Winograd form, one launch
+    if (wino_dgrad_enabled() && !mfma_bf16_dgrad()) {          // data-gradient weights of the dense layers in Winograd form, one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * 2.0 * tb.wino_dgrad_floats);
         dgrad_wino_weights_kernel<<<(tb.wino_dgrad.start[tb.wino_dgrad.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino_dgrad, params,
                                                                                                                  gradws + net->wd_off);
