@@ -9,6 +9,6 @@ The directory name carries a hyphen, so import it with
 ``importlib.import_module("endoscopydepthestimation-pytorch_amd")`` or ``import endo_amd``.
 """
 
-from . import _lib, distributed, losses, models, optim, scatter, scheduler, synthetic, train_step, utils  # noqa: F401
+from . import _lib, dataset, distributed, losses, models, optim, reader, scatter, scheduler, synthetic, train_step, utils  # noqa: F401
 from .models import FCDenseNet57, DepthScalingLayer, DepthWarpingLayer, FlowfromDepthLayer  # noqa: F401
 from .losses import SparseMaskedL1Loss, NormalizedDistanceLoss, ScaleInvariantLoss  # noqa: F401

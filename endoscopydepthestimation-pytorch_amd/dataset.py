@@ -1,0 +1,149 @@
+"""Training batches straight from sequence folders, assembled on the GPU -- the counterpart of the reference's
+``dataset.SfMDataset`` (train / validation phases, dataset.py:133-333 set-up, 335-460 ``__getitem__``) plus the ``DataLoader``
+that batches its samples (train.py:168-178, 254-270), without OpenCV / plyfile / albumentations and without a host image.
+
+    per folder (once)   reader.load_sequence  (or the reference's own precompute file, ``use_store_data``: dataset.py:320-331)
+                        -> scatter.SequenceScatter: point cloud, mask, visibility, per-view matrices resident in HBM
+    per sample          utils.generating_pos_and_increment (host RNG, same calls as the reference)
+    per batch           SequenceScatter.training_batch -> the 14 non-image tensors, reader.FrameDecoder -> the two colour tensors
+
+What the reference does per sample and this does not: the albumentations colour / blur / noise augmentations (train.py:121-144;
+out of scope) -- the colour tensors are the normalised frames, i.e. the reference's validation-phase tensors.
+A sample whose sparse depth masks come out empty is redrawn as in dataset.py:372-376.
+"""
+
+import os
+import pickle
+import random
+
+import numpy as np
+import torch
+
+from . import reader, scatter, utils
+
+
+def read_precompute_file(path):
+    """The list the reference pickles (dataset.py:310-319) as a dictionary of its fourteen entries."""
+    names = ("crop_positions", "selected_indexes", "visible_view_indexes", "point_cloud", "intrinsic_matrix", "mask_boundary",
+             "view_indexes_per_point", "extrinsics", "projection", "clean_point_list", "downsampling", "network_downsampling",
+             "inlier_percentage", "estimated_scale")
+    with open(str(path), "rb") as f:
+        entries = pickle.load(f)
+    if len(entries) != len(names):
+        raise ValueError("%s does not hold the %d entries of a precompute file" % (path, len(names)))
+    return dict(zip(names, entries))
+
+
+def _by_folder_name(table, folder):
+    """The reference keys its dictionaries by str(folder) on the machine that wrote the file; match by the folder's name."""
+    if folder in table:
+        return table[folder]
+    name = os.path.basename(os.path.normpath(folder))
+    for key, value in table.items():
+        if os.path.basename(os.path.normpath(str(key))) == name:
+            return value
+    raise KeyError("no precomputed entry for sequence %s" % folder)
+
+
+class TrainingBatches(object):
+    """Iterable over training batches (dictionaries keyed as ``synthetic.BATCH_KEYS``, everything on the device).
+
+    folder_list           sequence folders (``<root>/bag_x/_start_...``), as utils.get_parent_folder_names returns them
+    adjacent_range        (min, max) frame gap of a pair (train.py --adjacent_range)
+    precompute_path       the reference's precompute pickle (optional): crop window, matrices, scale and -- the part this
+                          package does not recompute -- the contaminated-point filter of every sequence.  Without it the
+                          folders are read with reader.load_sequence and no point is filtered.
+    image_file_names      the sample list (default: every ``0*.jpg`` of the folders, sorted, as utils.get_color_file_names)
+    num_iter              samples per epoch (dataset.py:137, 333); default: len(image_file_names)
+    """
+
+    def __init__(self, folder_list, adjacent_range, batch_size, downsampling=4.0, network_downsampling=64, visible_interval=30,
+                 precompute_path=None, image_file_names=None, num_iter=None, shuffle=True, rgb_mode="rgb", suggested_h=None,
+                 suggested_w=None, device="cuda", seed=None):
+        assert len(adjacent_range) == 2
+        self.folders = [str(f) for f in folder_list]
+        self.adjacent_range = list(adjacent_range)
+        self.batch_size = int(batch_size)
+        self.downsampling = float(downsampling)
+        self.rgb_mode = rgb_mode
+        self.shuffle = shuffle
+        self.device = torch.device(device)
+        self.rng = random.Random(seed)
+        if image_file_names is None:
+            image_file_names = []
+            for folder in self.folders:
+                image_file_names += [os.path.join(folder, n) for n in sorted(os.listdir(folder)) if n.startswith("0") and n.endswith(".jpg")]
+        self.image_file_names = [str(n) for n in image_file_names]
+        if not self.image_file_names:
+            raise ValueError("no frames found below %s" % self.folders)
+        self.num_iter = len(self.image_file_names) if num_iter is None else int(num_iter)
+        stored = read_precompute_file(precompute_path) if precompute_path is not None else None
+        self.sequences = {}
+        for folder in self.folders:
+            if stored is not None:
+                seq = {k: _by_folder_name(stored[k], folder) for k in ("crop_positions", "visible_view_indexes", "point_cloud", "intrinsic_matrix",
+                                                                       "mask_boundary", "view_indexes_per_point", "extrinsics", "projection",
+                                                                       "clean_point_list", "estimated_scale")}
+            else:
+                seq = reader.load_sequence(folder, self.downsampling, network_downsampling, visible_interval, suggested_h, suggested_w)
+                seq["clean_point_list"] = []
+            seq["scatter"] = scatter.SequenceScatter(
+                seq["point_cloud"], seq["mask_boundary"], seq["view_indexes_per_point"], seq["clean_point_list"], seq["visible_view_indexes"],
+                device=self.device, extrinsics=np.stack([np.asarray(m) for m in seq["extrinsics"]]),
+                projections=np.stack([np.asarray(m) for m in seq["projection"]]), intrinsic_matrix=seq["intrinsic_matrix"],
+                estimated_scale=seq["estimated_scale"])
+            self.sequences[folder] = seq
+        self.decoder = reader.FrameDecoder(device=self.device, slots=max(4, 2 * self.batch_size))
+
+    def __len__(self):
+        return (self.num_iter + self.batch_size - 1) // self.batch_size
+
+    def _draw(self, idx):
+        """One sample: (folder, pos, increment) -- dataset.py:338-350."""
+        name = self.image_file_names[idx % len(self.image_file_names)]
+        folder = os.path.dirname(name)
+        seq = self.sequences[folder]
+        pos, increment = utils.generating_pos_and_increment(idx, seq["visible_view_indexes"], self.adjacent_range)
+        return folder, pos, increment
+
+    def _assemble(self, samples):
+        """samples: list of (folder, pos, increment).  Returns (batch, per-sample validity)."""
+        order, parts = [], []
+        for folder in sorted(set(s[0] for s in samples)):
+            rows = [i for i, s in enumerate(samples) if s[0] == folder]
+            seq = self.sequences[folder]
+            positions = [(samples[i][1], samples[i][2]) for i in rows]
+            part = seq["scatter"].training_batch(positions)
+            sh, eh, sw, ew = [int(v) for v in seq["crop_positions"]]
+            views = seq["visible_view_indexes"]
+            c1 = torch.empty((len(rows), 3, eh - sh, ew - sw), dtype=torch.float32, device=self.device)
+            c2 = torch.empty_like(c1)
+            for k, (pos, inc) in enumerate(positions):
+                for dst, view in ((c1, views[pos]), (c2, views[pos + inc])):
+                    with open(os.path.join(folder, "%08d.jpg" % view), "rb") as f:
+                        self.decoder.decode(f.read(), sh, eh, sw, ew, self.downsampling, self.rgb_mode, out_f32=dst[k])
+            part["colors_1"], part["colors_2"] = c1, c2
+            order += rows
+            parts.append(part)
+        batch = {k: torch.cat([p[k] for p in parts], dim=0) for k in parts[0]}
+        if order != sorted(order):
+            inverse = torch.tensor(np.argsort(order), device=self.device)
+            batch = {k: v.index_select(0, inverse) for k, v in batch.items()}
+        valid = (batch["sparse_depth_masks_1"].sum(dim=(1, 2, 3)) != 0) & (batch["sparse_depth_masks_2"].sum(dim=(1, 2, 3)) != 0)
+        return batch, valid.tolist()
+
+    def __iter__(self):
+        indices = list(range(self.num_iter))
+        if self.shuffle:
+            self.rng.shuffle(indices)
+        for start in range(0, len(indices), self.batch_size):
+            samples = [self._draw(idx) for idx in indices[start:start + self.batch_size]]
+            batch, valid = self._assemble(samples)
+            attempts = 0
+            while not all(valid):          # dataset.py:372-376: a pair without sparse points is replaced by a random one
+                attempts += 1
+                if attempts > 20:
+                    raise RuntimeError("could not draw a pair with sparse points after 20 attempts")
+                samples = [s if ok else self._draw(self.rng.randint(0, len(self.image_file_names) - 1)) for s, ok in zip(samples, valid)]
+                batch, valid = self._assemble(samples)
+            yield batch
