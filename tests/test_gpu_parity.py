@@ -811,7 +811,7 @@ def test_fused_loss_head_matches_modules(shape):
     out_m = modular(batch)
     assert not out_f["skipped"] and not out_m["skipped"]
     assert abs(out_f["loss"] - out_m["loss"]) <= 1e-6 * abs(out_m["loss"])
-    assert_close(out_f["grad_norm"], out_m["grad_norm"], 1e-5, "gradient norm")
+    assert_close(out_f["grad_norm"], out_m["grad_norm"], 5e-5, "gradient norm")          # two backward passes (atomically summed statistics)
     assert_close(fused_model.flat_parameters(), module_model.flat_parameters(), 1e-6, "parameters after one iteration")
 
 
