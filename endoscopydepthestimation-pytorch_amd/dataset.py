@@ -50,16 +50,17 @@ class TrainingBatches(object):
 
     folder_list           sequence folders (``<root>/bag_x/_start_...``), as utils.get_parent_folder_names returns them
     adjacent_range        (min, max) frame gap of a pair (train.py --adjacent_range)
-    precompute_path       the reference's precompute pickle (optional): crop window, matrices, scale and -- the part this
-                          package does not recompute -- the contaminated-point filter of every sequence.  Without it the
-                          folders are read with reader.load_sequence and no point is filtered.
+    precompute_path       the reference's precompute pickle (optional): crop window, matrices, scale and contaminated-point lists
+                          of every sequence as the reference stored them.  Without it the folders are read with
+                          reader.load_sequence; inlier_percentage (0.99 in train.py) then runs the contaminated-point filter
+                          on each folder's frames, None skips it.
     image_file_names      the sample list (default: every ``0*.jpg`` of the folders, sorted, as utils.get_color_file_names)
     num_iter              samples per epoch (dataset.py:137, 333); default: len(image_file_names)
     """
 
     def __init__(self, folder_list, adjacent_range, batch_size, downsampling=4.0, network_downsampling=64, visible_interval=30,
                  precompute_path=None, image_file_names=None, num_iter=None, shuffle=True, rgb_mode="rgb", suggested_h=None,
-                 suggested_w=None, device="cuda", seed=None):
+                 suggested_w=None, device="cuda", seed=None, inlier_percentage=None):
         assert len(adjacent_range) == 2
         self.folders = [str(f) for f in folder_list]
         self.adjacent_range = list(adjacent_range)
@@ -85,8 +86,11 @@ class TrainingBatches(object):
                                                                        "mask_boundary", "view_indexes_per_point", "extrinsics", "projection",
                                                                        "clean_point_list", "estimated_scale")}
             else:
-                seq = reader.load_sequence(folder, self.downsampling, network_downsampling, visible_interval, suggested_h, suggested_w)
-                seq["clean_point_list"] = []
+                # inlier_percentage (train.py: 0.99) runs the contaminated-point filter on the folder's frames; None = no filter
+                seq = reader.load_sequence(folder, self.downsampling, network_downsampling, visible_interval, suggested_h, suggested_w,
+                                           inlier_percentage)
+                if seq["clean_point_list"] is None:
+                    seq["clean_point_list"] = []
             seq["scatter"] = scatter.SequenceScatter(
                 seq["point_cloud"], seq["mask_boundary"], seq["view_indexes_per_point"], seq["clean_point_list"], seq["visible_view_indexes"],
                 device=self.device, extrinsics=np.stack([np.asarray(m) for m in seq["extrinsics"]]),

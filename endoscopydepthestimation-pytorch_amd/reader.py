@@ -380,14 +380,96 @@ def get_test_color_img(img_file_name, start_h, end_h, start_w, end_w, downsampli
     return out.float()
 
 
+def get_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False, decoder=None):
+    """uint8 (views, H, W, 3) DEVICE tensor in cv2 order (B, G, R): the values of the reference's float32 array  [utils.py:288-300]"""
+    return get_pair_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv, "bgr", decoder)
+
+
+# ---------------------------------------------------------------------------------------------
+# contaminated-point filter (utils.py:303-404)
+# ---------------------------------------------------------------------------------------------
+def compute_sanity_threshold(sanity_array, inlier_percentage):
+    """Edges of the window around the histogram's peak bin that holds `inlier_percentage` of the samples  [utils.py:303-336]"""
+    edges = np.arange(1000) * np.max(sanity_array) / 1000.0
+    counts, edges = np.histogram(sanity_array, bins=edges, density=True)
+    share = counts * np.diff(edges)
+    peak = int(np.argmax(share))
+    covered, above, below = share[peak], 1, 1
+    while True:
+        if peak + above < len(share):
+            covered += share[peak + above]
+            above += 1
+            if covered >= inlier_percentage:
+                break
+        if peak - below >= 0:
+            covered += share[peak - below]
+            below += 1
+            if covered >= inlier_percentage:
+                break
+        if peak + above >= len(share) and peak - below < 0:
+            return np.min(edges), np.max(edges)
+    return edges[peak - below + 1], edges[peak + above]
+
+
+def point_brightness(imgs, point_cloud, view_indexes_per_point, mask_boundary, projection_matrices, extrinsic_matrices,
+                     d=7, sigma_color=25.0, sigma_space=25.0):
+    """Per frame and point: (valid (F, P) bool, camera depth (F, P) float64, filtered brightness (F, P) float32) as numpy arrays.
+    imgs: device uint8 (F, H, W, 3) in cv2 order (reader.get_color_imgs).  One kernel evaluates the bilateral filter only at the
+    pixels the points project to (endo_point_brightness)."""
+    lib = _lib.load()
+    if not (torch.is_tensor(imgs) and imgs.is_cuda and imgs.dtype == torch.uint8 and imgs.dim() == 4 and imgs.shape[3] == 3):
+        raise ValueError("imgs must be a device uint8 tensor (frames, H, W, 3)")
+    imgs = imgs.contiguous()
+    frames, height, width, _ = imgs.shape
+    dev = imgs.device
+    pts = torch.from_numpy(np.ascontiguousarray(np.asarray(point_cloud, dtype=np.float64).reshape(-1, 4))).to(dev)
+    n_points = int(pts.shape[0])
+    proj = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float64).reshape(3, 4) for m in projection_matrices]))).to(dev)
+    ext = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(m, dtype=np.float64).reshape(4, 4) for m in extrinsic_matrices]))).to(dev)
+    if proj.shape[0] != frames or ext.shape[0] != frames:
+        raise ValueError("one projection and one extrinsic matrix per frame")
+    vis = torch.from_numpy(np.ascontiguousarray(np.asarray(view_indexes_per_point, dtype=np.float32).reshape(n_points, frames))).to(dev)
+    mask = torch.from_numpy(np.ascontiguousarray(np.asarray(mask_boundary, dtype=np.uint8).reshape(height, width))).to(dev)
+    valid = torch.empty((frames, n_points), dtype=torch.int32, device=dev)
+    depth = torch.empty((frames, n_points), dtype=torch.float64, device=dev)
+    bright = torch.empty((frames, n_points), dtype=torch.float32, device=dev)
+    _lib.check(lib.endo_point_brightness(_lib.ptr(imgs), frames, height, width, _lib.ptr(pts), n_points, _lib.ptr(proj), _lib.ptr(ext),
+                                         _lib.ptr(vis), _lib.ptr(mask), int(d), float(sigma_color), float(sigma_space), _lib.ptr(valid),
+                                         _lib.ptr(depth), _lib.ptr(bright), _lib.stream()), "endo_point_brightness")
+    return valid.cpu().numpy() != 0, depth.cpu().numpy(), bright.cpu().numpy()
+
+
+def get_clean_point_list(imgs, point_cloud, view_indexes_per_point, mask_boundary, inlier_percentage, projection_matrices,
+                         extrinsic_matrices, is_hsv=False):
+    """float32 (points,) 1 = keep, 0 = contaminated: in at least half of the frames it appears in, the point's depth^2 x brightness
+    lies outside the window holding `inlier_percentage` of that frame's points  [utils.py:339-404].  imgs as reader.get_color_imgs."""
+    if is_hsv:
+        raise NotImplementedError("is_hsv=True is not part of the training configuration")
+    n_points = len(point_cloud)
+    if inlier_percentage <= 0.0 or inlier_percentage >= 1.0:
+        return list()
+    valid, depth, bright = point_brightness(imgs, point_cloud, view_indexes_per_point, mask_boundary, projection_matrices, extrinsic_matrices)
+    flagged = np.zeros(n_points, dtype=np.int32)
+    seen = np.zeros(n_points, dtype=np.int32)
+    for f in range(valid.shape[0]):
+        index = np.nonzero(valid[f])[0]
+        seen[index] += 1
+        if index.size < 2:
+            continue
+        sanity = depth[f, index] ** 2 * bright[f, index]
+        low, high = compute_sanity_threshold(sanity, inlier_percentage)
+        flagged[index[(sanity <= low) | (sanity >= high)]] += 1
+    return (flagged < seen / 2).astype(np.float32)
+
+
 # ---------------------------------------------------------------------------------------------
 # one sequence folder -> what dataset.pre_processing_data collects (dataset.py:41-112), minus the contaminated-point filter
 # ---------------------------------------------------------------------------------------------
-def load_sequence(folder, downsampling, network_downsampling, visible_interval, suggested_h=None, suggested_w=None):
+def load_sequence(folder, downsampling, network_downsampling, visible_interval, suggested_h=None, suggested_w=None, inlier_percentage=None):
     """Dictionary with the per-sequence entries of the reference's precompute file: crop_positions, selected_indexes,
     visible_view_indexes, point_cloud, intrinsic_matrix, mask_boundary, view_indexes_per_point, extrinsics, projection,
-    estimated_scale.  The contaminated-point filter (utils.get_clean_point_list) is not part of this row: pass the
-    precompute file's list, or all ones, to scatter.SequenceScatter."""
+    estimated_scale and -- with inlier_percentage (train.py --inlier_percentage, 0.99) -- clean_point_list: every visible frame
+    decoded on the device and the contaminated-point filter run on them (dataset.py:96-111).  This part needs the GPU."""
     folder = str(folder)
     mask, start_h, end_h, start_w, end_w = downsample_and_crop_mask(read_mask(os.path.join(folder, "undistorted_mask.bmp")),
                                                                     downsampling, network_downsampling, suggested_h, suggested_w)
@@ -397,6 +479,10 @@ def load_sequence(folder, downsampling, network_downsampling, visible_interval, 
     points = read_point_cloud(os.path.join(folder, "structure.ply"))
     views = overlapping_visible_view_indexes_per_point(read_view_indexes_per_point(folder, visible, len(points)), visible_interval)
     extrinsics, projections = get_extrinsic_matrix_and_projection_matrix(read_pose_data(folder), intrinsics, len(visible))
-    return {"crop_positions": [start_h, end_h, start_w, end_w], "selected_indexes": selected, "visible_view_indexes": visible,
+    clean = None
+    if inlier_percentage is not None:
+        frames = get_color_imgs(folder, visible, start_h, end_h, start_w, end_w, downsampling)
+        clean = get_clean_point_list(frames, points, views, mask, inlier_percentage, projections, extrinsics)
+    return {"clean_point_list": clean, "crop_positions": [start_h, end_h, start_w, end_w], "selected_indexes": selected, "visible_view_indexes": visible,
             "point_cloud": points, "intrinsic_matrix": intrinsics, "mask_boundary": mask, "view_indexes_per_point": views,
             "extrinsics": extrinsics, "projection": projections, "estimated_scale": global_scale_estimation(extrinsics, points)}

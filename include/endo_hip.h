@@ -304,6 +304,20 @@ int endo_jpeg_decode_crop(const uint8_t* data, int64_t size, double downsampling
                           int end_w, int rgb_order, uint8_t* out_hwc, float* out_chw, void* staging, void* workspace,
                           int64_t workspace_bytes, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Contaminated-point filter, the per-pixel half -- reference utils.py:339-404 (get_clean_point_list), dataset.py:96-111.
+ * imgs [frames][H][W][3] uint8 in cv2 order (B, G, R) as utils.get_color_imgs returns them (values, before the / 255);
+ * points [P][4] fp64; projections [frames][3][4], extrinsics [frames][4][4] fp64; visibility [P][frames] fp32
+ * (view_indexes_per_point); mask [H][W] uint8.  For frame f and point p (outputs [frames][P]): valid = visible > 0.5, projects
+ * to 0 <= u <= W-1, 0 <= v <= H-1 with camera depth > 0, and mask[round(v)][round(u)] == 255 (round half to even); depth = the
+ * camera depth; brightness = max(B, G, R) of cv2.bilateralFilter(img / 255, d, sigma_color, sigma_space) at that pixel (circular
+ * window of radius d / 2, BORDER_REFLECT_101, colour distance |db| + |dg| + |dr|), evaluated only there.
+ * ------------------------------------------------------------------------------------------- */
+int endo_point_brightness(const uint8_t* imgs, int frames, int height, int width, const double* points, int n_points,
+                          const double* projections, const double* extrinsics, const float* visibility, const uint8_t* mask,
+                          int d, double sigma_color, double sigma_space, int32_t* valid, double* depth, float* brightness,
+                          void* stream);
+
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f
  * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read

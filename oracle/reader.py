@@ -396,3 +396,104 @@ def get_pair_color_imgs(prefix_seq, pair_indexes, start_h, end_h, start_w, end_w
         small = resize_linear(rgb, downsampling_factor)[start_h:end_h, start_w:end_w, :]
         imgs.append(small if rgb_mode == "rgb" else small[..., ::-1])
     return np.asarray(imgs, dtype=np.uint8)
+
+
+# ---------------------------------------------------------------------------------------------
+# contaminated-point filter -- utils.py:303-404 (compute_sanity_threshold, get_clean_point_list), dataset.py:96-111
+# ---------------------------------------------------------------------------------------------
+def get_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False):
+    """utils.py:288-300: BGR float32 (views, H, W, 3) holding the uint8 values."""
+    assert not is_hsv
+    imgs = [resize_linear(decode_jpeg_pil(os.path.join(str(prefix_seq), "%08d.jpg" % i)), downsampling_factor)[start_h:end_h, start_w:end_w, ::-1]
+            for i in visible_view_indexes]
+    return np.array(imgs, dtype="float32")
+
+
+def bilateral_filter(img, d, sigma_color, sigma_space):
+    """cv2.bilateralFilter(src=float32 (H, W, 3), d, sigmaColor, sigmaSpace), BORDER_REFLECT_101 (imgproc/bilateral_filter):
+    circular window of radius d // 2, spatial weight exp(-r^2 / (2 sigma_space^2)), colour weight exp(-(|db| + |dg| + |dr|)^2 /
+    (2 sigma_color^2)) shared by the channels.  OpenCV evaluates the colour weight through a 4096-bin-per-channel table with linear
+    interpolation; the closed form differs from it by ~1e-7 relative."""
+    radius = d // 2
+    src = img.astype(np.float32)
+    padded = np.pad(src, ((radius, radius), (radius, radius), (0, 0)), mode="reflect")
+    h, w, _ = src.shape
+    num = np.zeros_like(src, dtype=np.float64)
+    den = np.zeros((h, w, 1), dtype=np.float64)
+    cc, sc = -0.5 / (sigma_color * sigma_color), -0.5 / (sigma_space * sigma_space)
+    for i in range(-radius, radius + 1):
+        for j in range(-radius, radius + 1):
+            r = np.sqrt(float(i * i + j * j))
+            if r > radius:
+                continue
+            nb = padded[radius + i:radius + i + h, radius + j:radius + j + w].astype(np.float64)
+            l1 = np.abs(nb - src).sum(axis=2, keepdims=True)
+            wgt = np.exp(r * r * sc) * np.exp(l1 * l1 * cc)
+            num += wgt * nb
+            den += wgt
+    return (num / den).astype(np.float32)
+
+
+def compute_sanity_threshold(sanity_array, inlier_percentage):
+    """utils.py:303-336: grow a window around the histogram's peak bin until it holds `inlier_percentage` of the samples."""
+    hist, edges = np.histogram(sanity_array, bins=np.arange(1000) * np.max(sanity_array) / 1000.0, density=True)
+    share = hist * np.diff(edges)
+    peak = int(np.argmax(share))
+    total = share[peak]
+    up, down = 1, 1
+    while True:
+        if peak + up < len(share):
+            total += share[peak + up]
+            up += 1
+            if total >= inlier_percentage:
+                return edges[peak - down + 1], edges[peak + up]
+        if peak - down >= 0:
+            total += share[peak - down]
+            down += 1
+            if total >= inlier_percentage:
+                return edges[peak - down + 1], edges[peak + up]
+        if peak + up >= len(share) and peak - down < 0:
+            return np.min(edges), np.max(edges)
+
+
+def point_brightness(img_bgr_u8values, d=7, sigma_color=25, sigma_space=25):
+    """V of cv2.COLOR_BGR2HSV_FULL (= max(B, G, R) for float images) of the bilateral-filtered frame / 255 (utils.py:352-356)."""
+    return bilateral_filter(np.asarray(img_bgr_u8values, dtype=np.float32) / 255.0, d, sigma_color, sigma_space).max(axis=2)
+
+
+def frame_point_terms(img, pts, view_column, mask, projection_matrix, extrinsic_matrix, brightness=None):
+    """One frame of utils.py:345-388: (indices of the points that are visible, project inside the image and the mask; their
+    camera depth; the filtered brightness at their pixel)."""
+    height, width = np.asarray(img).shape[:2]
+    value = (brightness if brightness is not None else point_brightness(img)).reshape(-1)
+    visible = np.where(np.asarray(view_column).reshape(-1) > 0.5)[0]
+    cam = np.einsum('ij,mj->mi', np.asarray(extrinsic_matrix), pts)
+    cam = cam / cam[:, 3].reshape((-1, 1))
+    px = np.einsum('ij,mj->mi', np.asarray(projection_matrix), pts)
+    px = px / px[:, 2].reshape((-1, 1))
+    vpx, vcam = px[visible].reshape((-1, 3)), cam[visible].reshape((-1, 4))
+    inside = np.where((vpx[:, 0] <= width - 1) & (vpx[:, 0] >= 0) & (vpx[:, 1] <= height - 1) & (vpx[:, 1] >= 0) & (vcam[:, 2] > 0))[0]
+    loc = (np.round(vpx[inside, 0]) + np.round(vpx[inside, 1]) * width).astype(np.int32).reshape(-1)
+    in_mask = np.where(np.asarray(mask).reshape(-1)[loc] == 255)[0]
+    return visible[inside[in_mask]], vcam[inside[in_mask], 2], value[loc[in_mask]]
+
+
+def get_clean_point_list(imgs, point_cloud, view_indexes_per_point, mask_boundary, inlier_percentage, projection_matrices,
+                         extrinsic_matrices, is_hsv=False, brightness=None):
+    """utils.py:339-404 for is_hsv False.  brightness: optional per-frame (H, W) planes replacing the filtered V channel."""
+    assert not is_hsv
+    pts = np.asarray(point_cloud).reshape((-1, 4))
+    if inlier_percentage <= 0.0 or inlier_percentage >= 1.0:
+        return list()
+    contaminated = np.zeros(pts.shape[0], dtype=np.int32)
+    appearances = np.zeros(pts.shape[0], dtype=np.int32)
+    for i in range(len(projection_matrices)):
+        index, depth, value = frame_point_terms(imgs[i], pts, view_indexes_per_point[:, i], mask_boundary, projection_matrices[i],
+                                                extrinsic_matrices[i], None if brightness is None else brightness[i])
+        sanity = depth ** 2 * value
+        appearances[index] += 1
+        if sanity.shape[0] < 2:
+            continue
+        lo, hi = compute_sanity_threshold(sanity, inlier_percentage)
+        contaminated[index[(sanity <= lo) | (sanity >= hi)]] += 1
+    return (contaminated < appearances / 2).astype(np.float32)

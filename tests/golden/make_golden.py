@@ -493,6 +493,28 @@ def reader_case(ref, path):
            "estimated_scale_here": np.array(float(scale)), "downsampling": np.array(float(data[10])),
            "network_downsampling": np.array(int(data[11])), "frames": np.array(frames)}
     out["color_imgs"] = oreader.get_pair_color_imgs(seq, frames, crop[0], crop[1], crop[2], crop[3], 4.0, False, "rgb")
+    # contaminated-point filter (utils.py:303-404): the oracle's restatement (bilateral filter, HSV value, thresholds) run on all
+    # 35 frames of the sequence must reproduce the list the reference stored; the reference's own compute_sanity_threshold (no
+    # cv2 inside) gives known answers for that function
+    all_imgs = oreader.get_color_imgs(seq, visible, crop[0], crop[1], crop[2], crop[3], 4.0)
+    clean = oreader.get_clean_point_list(all_imgs, data[3][key], data[6][key], data[5][key], float(data[12]), data[8][key], data[7][key])
+    assert np.array_equal(clean, np.asarray(data[9][key])), "the restated contaminated-point filter does not reproduce the reference's list"
+    out["clean_point_list"] = np.asarray(data[9][key], dtype=np.float32)
+    out["inlier_percentage"] = np.array(float(data[12]))
+    pts = np.asarray(data[3][key]).reshape(-1, 4)
+    for tag, view in (("a", visible.index(frames[0])), ("b", visible.index(frames[1]))):
+        idx, depth, value = oreader.frame_point_terms(all_imgs[view], pts, np.asarray(data[6][key])[:, view], data[5][key], data[8][key][view], data[7][key][view])
+        out["terms_%s_index" % tag], out["terms_%s_depth" % tag], out["terms_%s_brightness" % tag] = idx, depth, value
+        out["terms_%s_view" % tag] = np.array(view)
+    rng = np.random.default_rng(3)
+    sanity_in, sanity_out = [], []
+    for k in range(6):
+        arr = np.abs(rng.normal(1.0 + k, 0.3 + 0.2 * k, size=40 + 60 * k)) ** 2
+        sanity_in.append(arr)
+        sanity_out.append([float(v) for v in u.compute_sanity_threshold(arr, 0.99 if k % 2 == 0 else 0.9)])
+    out["sanity_lengths"] = np.array([len(a) for a in sanity_in])
+    out["sanity_values"] = np.concatenate(sanity_in)
+    out["sanity_thresholds"] = np.array(sanity_out)
     full = oreader.decode_jpeg_pil(os.path.join(seq, "%08d.jpg" % frames[0]))
     out["full_frame0_row_sums"] = full.astype(np.int64).sum(axis=(1, 2))          # a fingerprint of the library's full decode
     out["full_frame0_col_sums"] = full.astype(np.int64).sum(axis=(0, 2))
