@@ -199,12 +199,13 @@ def cpu_baseline(cfg):
             "ms_per_step": full["ms_per_step"], "batch": cfg["batch"], "batch1_by_threads": sweep}
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, config=1):
     """HBM bytes per step of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
     serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
-    bench.py command).  None when there is no such file."""
+    bench.py command; `*_pmc_traffic.json` for configs[1], `*_pmc_traffic_config<k>.json` otherwise).  None when there is no such file."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    suffix = "_pmc_traffic.json" if config == 1 else "_pmc_traffic_config%d.json" % config
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     for path in reversed(files):
         try:
             with open(path) as fh:
@@ -387,8 +388,8 @@ def main():
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
     traffic, traffic_src = (None, None)
-    if args.config == 1:
-        traffic, traffic_src = pmc_traffic(dom_name)      # bytes per step -> per launch with the launches counted here
+    if args.config in (1, 2):
+        traffic, traffic_src = pmc_traffic(dom_name, args.config)      # bytes per step -> per launch with the launches counted here
     if traffic is not None and cnt:
         traffic = traffic / (cnt / args.steps)
     warp_gbs = warp_bytes / warp_kernel_ms / 1e6 if warp_kernel_ms > 0 else 0.0
