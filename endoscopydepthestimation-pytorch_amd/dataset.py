@@ -14,7 +14,10 @@ A sample whose sparse depth masks come out empty is redrawn as in dataset.py:372
 
 import os
 import pickle
+import queue
 import random
+import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
@@ -56,11 +59,15 @@ class TrainingBatches(object):
                           on each folder's frames, None skips it.
     image_file_names      the sample list (default: every ``0*.jpg`` of the folders, sorted, as utils.get_color_file_names)
     num_iter              samples per epoch (dataset.py:137, 333); default: len(image_file_names)
+    reader_threads        host threads decoding frames (the Huffman stage of endo_jpeg_decode_crop releases the GIL; one FrameDecoder
+                          per thread): 2.2 ms per 1920x1080 frame and thread, so 4 threads put a batch of 8 pairs together in ~9 ms
+    prefetch              batches assembled ahead of the consumer by a producer thread on a side stream (the reference's DataLoader
+                          workers); 0 = assemble in the caller's thread, on its stream
     """
 
     def __init__(self, folder_list, adjacent_range, batch_size, downsampling=4.0, network_downsampling=64, visible_interval=30,
                  precompute_path=None, image_file_names=None, num_iter=None, shuffle=True, rgb_mode="rgb", suggested_h=None,
-                 suggested_w=None, device="cuda", seed=None, inlier_percentage=None):
+                 suggested_w=None, device="cuda", seed=None, inlier_percentage=None, reader_threads=4, prefetch=1):
         assert len(adjacent_range) == 2
         self.folders = [str(f) for f in folder_list]
         self.adjacent_range = list(adjacent_range)
@@ -97,7 +104,21 @@ class TrainingBatches(object):
                 projections=np.stack([np.asarray(m) for m in seq["projection"]]), intrinsic_matrix=seq["intrinsic_matrix"],
                 estimated_scale=seq["estimated_scale"])
             self.sequences[folder] = seq
-        self.decoder = reader.FrameDecoder(device=self.device, slots=max(4, 2 * self.batch_size))
+        self.reader_threads = max(1, int(reader_threads))
+        self.prefetch = max(0, int(prefetch))
+        self._pool = ThreadPoolExecutor(self.reader_threads) if self.reader_threads > 1 else None
+        self._local = threading.local()
+        self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+
+    def _decode_into(self, path, window, dst, stream):
+        """One frame into dst (3, H, W) on `stream`; runs on a reader thread with its own FrameDecoder."""
+        decoder = getattr(self._local, "decoder", None)
+        if decoder is None:
+            decoder = self._local.decoder = reader.FrameDecoder(device=self.device, slots=4)
+        with open(path, "rb") as f:
+            data = f.read()
+        with torch.cuda.device(self.device), torch.cuda.stream(stream):
+            decoder.decode(data, window[0], window[1], window[2], window[3], self.downsampling, self.rgb_mode, out_f32=dst)
 
     def __len__(self):
         return (self.num_iter + self.batch_size - 1) // self.batch_size
@@ -122,10 +143,17 @@ class TrainingBatches(object):
             views = seq["visible_view_indexes"]
             c1 = torch.empty((len(rows), 3, eh - sh, ew - sw), dtype=torch.float32, device=self.device)
             c2 = torch.empty_like(c1)
+            stream = torch.cuda.current_stream(self.device)
+            jobs = []
             for k, (pos, inc) in enumerate(positions):
                 for dst, view in ((c1, views[pos]), (c2, views[pos + inc])):
-                    with open(os.path.join(folder, "%08d.jpg" % view), "rb") as f:
-                        self.decoder.decode(f.read(), sh, eh, sw, ew, self.downsampling, self.rgb_mode, out_f32=dst[k])
+                    jobs.append((os.path.join(folder, "%08d.jpg" % view), (sh, eh, sw, ew), dst[k], stream))
+            if self._pool is None:
+                for job in jobs:
+                    self._decode_into(*job)
+            else:
+                for done in [self._pool.submit(self._decode_into, *job) for job in jobs]:
+                    done.result()
             part["colors_1"], part["colors_2"] = c1, c2
             order += rows
             parts.append(part)
@@ -137,6 +165,52 @@ class TrainingBatches(object):
         return batch, valid.tolist()
 
     def __iter__(self):
+        if not self.prefetch:
+            yield from self._batches()
+            return
+        # producer thread: assembles on the side stream, hands over (batch, event); the consumer's stream waits for the event and
+        # the tensors are marked as used by it, so the caching allocator does not hand their memory back to the side stream early
+        handover = queue.Queue(maxsize=self.prefetch)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                with torch.cuda.device(self.device), torch.cuda.stream(self._side):
+                    for batch in self._batches():
+                        ready = torch.cuda.Event()
+                        ready.record(self._side)
+                        while not stop.is_set():
+                            try:
+                                handover.put((batch, ready), timeout=0.1)
+                                break
+                            except queue.Full:
+                                continue
+                        if stop.is_set():
+                            return
+                handover.put(None)
+            except BaseException as exc:          # noqa: BLE001 -- re-raised in the consumer
+                handover.put(exc)
+
+        worker = threading.Thread(target=produce, daemon=True)
+        worker.start()
+        try:
+            while True:
+                item = handover.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                batch, ready = item
+                current = torch.cuda.current_stream(self.device)
+                current.wait_event(ready)
+                for value in batch.values():
+                    value.record_stream(current)
+                yield batch
+        finally:
+            stop.set()
+            worker.join(timeout=5.0)
+
+    def _batches(self):
         indices = list(range(self.num_iter))
         if self.shuffle:
             self.rng.shuffle(indices)
