@@ -52,7 +52,7 @@ static const char* const kFamilyNames[ENDO_PROF_FAMILIES] = {
 
 using namespace endo;
 
-extern "C" int endo_abi_version(void) { return 1; }
+extern "C" int endo_abi_version(void) { return ENDO_ABI_VERSION; }
 
 extern "C" const char* endo_error_string(int code) {
     if (code == 0) return "ok";

@@ -32,7 +32,10 @@ extern "C" {
 #define ENDO_E_BADARG (-1)
 #define ENDO_E_UNSUPPORTED (-2)
 
-/* library identification: returns ABI version (bumped on any signature change) */
+/* library identification: returns ENDO_ABI_VERSION (bumped whenever the set of entry points or a signature changes).
+ * 2: round 2 (adds the tiled warp entries, endo_relative_poses, endo_loss_head, endo_set_option, endo_net_tape_offset,
+ * endo_jpeg_*, endo_point_brightness); so far entry points have only been added. */
+#define ENDO_ABI_VERSION 2
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
 const char* endo_error_string(int code);
