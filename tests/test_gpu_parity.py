@@ -429,6 +429,39 @@ def test_network_backward_kernel_forms(shape, which):
     assert_grads_on_pattern(params, g64p, None, GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
 
 
+def test_network_backward_eval_mode():
+    """Backward through the network in eval mode (running statistics, no batch-statistic terms in the BN backward; what a caller
+    fine-tuning with frozen BN would run -- endo_net_bwd(training = 0)): all 210 gradients against the fp64 oracle on the pass's
+    own activation pattern, the bound of the training-mode test."""
+    n, h, w = 2, 64, 96
+    state, model = make_model(68)
+    rng = np.random.default_rng(19)
+    # running statistics that are not the initial (0, 1): take them from one training-mode pass of the oracle
+    warm = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    onet.forward(state, warm, training=True)
+    _, model = make_model(68)
+    with torch.no_grad():
+        for name, buf in model.named_buffers():
+            if name in state and buf.dtype.is_floating_point:
+                buf.copy_(state[name].to(buf.device))
+    model._flatten()          # gather the edited buffers into the flat BN table the library reads
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    cot = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    model.eval()
+    y = model(x.to(dev()))
+    (pattern,) = pattern_of(y, model, n, h, w)
+    (y * cot.to(dev())).sum().backward()
+    torch.cuda.synchronize()
+    st64 = state_as(state, torch.float64)
+    names = onet.trainable_names()
+    for nm in names:
+        st64[nm].requires_grad_(True)
+    y64 = onet.forward(st64, x.double(), training=False, pattern=pattern)
+    g64 = dict(zip(names, torch.autograd.grad((y64 * cot.double()).sum(), [st64[nm] for nm in names])))
+    assert_close(y, y64.detach(), 1e-5, "eval-mode depth")
+    assert_grads_on_pattern(dict(model.named_parameters()), g64, None, GRAD_TOL, "network backward, eval mode")
+
+
 BF16_FWD_TOL = 2e-2       # bf16-operand mode (ENDO_OPT_MFMA_BF16): depth against the fp64 oracle on the pass's own pattern, max error / max
 BF16_GRAD_TOL = 1e-1      # ... and every parameter gradient, max error / the tensor's max (operands carry 8 significant bits;
                           # measured: depth 6e-3 / 1e-2, gradient tensors median 9.5e-3 / 7e-3, worst 6.0e-2 / 7.2e-2 -- the
