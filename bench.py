@@ -190,31 +190,95 @@ def cpu_baseline(cfg):
         # a thread count whose warm-up alone takes 3x the best step so far is not going to win: one iteration is enough
         sweep.append(run(1, threads, 2, give_up_after=3.0 * sweep[0]["ms_per_step"] / 1e3))
     best = max(sweep, key=lambda r: r["value"])
-    full = run(cfg["batch"], best["threads"], 1 if best["ms_per_step"] * cfg["batch"] > 4000.0 else 2)
+    # median of >= 3 timed iterations after the warm-up (the 512x640 workload, ~4x the work per sample, gets 1 when a
+    # batch-1 step already takes > 4 s: the whole baseline leg stays within ~2 minutes)
+    full = run(cfg["batch"], best["threads"], 1 if best["ms_per_step"] > 4000.0 else 3)
     return {"value": full["value"], "unit": "frame-pairs/s", "cores": full["threads"], "kind": "port",
             "cpu_model": model, "physical_cores": physical, "logical_cpus": logical,
-            "sample": "%d full training iteration(s) of the CPU oracle at batch %d, %dx%d (the GPU workload's batch) after 1 warm-up, "
+            "sample": "median of %d full training iteration(s) of the CPU oracle at batch %d, %dx%d (the GPU workload's batch) after 1 warm-up, "
                       "%d torch threads = the faster of {32, all %d physical cores} at batch 1" % (
                           max(full["iterations"], 1), cfg["batch"], h, w, full["threads"], physical),
-            "ms_per_step": full["ms_per_step"], "batch": cfg["batch"], "batch1_by_threads": sweep}
+            "ms_per_step": full["ms_per_step"], "timed_iterations": full["iterations"], "batch": cfg["batch"], "batch1_by_threads": sweep}
+
+
+def count_dispatches(step_fn, batch, optimizer, keep_dot=None):
+    """Kernel dispatches of ONE training iteration: the iteration (forward, loss head, backward on both streams, clip + SGD; without
+    the host-side guard of train.py:317, which cannot be captured) is captured into a HIP graph and the nodes of its DOT dump are
+    counted by type.  Nothing is replayed.  Returns a dict, or {"error": ...} when this stack cannot capture / dump."""
+    import re
+    import tempfile
+    import torch
+
+    def one():
+        optimizer.zero_grad()
+        losses_t, x, tape, pred, grad_pred = step_fn._fused_iteration(batch)
+        step_fn._fused_backward(x, tape, grad_pred)
+        optimizer.step(grad_scale=1.0)
+
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        graph.enable_debug_mode()
+        with torch.cuda.graph(graph):
+            one()
+        torch.cuda.synchronize()
+        path = keep_dot or tempfile.mktemp(suffix=".dot")
+        graph.debug_dump(path)
+        with open(path) as fh:
+            text = fh.read()
+        if not keep_dot:
+            os.unlink(path)
+    except Exception as exc:          # noqa: BLE001 -- a diagnostic: the bench line simply says why it is missing
+        return {"error": repr(exc)[:200]}
+    counts = {"kernels": 0, "memsets": 0, "memcpys": 0, "other_nodes": 0}
+    for label in re.findall(r'label\s*=\s*"([^"]*)"', text):
+        up = label.upper()
+        if "MEMSET" in up:
+            counts["memsets"] += 1
+        elif "MEMCPY" in up or "MEMCOPY" in up:
+            counts["memcpys"] += 1
+        elif "EVENT" in up or "EMPTY" in up or "HOST" in up or "GRAPH" in up:
+            counts["other_nodes"] += 1
+        else:
+            counts["kernels"] += 1
+    counts["how"] = "nodes of one captured iteration (hipGraph DOT dump); no host guard inside the capture"
+    return counts
 
 
 def pmc_traffic(family, config=1):
     """HBM bytes per step of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
     serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
-    bench.py command; `*_pmc_traffic.json` for configs[1], `*_pmc_traffic_config<k>.json` otherwise).  None when there is no such file."""
+    bench.py command; `*_pmc_traffic.json` for configs[1], `*_pmc_traffic_config<k>.json` otherwise).  The file records the
+    sha256 of the kernel sources it was measured on (tools/source_id.py): when that is not the tree this process runs, the
+    traffic is reported as None with the reason instead of stale bytes.  Returns (bytes per step or None, source / reason)."""
     import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from source_id import csrc_sha256
     suffix = "_pmc_traffic.json" if config == 1 else "_pmc_traffic_config%d.json" % config
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
-    for path in reversed(files):
-        try:
-            with open(path) as fh:
-                entry = json.load(fh)["families"].get(family)
-        except (OSError, ValueError, KeyError):
-            continue
-        if entry:
-            return entry["traffic_bytes_per_step"], "profiles/" + os.path.basename(path)
-    return None, None
+    if not files:
+        return None, "no profiles/*%s" % suffix
+    path = files[-1]
+    name = "profiles/" + os.path.basename(path)
+    try:
+        with open(path) as fh:
+            doc = json.load(fh)
+    except (OSError, ValueError):
+        return None, "unreadable: " + name
+    measured_on = (doc.get("source") or {}).get("csrc_sha256")
+    running = csrc_sha256()
+    if measured_on != running:
+        return None, "stale: %s was measured on kernel sources %s, this tree is %s -- regenerate it with tools/final_profiles.sh" % (
+            name, (measured_on or "of an unrecorded revision")[:12], running[:12])
+    entry = doc.get("families", {}).get(family)
+    if not entry:
+        return None, "%s has no family %s" % (name, family)
+    return entry["traffic_bytes_per_step"], name
 
 
 def main():
@@ -225,6 +289,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-family time table to stderr")
+    ap.add_argument("--keep-graph-dot", default=None, help="development: keep the DOT dump the dispatch count is made from")
+    ap.add_argument("--kernel-option", action="append", default=[], metavar="ID=VALUE",
+                    help="development A/B: FCDenseNet57.set_kernel_option(ID, VALUE) (include/endo_hip.h ENDO_OPT_*); recorded in the line")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -254,12 +321,17 @@ def main():
     dev = torch.device("cuda", local)
     lib = pkg._lib.load()
     bf16 = bool(cfg.get("bf16_operands"))
-    lib.endo_set_option(4, 1 if bf16 else 0)                            # ENDO_OPT_MFMA_BF16 (include/endo_hip.h)
 
     torch.manual_seed(10085)                                            # reference train.py:80
     model = pkg.models.FCDenseNet57(n_classes=1)
     pkg.utils.kaiming_weight_zero_bias(model, mode="fan_in", activation_mode="relu", distribution="normal")
     model = model.to(dev).train()
+    model.set_kernel_option(4, 1 if bf16 else 0)                       # ENDO_OPT_MFMA_BF16 (include/endo_hip.h): this model only
+    for spec in args.kernel_option:
+        option_id, value = (int(v) for v in spec.split("="))
+        if option_id == 4:
+            raise SystemExit("the operand precision belongs to --config, not to --kernel-option")
+        model.set_kernel_option(option_id, value)
     optimizer = pkg.optim.FusedClipSGD(model, lr=1.0e-3, momentum=0.9, max_norm=10.0)
     scheduler = pkg.scheduler.CyclicLR(optimizer, base_lr=1.0e-4, max_lr=1.0e-3, step_size=2000)
     step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1)
@@ -282,7 +354,7 @@ def main():
         all_mask |= 1 << f
     it = 0
     serial_steps = max(args.warmup - 1, 0)
-    lib.endo_set_wgrad_overlap(0)
+    model.set_kernel_option(5, 0)                                      # ENDO_OPT_WGRAD_OVERLAP off: kernels one at a time
     lib.endo_prof_enable(all_mask if serial_steps > 0 else 0)
     for _ in range(serial_steps):
         scheduler.batch_step(batch_iteration=it)
@@ -291,7 +363,7 @@ def main():
     barrier()
     fam_warm = {f: prof_read(lib, f) for f in MFMA_FAMILIES} if serial_steps > 0 else None
     lib.endo_prof_enable(0)
-    lib.endo_set_wgrad_overlap(1)
+    model.set_kernel_option(5, 1)
     for _ in range(args.warmup - serial_steps):
         scheduler.batch_step(batch_iteration=it)
         step_fn(batch)
@@ -339,19 +411,30 @@ def main():
         d1.grad = d2.grad = None
         loss.backward()
 
-    for _ in range(3):
-        warp_both()
-    torch.cuda.synchronize()
-    tw = time.perf_counter()
+    def warp_both_fused():          # the same chain as ONE library call (endo_warp_consistency): what the metric is quoted on
+        with torch.no_grad():
+            return pkg.losses.warp_consistency(d1, d2, batch["boundaries"], batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"],
+                                               batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"],
+                                               dcl_weight=2.0)
+
     reps = 20
-    for _ in range(reps):
-        warp_both()
-    torch.cuda.synchronize()
-    warp_ms_per_pair = (time.perf_counter() - tw) / reps / batch_size * 1e3
+
+    def host_inclusive(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        tw = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - tw) / reps / batch_size * 1e3
+
+    warp_ms_per_pair_modules = host_inclusive(warp_both)
+    warp_ms_per_pair = host_inclusive(warp_both_fused)
     # kernel time of the same calls (HIP events on the launch stream around every geometry / loss entry point)
     lib.endo_prof_enable((1 << FAMILY_GEOMETRY) | (1 << FAMILY_LOSS))
     for _ in range(reps):
-        warp_both()
+        warp_both_fused()
     torch.cuda.synchronize()
     geo = prof_read(lib, FAMILY_GEOMETRY)
     los = prof_read(lib, FAMILY_LOSS)
@@ -375,6 +458,7 @@ def main():
         lib.endo_prof_enable(0)
         print(json.dumps({"family_breakdown_one_step": breakdown}), file=sys.stderr)
 
+    dispatches = count_dispatches(step_fn, batch, optimizer, args.keep_graph_dot) if (rank == 0 and step_fn.fused_head) else None
     if world > 1:
         torch.distributed.barrier()
     if rank != 0:
@@ -413,6 +497,8 @@ def main():
         "collective_backend": torch.distributed.get_backend() if world > 1 else None,
         "per_rank_pairs_per_s": per_rank,
         "skipped_steps": skipped,
+        "kernel_options_overridden": args.kernel_option or None,
+        "dispatches_per_step": dispatches,
         "conv_roofline_frac_whole_step": (pairs / elapsed) * pair_gflop / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world),
         "depth_warp_fwd_bwd_ms_per_pair": warp_ms_per_pair,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved,
@@ -423,7 +509,7 @@ def main():
                      "algorithmic_gbs": by / ms / 1e6 if ms > 0 else None,
                      "concurrent": True},
         "roofline_serial": None if fam_warm is None else {
-            "note": "stand-alone kernel durations: warm-up steps with the weight-gradient side stream off (endo_set_wgrad_overlap(0))",
+            "note": "stand-alone kernel durations: warm-up steps with the weight-gradient side stream off (ENDO_OPT_WGRAD_OVERLAP = 0)",
             "kernel": dom_name, "achieved": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9,
             "frac": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9 / FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / serial_steps for f in MFMA_FAMILIES},
@@ -433,6 +519,7 @@ def main():
             "achieved": warp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp_gbs / HBM_PEAK_GBS, "traffic": None,
             "algorithmic_bytes_per_pair": warp_bytes / batch_size, "kernel_ms_per_pair": warp_kernel_ms / batch_size,
             "host_inclusive_ms_per_pair": warp_ms_per_pair,
+            "host_inclusive_ms_per_pair_through_the_modules_and_autograd": warp_ms_per_pair_modules,
             "note": "latency/launch bound at this size: %.0f KB per launch" % (warp_bytes / max(geo[1] + los[1], 1) * reps / 1e3)},
     }
     if bf16:

@@ -38,12 +38,15 @@ SIGNATURES = {
     "endo_scale_inv_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "endo_loss_head_workspace_floats": (_L, [_I, _I, _I]),
     "endo_loss_head": (_I, [_P] * 16 + [_F, _F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
+    "endo_warp_consistency_workspace_floats": (_L, [_I, _I, _I]),
+    "endo_warp_consistency": (_I, [_P] * 8 + [_F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
+    "endo_warp_fallback_blocks": (_I, [_P, _P, _I]),
     "endo_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "endo_net_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
     "endo_net_create_grouped": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "endo_net_groups": (_I, [_P]),
-    "endo_set_wgrad_overlap": (_I, [_I]),
-    "endo_set_option": (_I, [_I, _I]),
+    "endo_net_set_option": (_I, [_P, _I, _I]),
+    "endo_net_get_option": (_I, [_P, _I]),
     "endo_net_group_stride": (_L, [_P]),
     "endo_net_destroy": (None, [_P]),
     "endo_net_param_floats": (_L, []),

@@ -19,7 +19,7 @@
 
 namespace endo {
 
-__device__ __attribute__((aligned(16))) float g_pad_consts[8] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
+static __device__ __attribute__((aligned(16))) float g_pad_consts[8] = {__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""),
                                                                   0.0f, 0.0f, 0.0f, 0.0f};   // [0..3] NaN pad, [4..7] zero pad
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -33,7 +33,11 @@ struct WinoDgradTable {
 };
 
 // U[group][xi][c][j] = (G g' G^T)[xi],  g'[a][b] = W[c][16 group + j][2 - a][2 - b]  (the flipped filter of the data gradient)
-__global__ void __launch_bounds__(256) dgrad_wino_weights_kernel(const WinoDgradTable t, const float* __restrict__ params, float* __restrict__ u) {
+// layout 0: [group][xi][c][j] (dgrad_wino8_kernel: dword B reads);  layout 1: [group][c][a][j][i], xi = 4 a + i (dgrad_wino3_kernel:
+// one 16-byte B read per transform row)
+// layout1_max_groups: layers whose block has at most this many base-channel groups get layout 1 (0: layout 0 everywhere)
+static __global__ void __launch_bounds__(256) dgrad_wino_weights_kernel(const WinoDgradTable t, const float* __restrict__ params, float* __restrict__ u,
+                                                                 int layout1_max_groups = 0) {
     const int total = t.start[t.layers];
     for (int item = blockIdx.x * blockDim.x + threadIdx.x; item < total; item += gridDim.x * blockDim.x) {
         int l = 0;
@@ -60,6 +64,13 @@ __global__ void __launch_bounds__(256) dgrad_wino_weights_kernel(const WinoDgrad
             h[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
             h[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
             h[3][b] = g[2][b];
+        }
+        if (t.groups[l] <= layout1_max_groups) {
+            float* dst = u + t.u_off[l] + static_cast<int64_t>(grp) * kWinoDgradSlice + (c * 64 + j) * 4;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                *reinterpret_cast<f32x4*>(dst + a * 64) = f32x4{h[a][0], 0.5f * (h[a][0] + h[a][1] + h[a][2]), 0.5f * (h[a][0] - h[a][1] + h[a][2]), h[a][2]};
+            continue;
         }
         float* dst = u + t.u_off[l] + static_cast<int64_t>(grp) * kWinoDgradSlice + c * 16 + j;
 #pragma unroll
@@ -88,7 +99,10 @@ struct DgradWino8Geom {
 };
 
 // p.w % 32 == 0, p.h % 8 == 0, p.count % 16 == 0 (whole tiles and groups); u[l]: the layer's transformed weights, group-major.
-template <int NL>
+// EXP: diagnostic bit mask for tools/wino_bench (0 in the library; timing only): 1 = no x / gradient loads, 2 = no stores, 4 = no BN-sum
+// atomics, 8 = weights DMA'd for the first step only, 16 = no per-step barrier / DMA wait (racy), 32 = no MFMAs, 64 = no input
+// transform, 128 = trivial epilogue (no output transform / mask / sums)
+template <int NL, int EXP = 0>
 __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockParams p0, const float* __restrict__ u0, const float* __restrict__ u1,
                                                              const float* __restrict__ u2, const float* __restrict__ u3) {
     using G = DgradWino8Geom<NL>;
@@ -179,15 +193,19 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
                         const int64_t o = static_cast<int64_t>(co) * p.cs + static_cast<int64_t>(py + r) * p.w + px + 4 * hh;
-                        xc[r][hh] = *reinterpret_cast<const f32x4*>(x_n + o);
-                        dc[r][hh] = co >= p.acc_from ? *reinterpret_cast<const f32x4*>(out_n + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        if constexpr ((EXP & 1) != 0) {
+                            xc[r][hh] = f32x4{0.1f * lane, 0.2f, -0.3f, 0.4f}; dc[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            xc[r][hh] = *reinterpret_cast<const f32x4*>(x_n + o);
+                            dc[r][hh] = co >= p.acc_from ? *reinterpret_cast<const f32x4*>(out_n + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                     }
             }
             mean = p.saved[l][grp_off + 2 * co]; rstd = p.saved[l][grp_off + 2 * co + 1];
             scale = p.gamma[l][co] * rstd;
             beta = p.beta[l][co];
         }
-        if (step + 1 < nsteps) issue_weights(step + 1, buf ^ 1);
+        if (step + 1 < nsteps && (!(EXP & 8) || step == 0)) issue_weights(step + 1, buf ^ 1);
         if (active) {
             // ---- 16 transform-domain GEMMs over the layer's 12 dY maps: M = this wave's row of 16 tiles, N = the half's 16 channels ----
             f32x4 acc[16];
@@ -211,9 +229,19 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const float c0 = tl[a][0], c1 = tl[a][1], c2 = th2[a][0], c3 = th2[a][1];
-                    const float v0 = c0 - c2, v1 = c1 + c2, v2 = c2 - c1, v3 = c1 - c3;
+                    float v0 = c0 - c2, v1 = c1 + c2, v2 = c2 - c1, v3 = c1 - c3;
+                    if constexpr ((EXP & 64) != 0) { v0 = lo[a][0]; v1 = lo[a][1]; v2 = hi[a][0]; v3 = hi[a][1]; }
                     const float b0 = b_base[(4 * a + 0) * 192], b1 = b_base[(4 * a + 1) * 192];
                     const float b2 = b_base[(4 * a + 2) * 192], b3 = b_base[(4 * a + 3) * 192];
+                    if constexpr ((EXP & 32) != 0) {
+                        if (quad == 0) {
+                            acc[4 * a + 0] = f32x4{v0 * b0, 0.f, 0.f, 0.f}; acc[4 * a + 1] = f32x4{v1 * b1, 0.f, 0.f, 0.f};
+                            acc[4 * a + 2] = f32x4{v2 * b2, 0.f, 0.f, 0.f}; acc[4 * a + 3] = f32x4{v3 * b3, 0.f, 0.f, 0.f};
+                        } else {
+                            acc[4 * a + 0][quad] += v0 * b0; acc[4 * a + 1][quad] += v1 * b1;
+                            acc[4 * a + 2][quad] += v2 * b2; acc[4 * a + 3][quad] += v3 * b3;
+                        }
+                    } else
                     if (quad == 0) {
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                         acc[4 * a + 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0, b0, zero, 0, 0, 0);
@@ -230,6 +258,16 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
             }
             // ---- output transform A^T M A (tiles 4 lk + e), then layer l's ReLU mask + BN backward, accumulated over the layers ----
             float s1 = 0.f, s2 = 0.f;
+            if constexpr ((EXP & 128) != 0) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            total[r][hh][k] += acc[4 * (2 * r + hh) + k][0] + acc[4 * (2 * r + hh) + k][1] + acc[4 * (2 * r + hh) + k][2] + acc[4 * (2 * r + hh) + k][3] + xc[r][hh][k] * scale;
+                s1 = total[0][0][0]; s2 = mean + beta;
+            } else
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float u0r[4], u1r[4];
@@ -262,6 +300,8 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
                         f32x4 o = dc[r][hh];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) o[k] += total[r][hh][k];
+                        if constexpr ((EXP & 2) != 0) asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));
+                        else
                         *reinterpret_cast<f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + static_cast<int64_t>(py + r) * p.w + px + 4 * hh) = o;
                         total[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
                     }
@@ -275,9 +315,11 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino8_kernel(const DgradBlockPar
                 red[(w4 * 16 + li) * 2 + 1] = s2;
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (active && th < 32) {
+        if (!(EXP & 16) || step + 1 >= nsteps) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if (!(EXP & 4) && active && th < 32) {
             const int j = th >> 1, which = th & 1;
             const int cj = gq * 16 + j;
             const float* red = s_red + (buf * 2 + half) * G::kRed;
@@ -293,18 +335,18 @@ inline bool dgrad_wino_ok(const DgradBlockParams& p) {
 }
 
 // u[l]: transformed weights of layer l of the block (group-major slices of kWinoDgradSlice floats)
-template <int NL>
+template <int NL, int EXP = 0>
 inline int launch_dgrad_wino8(DgradBlockParams p, const float* const (&u)[4], hipStream_t stream) {
     using G = DgradWino8Geom<NL>;
     p.tiles_x = p.w / G::kTileX;
     const int tiles_y = p.h / G::kTileY;
     static bool configured = false;
     if (!configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wino8_kernel<NL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wino8_kernel<NL, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
         configured = true;
     }
-    dgrad_wino8_kernel<NL><<<dim3(p.tiles_x * tiles_y, 1, p.n), G::kThreads, G::kBytes, stream>>>(p, u[0], u[1], u[2], u[3]);
+    dgrad_wino8_kernel<NL, EXP><<<dim3(p.tiles_x * tiles_y, 1, p.n), G::kThreads, G::kBytes, stream>>>(p, u[0], u[1], u[2], u[3]);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

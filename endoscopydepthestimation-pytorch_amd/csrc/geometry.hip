@@ -401,6 +401,10 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
 // Backward: the d2 gradient is accumulated in an LDS tile (ds_add_f32) and flushed with one global atomic per touched source
 // pixel instead of four per output pixel.
 // ------------------------------------------------------------------------------------------
+// blocks of the tiled kernels that took the gather path because their source box did not fit the staging buffers
+// (endo_warp_fallback_blocks: lets a test assert that a large-motion batch really exercised the fallback); [0] forward, [1] backward
+static __device__ unsigned long long g_warp_fallback[2] = {0ull, 0ull};
+
 template <int TY, int TX>
 struct WarpTile {
     static constexpr int kThreads = 256;
@@ -472,6 +476,7 @@ __global__ void __launch_bounds__(256) warp_fwd_tiled_kernel(const float* __rest
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;          // block-uniform; bw <= 0: no pixel of the block has a tap in range
+    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[0], 1ull);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -557,6 +562,7 @@ __global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __rest
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
+    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[1], 1ull);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -695,6 +701,18 @@ static int launch_warp_bwd_tiled(const float* gw, const float* d1, const float* 
     const int tiles_x = (w + TX - 1) / TX, tiles_y = (h + TY - 1) / TY;
     warp_bwd_tiled_kernel<TY, TX><<<dim3(tiles_x * tiles_y, n), 256, 0, stream>>>(gw, d1, d2, mask, t, R, K, gd1, gd2, h, w, tiles_x, eps);
     return static_cast<int>(hipGetLastError());
+}
+
+extern "C" int endo_warp_fallback_blocks(long long* forward, long long* backward, int reset) {
+    unsigned long long host[2] = {0ull, 0ull};
+    ENDO_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_warp_fallback), sizeof(host)));          // synchronises with the device: a test hook
+    if (forward) *forward = static_cast<long long>(host[0]);
+    if (backward) *backward = static_cast<long long>(host[1]);
+    if (reset) {
+        const unsigned long long zero[2] = {0ull, 0ull};
+        ENDO_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_warp_fallback), zero, sizeof(zero)));
+    }
+    return 0;
 }
 
 extern "C" int endo_depth_warp_fwd_tiled(const float* depth_1, const float* depth_2, const float* mask, const float* t, const float* R,

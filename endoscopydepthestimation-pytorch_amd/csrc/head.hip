@@ -42,9 +42,72 @@ __global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl
     }
 }
 
+// loss = c_dcl * (parts[0] + parts[1]) (train.py:311-314 with c_dcl = dcl_weight * 0.5); up[0] = d loss / d (each term)
+__global__ void consistency_combine_kernel(const float* __restrict__ parts, float c_dcl, float* __restrict__ loss, float* __restrict__ up) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        loss[0] = c_dcl * (parts[0] + parts[1]);
+        up[0] = c_dcl;
+    }
+}
+
 }  // namespace endo
 
 using namespace endo;
+
+// ---------------------------------------------------------------------------------------------
+// Depth warp both ways + depth-consistency loss, forward and backward, as ONE call (reference models.py:454-554 twice,
+// losses.py:112-146 twice, train.py:305-314, and their autograd backward): the second BASELINE metric ("depth-warp fwd+bwd ms
+// per pair") measures exactly this chain, and through the modules ~2/3 of it was Python / autograd time around 10 launches.
+// Same entry points as endo_loss_head composes, same arithmetic as the modules.
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t endo_warp_consistency_workspace_floats(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return -1;
+    const int64_t p = static_cast<int64_t>(n) * h * w;
+    return 12 * (p + 3) + 32 * n + 64;
+}
+
+extern "C" int endo_warp_consistency(const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                                     const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics,
+                                     float dcl_weight, float eps, float* loss, float* grad_depth_1, float* grad_depth_2,
+                                     float* workspace, int n, int h, int w, void* stream_) {
+    if (!depth_1 || !depth_2 || !boundaries || !t_1_wrt_2 || !r_1_wrt_2 || !t_2_wrt_1 || !r_2_wrt_1 || !intrinsics || !loss ||
+        !grad_depth_1 || !grad_depth_2 || !workspace || n <= 0 || h <= 0 || w <= 0)
+        return ENDO_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int64_t p = static_cast<int64_t>(n) * h * w;
+    float* ws = workspace;
+    auto take = [&](int64_t count) { float* q = ws; ws += (count + 3) / 4 * 4; return q; };
+    float* warped_21 = take(p);     float* warped_12 = take(p);
+    float* inter_1 = take(p);       float* inter_2 = take(p);
+    float* g_d1_dcl = take(p);      float* g_d2_dcl = take(p);
+    float* g_w21 = take(p);         float* g_w12 = take(p);
+    float* g_d1_w21 = take(p);      float* g_d2_w21 = take(p);            // warp 2->1: d1 = depth_1, d2 = depth_2
+    float* g_d2_w12 = take(p);      float* g_d1_w12 = take(p);            // warp 1->2: d1 = depth_2, d2 = depth_1
+    double* nd_stats_1 = reinterpret_cast<double*>(take(2 * 2 * 4 * n));
+    double* nd_stats_2 = nd_stats_1 + 4 * n;
+    float* parts = take(4);
+    float* up = take(4);
+    int rc;
+#define HEAD(call) do { rc = (call); if (rc) return rc; } while (0)
+    HEAD(endo_depth_warp_fwd(depth_1, depth_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, warped_21, inter_1, n, h, w, eps, stream_));
+    HEAD(endo_depth_warp_fwd(depth_2, depth_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, warped_12, inter_2, n, h, w, eps, stream_));
+    HEAD(endo_norm_dist_fwd(depth_1, warped_21, inter_1, intrinsics, parts + 0, nd_stats_1, n, h, w, 1.0e-5f, stream_));
+    HEAD(endo_norm_dist_fwd(depth_2, warped_12, inter_2, intrinsics, parts + 1, nd_stats_2, n, h, w, 1.0e-5f, stream_));
+    consistency_combine_kernel<<<1, 64, 0, stream>>>(parts, static_cast<float>(static_cast<double>(dcl_weight) * 0.5), loss, up);
+    ENDO_LAUNCH_CHECK();
+    HEAD(endo_norm_dist_bwd(up, depth_1, warped_21, inter_1, intrinsics, nd_stats_1, g_d1_dcl, g_w21, n, h, w, 1.0e-5f, stream_));
+    HEAD(endo_norm_dist_bwd(up, depth_2, warped_12, inter_2, intrinsics, nd_stats_2, g_d2_dcl, g_w12, n, h, w, 1.0e-5f, stream_));
+    HEAD(endo_depth_warp_bwd(g_w21, depth_1, depth_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_d1_w21, g_d2_w21, n, h, w, eps, stream_));
+    HEAD(endo_depth_warp_bwd(g_w12, depth_2, depth_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_d2_w12, g_d1_w12, n, h, w, eps, stream_));
+#undef HEAD
+    int blocks = static_cast<int>((p / 4 + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    head_add_kernel<<<blocks, 256, 0, stream>>>(grad_depth_1, g_d1_dcl, g_d1_w21, g_d1_w12, nullptr, p);
+    head_add_kernel<<<blocks, 256, 0, stream>>>(grad_depth_2, g_d2_dcl, g_d2_w21, g_d2_w12, nullptr, p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int64_t endo_loss_head_workspace_floats(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return -1;

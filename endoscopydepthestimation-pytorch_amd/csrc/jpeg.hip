@@ -49,7 +49,7 @@ struct Huffman {
         for (int l = 1; l <= 9; ++l) {
             for (int i = 0; i < bits[l]; ++i, ++idx, ++c) {
                 const int first = c << (9 - l);
-                for (int f = 0; f < (1 << (9 - l)); ++f) { look_len[first + f] = static_cast<uint8_t>(l); look_sym[first + f] = values[idx]; }
+                for (int f = 0; f < (1 << (9 - l)) && first + f < 512; ++f) { look_len[first + f] = static_cast<uint8_t>(l); look_sym[first + f] = values[idx]; }
             }
             c <<= 1;
         }
@@ -110,6 +110,14 @@ static int parse_jpeg(const uint8_t* d, int64_t n, JpegHeader& hd) {
                 for (int l = 1; l <= 16; ++l) { t.bits[l] = s[q + l]; count += t.bits[l]; }
                 q += 17;
                 if (count > 256 || q + count > body) return ENDO_E_BADARG;
+                {   // Kraft check: an over-subscribed length table would index the 9-bit lookup (and the canonical codes) out of range
+                    int code = 0;
+                    for (int l = 1; l <= 16; ++l) {
+                        code += t.bits[l];
+                        if (code > (1 << l)) return ENDO_E_BADARG;
+                        code <<= 1;
+                    }
+                }
                 std::memcpy(t.values, s + q, count);
                 q += count;
                 t.present = true;
@@ -201,11 +209,17 @@ struct BitReader {
         skip(nbits);
         return v;
     }
-    void reset_at_restart() {          // byte-align, drop the buffered bits, step over the RSTn marker
+    // Byte-align, drop the buffered bits (fill() never reads past a marker, so what is buffered is the interval's padding) and step
+    // over the RSTn marker -- whether or not fill() had already run into it: an interval whose last bits were consumed without
+    // another fill() leaves p AT the marker with marker_hit still clear.  FF fill bytes in front of the marker are legal (T.81 B.1.1.2).
+    // false: a restart is due and no RSTn follows (damaged stream).
+    bool reset_at_restart() {
         acc = 0;
         count = 0;
-        if (marker_hit && p + 1 < end && p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) p += 2;
         marker_hit = false;
+        while (p + 1 < end && p[0] == 0xFF && p[1] == 0xFF) ++p;
+        if (p + 1 < end && p[0] == 0xFF && p[1] >= 0xD0 && p[1] <= 0xD7) { p += 2; return true; }
+        return false;
     }
 };
 
@@ -233,7 +247,7 @@ static int entropy_decode(const JpegHeader& hd, int16_t* blocks) {
     for (int my = 0; my < hd.mcus_y; ++my) {
         for (int mx = 0; mx < hd.mcus_x; ++mx) {
             if (hd.restart && until_restart == 0) {
-                br.reset_at_restart();
+                if (!br.reset_at_restart()) return ENDO_E_BADARG;
                 pred[0] = pred[1] = pred[2] = 0;
                 until_restart = hd.restart;
             }

@@ -25,10 +25,13 @@
 #include "wgrad_subpix_kernels.h"
 #include "wino_fwd_kernels.h"
 #include "dgrad_wino_kernels.h"
+#include "dgrad_wino3_kernels.h"
 
 #include <cstdlib>
 
 namespace endo {
+
+int run_dgrad_wino3_nl4(const DgradBlockParams& p, const float* const* u, hipStream_t stream);          // dgrad_wino3.hip
 
 constexpr int kGrowth = 12;
 constexpr int kLayers = 4;
@@ -38,7 +41,6 @@ constexpr int kNew = kGrowth * kLayers;   // 48
 constexpr float kBnEps = 1.0e-5f;
 constexpr float kBnMomentum = 0.1f;
 constexpr int kSideStreamFromLevel = 0;      // weight gradients of levels >= this run on the side stream (in-job A/B: 0 -> -4.7 %, 1 -> -3 %, 2 -> -1.8 % step time)
-static int g_wgrad_overlap = 1;              // endo_set_wgrad_overlap: 0 = weight gradients in line on the caller's stream
 
 struct ConvP { int64_t w, b; int cout, cin, ks; int64_t u; int64_t ud; };      // u / ud: offsets of the layer's Winograd-domain forward / data-gradient weights (dense layers), floats
 struct BnP { int64_t g, b; int c; int64_t run; int64_t saved; };   // run: offset in bn_running; saved: offset (pairs) in saved/scratch
@@ -159,6 +161,9 @@ struct endo_net {
     // coarse levels is a string of launches too small to fill the chip.  Forked after every prep_dy, joined once at the end.
     hipStream_t wstream;
     hipEvent_t ev_fork, ev_join;
+    // kernel-form / precision options of THIS network (endo_net_set_option): two networks in one process never change each
+    // other's arithmetic, and a thread stepping one model is not affected by another thread configuring a second one
+    int opt[ENDO_OPT_COUNT];
 };
 
 namespace endo {
@@ -480,7 +485,7 @@ struct Ctx {
     // context of the weight-gradient side stream, ordered after everything issued so far on the main stream
     int fork_wgrad(Ctx& side, int level) const {
         side = *this;
-        if (!net->wstream || !g_wgrad_overlap || level < kSideStreamFromLevel) return 0;          // run in line
+        if (!net->wstream || !net->opt[ENDO_OPT_WGRAD_OVERLAP] || level < kSideStreamFromLevel) return 0;          // run in line
         ENDO_CHECK(hipEventRecord(net->ev_fork, stream));
         ENDO_CHECK(hipStreamWaitEvent(net->wstream, net->ev_fork, 0));
         side.stream = net->wstream;
@@ -541,37 +546,34 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
     return 2.0 * net->n * net->groups * net->lv[level].plane * cin * cout * ks * ks;
 }
 
-// Tuning options (endo_set_option; defaults from the environment at first use, for in-job A/B runs of one build):
-//   ENDO_OPT_WINO_FWD    / ENDO_WINO_FWD     dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd (2 LDS stages),
-//                                            3 / 4 = Winograd with 3 / 4 stages
-//   ENDO_OPT_WINO_DGRAD  / ENDO_WINO_DGRAD   fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd
-//   ENDO_OPT_DGRAD_VEC   / ENDO_DGRAD_VEC    new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
-//   ENDO_OPT_MFMA_BF16   / ENDO_MFMA_BF16    1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
-//   ENDO_OPT_WINO_MIN_TILES / ENDO_WINO_MIN_TILES   a Winograd kernel is used from this many tiles per launch on (default 1024: the
-//                                            levels whose launches fill the chip several times; tests set 1 to reach the kernels at small sizes)
-static int g_options[ENDO_OPT_COUNT];
-static bool g_options_init = false;
-static int option(int id) {
-    if (!g_options_init) {
-        auto env = [](const char* name, int dflt) { const char* e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-        g_options[ENDO_OPT_WINO_FWD] = env("ENDO_WINO_FWD", 1);
-        g_options[ENDO_OPT_WINO_DGRAD] = env("ENDO_WINO_DGRAD", 1);
-        g_options[ENDO_OPT_DGRAD_VEC] = env("ENDO_DGRAD_VEC", 1);
-        g_options[ENDO_OPT_WINO_MIN_TILES] = env("ENDO_WINO_MIN_TILES", 1024);
-        g_options[ENDO_OPT_MFMA_BF16] = env("ENDO_MFMA_BF16", 0);
-        g_options_init = true;
-    }
-    return g_options[id];
+// Tuning options, per network handle (endo_net_set_option; defaults set by endo_net_create*, no environment variables):
+//   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd (2 LDS stages), 3 / 4 = Winograd
+//                            with 3 / 4 stages
+//   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
+//                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h)
+//   ENDO_OPT_DGRAD_VEC       new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
+//   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
+//   ENDO_OPT_WINO_MIN_TILES  a Winograd kernel is used from this many tiles per launch on (default 1024: the levels whose launches fill
+//                            the chip several times; tests set 1 to reach the kernels at small sizes)
+//   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
+static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
+    opt[ENDO_OPT_WINO_FWD] = 1;
+    opt[ENDO_OPT_WINO_DGRAD] = 1;
+    opt[ENDO_OPT_DGRAD_VEC] = 1;
+    opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
+    opt[ENDO_OPT_MFMA_BF16] = 0;
+    opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
 }
-static int wino_fwd_mode() { return option(ENDO_OPT_WINO_FWD); }
-static bool wino_fwd_enabled() { return wino_fwd_mode() != 0; }
-static bool wino_dgrad_enabled() { return option(ENDO_OPT_WINO_DGRAD) != 0; }
-static bool dgrad_vec_enabled() { return option(ENDO_OPT_DGRAD_VEC) != 0; }
+static int wino_fwd_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_FWD]; }
+static bool wino_fwd_enabled(const Ctx& c) { return wino_fwd_mode(c) != 0; }
+static int wino_dgrad_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_DGRAD]; }
+static bool wino_dgrad_enabled(const Ctx& c) { return wino_dgrad_mode(c) != 0; }
+static bool dgrad_vec_enabled(const Ctx& c) { return c.net->opt[ENDO_OPT_DGRAD_VEC] != 0; }
 // bit 0: weight gradients, bit 1: forward, bit 2: data gradients of the dense layers (1 = all three)
-static int mfma_bf16_mask() { const int v = option(ENDO_OPT_MFMA_BF16); return v == 1 ? 7 : (v >> 1); }
-static bool mfma_bf16_wgrad() { return (mfma_bf16_mask() & 1) != 0; }
-static bool mfma_bf16_fwd() { return (mfma_bf16_mask() & 2) != 0; }
-static bool mfma_bf16_dgrad() { return (mfma_bf16_mask() & 4) != 0; }
+static int mfma_bf16_mask(const Ctx& c) { const int v = c.net->opt[ENDO_OPT_MFMA_BF16]; return v == 1 ? 7 : (v >> 1); }
+static bool mfma_bf16_wgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 1) != 0; }
+static bool mfma_bf16_fwd(const Ctx& c) { return (mfma_bf16_mask(c) & 2) != 0; }
+static bool mfma_bf16_dgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 4) != 0; }
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
@@ -587,14 +589,14 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
     // 32 x 16 pixel tiles while they fill the chip several times over, 32 x 8 below that.
-    if (wino_fwd_enabled() && cv.u >= 0 && !mfma_bf16_fwd()) {
+    if (wino_fwd_enabled(c) && cv.u >= 0 && !mfma_bf16_fwd(c)) {
         ConvParams pw = p;
         pw.wgt = c.tape + c.net->wino_off + cv.u;          // group 0's tape: weights are shared by the groups
         const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
         const long t8 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
         if (wino_fwd_ok(pw)) {
-            const int mode = wino_fwd_mode();          // in-job A/B: 1 = 2 LDS stages (default), 3 = 3 stages, 4 = 4 stages
-            const long min_tiles = option(ENDO_OPT_WINO_MIN_TILES);
+            const int mode = wino_fwd_mode(c);          // in-job A/B: 1 = 2 LDS stages (default), 3 = 3 stages, 4 = 4 stages
+            const long min_tiles = c.net->opt[ENDO_OPT_WINO_MIN_TILES];
             const bool big = t16 >= min_tiles, small = t8 >= (min_tiles * 3) / 4;
             if (mode == 4) {
                 if (big) return launch_wino_fwd<2, 4, 2, 4>(pw, c.stream);
@@ -638,7 +640,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;      // inside one group's tape
         p.out = partial; p.out_ns = static_cast<int64_t>(cv.cout) * lv.plane;
         p.bias = nullptr; p.out_sums = nullptr;
-        int rc = mfma_bf16_fwd() ? launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream)
+        int rc = mfma_bf16_fwd(c) ? launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream)
                              : launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
         if (rc) return rc;
         int bx = static_cast<int>((lv.plane + 255) / 256);
@@ -654,7 +656,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     const long tiles_wide = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
     // level 0 stays on 32x16: in the training step (A/B of two library builds inside one job) it is 5 % faster than 32x8,
     // although the isolated microbenchmark prefers 32x8 by 5 %
-    if (mfma_bf16_fwd()) {          // bf16 MFMA operands (ENDO_OPT_MFMA_BF16): the same tile shapes
+    if (mfma_bf16_fwd(c)) {          // bf16 MFMA operands (ENDO_OPT_MFMA_BF16): the same tile shapes
         if (tiles_big < 1024 && tiles_wide >= 1024) return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1, 1>(p, c.stream);
         if (tiles_big < 1024 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream);
         return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1, 1>(p, c.stream);
@@ -679,7 +681,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.out_sums = c.out_sums(next, oc0);
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
-    if (mfma_bf16_fwd()) return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 2, 1, 1>(p, c.stream);
+    if (mfma_bf16_fwd(c)) return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 2, 1, 1>(p, c.stream);
     return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower)
 }
 
@@ -763,8 +765,8 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
-    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, mfma_bf16_wgrad());
-    if (wgrad_taps_ok(p)) return mfma_bf16_wgrad() ? launch_wgrad_taps<12, IN_BNRELU, 1>(p, c.stream) : launch_wgrad_taps<12, IN_BNRELU>(p, c.stream);
+    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, mfma_bf16_wgrad(c));
+    if (wgrad_taps_ok(p)) return mfma_bf16_wgrad(c) ? launch_wgrad_taps<12, IN_BNRELU, 1>(p, c.stream) : launch_wgrad_taps<12, IN_BNRELU>(p, c.stream);
     return launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }
 
@@ -864,10 +866,10 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             {
                 ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * kGrowth * kGrowth * 9 * nl,
                                4.0 * c.nt() * lv.plane * (3.0 * kGrowth + kGrowth * nl));
-                if (mfma_bf16_dgrad() && dgrad_block_vec_ok(p))
+                if (mfma_bf16_dgrad(c) && dgrad_block_vec_ok(p))
                     rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4, 1>(p, c.stream)
                        : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4, 1>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4, 1>(p, c.stream);
-                else if (dgrad_block_vec_ok(p) && dgrad_vec_enabled())
+                else if (dgrad_block_vec_ok(p) && dgrad_vec_enabled(c))
                     rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4>(p, c.stream)
                        : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4>(p, c.stream);
                 else
@@ -897,13 +899,14 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                        4.0 * c.nt() * lv.plane * (3.0 * c0 + kGrowth * kLayers));
         int rc;
         const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
-        if (mfma_bf16_dgrad()) {
+        if (mfma_bf16_dgrad(c)) {
             rc = launch_dgrad_block8<4, 1>(p, c.stream);
-        } else if (wino_dgrad_enabled() && dgrad_wino_ok(p) && wtiles >= option(ENDO_OPT_WINO_MIN_TILES) && cv[0].ud >= 0) {
+        } else if (wino_dgrad_enabled(c) && dgrad_wino_ok(p) && wtiles >= c.net->opt[ENDO_OPT_WINO_MIN_TILES] && cv[0].ud >= 0) {
             // fine levels: Winograd F(2x2, 3x3), 48 instead of 108 MFMAs per 64 pixels and step (dgrad_wino_kernels.h)
             const float* ub = c.gradws + c.net->wd_off;
             const float* const u[4] = {ub + cv[0].ud, ub + cv[1].ud, ub + cv[2].ud, ub + cv[3].ud};
-            rc = launch_dgrad_wino8<4>(p, u, c.stream);
+            // mode 1: the phase-skewed kernel (its U layout; endo_net_bwd transforms the weights to match), 2: the round-2 kernel
+            rc = (wino_dgrad_mode(c) == 1 && dgrad_wino3_ok(p)) ? run_dgrad_wino3_nl4(p, u, c.stream) : launch_dgrad_wino8<4>(p, u, c.stream);
         } else {
             rc = launch_dgrad_block8<4>(p, c.stream);       // 512-thread blocks: +15 % over the 4-wave kernel (tools/conv_bench)
         }
@@ -943,7 +946,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         rc = c.fork_wgrad(cw, level);
         if (rc) return rc;
         ProfScope prof(kProfWgradOther, cw.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * cv.cin);
-        rc = wgrad1x1_dma_ok(p) ? (mfma_bf16_wgrad() ? launch_wgrad1x1_dma<1>(p, cw.stream) : launch_wgrad1x1_dma<0>(p, cw.stream))
+        rc = wgrad1x1_dma_ok(p) ? (mfma_bf16_wgrad(c) ? launch_wgrad1x1_dma<1>(p, cw.stream) : launch_wgrad1x1_dma<0>(p, cw.stream))
                                 : launch_wgrad1x1(p, cw.stream);
         if (rc) return rc;
     }
@@ -960,7 +963,7 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
-        rc = (nx.w % 4 == 0) ? (mfma_bf16_dgrad() ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4, 2, 1, 1>(p, c.stream)
+        rc = (nx.w % 4 == 0) ? (mfma_bf16_dgrad(c) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4, 2, 1, 1>(p, c.stream)
                                                   : launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream))
                              : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);
         if (rc) return rc;
@@ -1028,6 +1031,7 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     if (!net) return ENDO_E_BADARG;
     net->n = n; net->h = h; net->w = w; net->groups = groups;
     net->wstream = nullptr; net->ev_fork = nullptr; net->ev_join = nullptr;
+    default_options(net->opt);
     int64_t off = 0, sums = 0, pq = 0;
     for (int l = 0; l <= kLevels; ++l) {
         auto& lv = net->lv[l];
@@ -1072,17 +1076,16 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
 
 extern "C" int endo_net_create(endo_net** out, int n, int h, int w) { return endo_net_create_grouped(out, n, h, w, 1); }
 
-extern "C" int endo_set_wgrad_overlap(int enable) {
-    const int old = g_wgrad_overlap;
-    g_wgrad_overlap = enable ? 1 : 0;
+extern "C" int endo_net_set_option(endo_net* net, int option_id, int value) {
+    if (!net || option_id < 0 || option_id >= ENDO_OPT_COUNT) return ENDO_E_BADARG;
+    const int old = net->opt[option_id];
+    net->opt[option_id] = value;
     return old;
 }
 
-extern "C" int endo_set_option(int option_id, int value) {
-    if (option_id < 0 || option_id >= ENDO_OPT_COUNT) return -1;
-    const int old = option(option_id);
-    g_options[option_id] = value;
-    return old;
+extern "C" int endo_net_get_option(const endo_net* net, int option_id) {
+    if (!net || option_id < 0 || option_id >= ENDO_OPT_COUNT) return ENDO_E_BADARG;
+    return net->opt[option_id];
 }
 
 extern "C" void endo_net_destroy(endo_net* net) {
@@ -1133,7 +1136,7 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape + g * net->gs) + net->sums_off, 0, net->sums_bytes, c.stream));
-    if (wino_fwd_enabled() && !mfma_bf16_fwd()) {          // dense-layer weights in Winograd form, all 44 layers in one launch
+    if (wino_fwd_enabled(c) && !mfma_bf16_fwd(c)) {          // dense-layer weights in Winograd form, all 44 layers in one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * (tb.wino_floats + tb.wino_floats * 9 / 16));
         wino_fwd_weights_kernel<<<(tb.wino.start[tb.wino.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino, params, tape + net->wino_off);
         ENDO_LAUNCH_CHECK();
@@ -1201,10 +1204,11 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(gradws + g * net->gs + net->pq_off, 0,
                                   static_cast<size_t>(net->scratch_off + net->scratch_bytes - net->pq_off * 4), c.stream));
-    if (wino_dgrad_enabled() && !mfma_bf16_dgrad()) {          // data-gradient weights of the dense layers in Winograd form, one launch
+    if (wino_dgrad_enabled(c) && !mfma_bf16_dgrad(c)) {          // data-gradient weights of the dense layers in Winograd form, one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * 2.0 * tb.wino_dgrad_floats);
-        dgrad_wino_weights_kernel<<<(tb.wino_dgrad.start[tb.wino_dgrad.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino_dgrad, params,
-                                                                                                                 gradws + net->wd_off);
+        // mode 1: blocks the phase-skewed kernel takes (dgrad_wino3_ok: at most 12 base-channel groups) get its U layout
+        dgrad_wino_weights_kernel<<<(tb.wino_dgrad.start[tb.wino_dgrad.layers] + 255) / 256, 256, 0, c.stream>>>(
+            tb.wino_dgrad, params, gradws + net->wd_off, wino_dgrad_mode(c) == 1 ? DgradWino3Geom<4>::kMaxCount / 16 : 0);
         ENDO_LAUNCH_CHECK();
     }
     int rc;

@@ -109,6 +109,10 @@ class TrainingBatches(object):
         self._pool = ThreadPoolExecutor(self.reader_threads) if self.reader_threads > 1 else None
         self._local = threading.local()
         self._side = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        # the sequences' resident tensors (SequenceScatter) were produced by asynchronous kernels on this thread's stream; the
+        # producer thread reads them from the side stream
+        if torch.cuda.is_available():
+            torch.cuda.current_stream(self.device).synchronize()
 
     def _decode_into(self, path, window, dst, stream):
         """One frame into dst (3, H, W) on `stream`; runs on a reader thread with its own FrameDecoder."""
@@ -128,7 +132,7 @@ class TrainingBatches(object):
         name = self.image_file_names[idx % len(self.image_file_names)]
         folder = os.path.dirname(name)
         seq = self.sequences[folder]
-        pos, increment = utils.generating_pos_and_increment(idx, seq["visible_view_indexes"], self.adjacent_range)
+        pos, increment = utils.generating_pos_and_increment(idx, seq["visible_view_indexes"], self.adjacent_range, rng=self.rng)
         return folder, pos, increment
 
     def _assemble(self, samples):
@@ -173,23 +177,27 @@ class TrainingBatches(object):
         handover = queue.Queue(maxsize=self.prefetch)
         stop = threading.Event()
 
+        def hand_over(item):
+            """False when the consumer has left (the queue may be full and will never drain)."""
+            while not stop.is_set():
+                try:
+                    handover.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    continue
+            return False
+
         def produce():
             try:
                 with torch.cuda.device(self.device), torch.cuda.stream(self._side):
                     for batch in self._batches():
                         ready = torch.cuda.Event()
                         ready.record(self._side)
-                        while not stop.is_set():
-                            try:
-                                handover.put((batch, ready), timeout=0.1)
-                                break
-                            except queue.Full:
-                                continue
-                        if stop.is_set():
+                        if not hand_over((batch, ready)):
                             return
-                handover.put(None)
+                hand_over(None)
             except BaseException as exc:          # noqa: BLE001 -- re-raised in the consumer
-                handover.put(exc)
+                hand_over(exc)
 
         worker = threading.Thread(target=produce, daemon=True)
         worker.start()

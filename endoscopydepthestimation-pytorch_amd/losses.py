@@ -138,3 +138,39 @@ class ScaleInvariantLoss(nn.Module):
     def forward(self, x):
         predicted_depths, goal_depths, boundaries = x
         return _ScaleInvFn.apply(predicted_depths, goal_depths, boundaries, self.epsilon)
+
+
+_consistency_ws = {}
+
+
+def warp_consistency(depth_maps_1, depth_maps_2, img_masks, translations_1_wrt_2, rotations_1_wrt_2, translations_2_wrt_1,
+                     rotations_2_wrt_1, intrinsic_matrices, dcl_weight=1.0, epsilon=1.0e-8):
+    """Depth warping both ways + NormalizedDistanceLoss both ways, forward and backward, as one library call
+    (``endo_warp_consistency``; reference models.py:454-554 and losses.py:112-146 twice each, train.py:305-314, and the autograd
+    backward of that chain):
+
+        loss = dcl_weight * 0.5 * (NDL([d1, warp(d2 -> 1), ...]) + NDL([d2, warp(d1 -> 2), ...]))
+
+    Returns ``(loss, d loss / d depth_maps_1, d loss / d depth_maps_2)``.  The same kernels and arithmetic as
+    ``DepthWarpingLayer`` + ``NormalizedDistanceLoss`` under autograd (tests/test_gpu_parity.py::test_warp_consistency_call),
+    without the ~10 autograd nodes around them -- the chain BASELINE.json's second metric times."""
+    lib = _lib.load()
+    d1 = _lib.dev_f32(depth_maps_1, "depth maps 1")
+    d2 = _lib.dev_f32(depth_maps_2, "depth maps 2")
+    mask = _lib.dev_f32(img_masks, "image masks")
+    n, _, h, w = d1.shape
+    pose = lambda t, cols, what: _lib.dev_f32(t, what).reshape(n, cols)
+    t12, r12 = pose(translations_1_wrt_2, 3, "translations"), pose(rotations_1_wrt_2, 9, "rotations")
+    t21, r21 = pose(translations_2_wrt_1, 3, "translations"), pose(rotations_2_wrt_1, 9, "rotations")
+    k = pose(intrinsic_matrices, 9, "intrinsics")
+    need = int(lib.endo_warp_consistency_workspace_floats(n, h, w))
+    key = (d1.device, n, h, w)
+    ws = _consistency_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _consistency_ws[key] = torch.empty(need, dtype=torch.float32, device=d1.device)
+    loss = torch.empty((), dtype=torch.float32, device=d1.device)
+    g1, g2 = torch.empty_like(d1), torch.empty_like(d2)
+    _lib.check(lib.endo_warp_consistency(_lib.ptr(d1), _lib.ptr(d2), _lib.ptr(mask), _lib.ptr(t12), _lib.ptr(r12), _lib.ptr(t21),
+                                         _lib.ptr(r21), _lib.ptr(k), float(dcl_weight), float(epsilon), _lib.ptr(loss), _lib.ptr(g1),
+                                         _lib.ptr(g2), _lib.ptr(ws), n, h, w, _lib.stream()), "endo_warp_consistency")
+    return loss, g1, g2

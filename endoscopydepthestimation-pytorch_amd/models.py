@@ -250,8 +250,32 @@ class FCDenseNet(nn.Module):
                 raise RuntimeError("parameter packing mismatch between Python and libendo_hip.so")
             hnd = ctypes.c_void_p()
             _lib.check(lib.endo_net_create_grouped(ctypes.byref(hnd), n, h, w, groups), "endo_net_create_grouped(%d,%d,%d,%d)" % key)
+            for option_id, value in getattr(self, "_kernel_options", {}).items():
+                lib.endo_net_set_option(hnd, option_id, value)
             self._handles[key] = (hnd, int(lib.endo_net_tape_floats(hnd)), int(lib.endo_net_gradws_floats(hnd)))
         return self._handles[key]
+
+    # kernel-form / precision options (include/endo_hip.h ENDO_OPT_*) belong to THIS module object -- like everything else about a
+    # reference module (train.py:191): they apply to every native handle it owns, present and future, and to no other model
+    _OPTION_DEFAULTS = {0: 1, 1: 1, 2: 1, 3: 1024, 4: 0, 5: 1}
+
+    def set_kernel_option(self, option_id, value):
+        """Returns the previous value."""
+        option_id, value = int(option_id), int(value)
+        if option_id not in self._OPTION_DEFAULTS:
+            raise ValueError("unknown kernel option %d" % option_id)
+        options = self.__dict__.setdefault("_kernel_options", {})
+        old = options.get(option_id, self._OPTION_DEFAULTS[option_id])
+        options[option_id] = value
+        lib = _lib.load()
+        for hnd, _, _ in self._handles.values():
+            rc = lib.endo_net_set_option(hnd, option_id, value)
+            if rc < 0:
+                raise RuntimeError("endo_net_set_option(%d, %d) failed: %d" % (option_id, value, rc))
+        return old
+
+    def kernel_option(self, option_id):
+        return self.__dict__.get("_kernel_options", {}).get(int(option_id), self._OPTION_DEFAULTS[int(option_id)])
 
     def __del__(self):
         try:

@@ -32,12 +32,15 @@ def init_net(net, type="kaiming", mode="fan_in", activation_mode="relu", distrib
     return net
 
 
-def generating_pos_and_increment(idx, visible_view_indexes, adjacent_range):
+def generating_pos_and_increment(idx, visible_view_indexes, adjacent_range, rng=None):
     """reference utils.py:412-438 (called dataset.py:346-350): position of the first frame of a training pair inside the
     sequence's visible views and the signed gap to its partner, drawn from ``adjacent_range`` = (min gap, max gap) -- the
     "adjacent range 5-30" of BASELINE.json configs[4].  Host-side pair selection: it consumes Python's ``random`` exactly as the
-    reference does (same calls in the same order), so a seeded run picks the same pairs."""
+    reference does (same calls in the same order), so a seeded run picks the same pairs.  ``rng``: a ``random.Random`` to draw
+    from instead of the module-level generator (same calls; lets an iterator own its seed -- dataset.TrainingBatches)."""
     import random
+    if rng is not None:
+        random = rng
     visible_view_idx = idx % len(visible_view_indexes)
     low, high = adjacent_range[0], adjacent_range[1]
     count = len(visible_view_indexes)

@@ -34,8 +34,11 @@ extern "C" {
 
 /* library identification: returns ENDO_ABI_VERSION (bumped whenever the set of entry points or a signature changes).
  * 2: round 2 (adds the tiled warp entries, endo_relative_poses, endo_loss_head, endo_set_option, endo_net_tape_offset,
- * endo_jpeg_*, endo_point_brightness); so far entry points have only been added. */
-#define ENDO_ABI_VERSION 2
+ * endo_jpeg_*, endo_point_brightness).
+ * 3: round 3 -- kernel-form / precision options move from the process to the network handle: endo_net_set_option /
+ * endo_net_get_option REPLACE endo_set_option and endo_set_wgrad_overlap (removed; no environment defaults any more);
+ * adds endo_warp_consistency and endo_warp_fallback_blocks. */
+#define ENDO_ABI_VERSION 3
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
 const char* endo_error_string(int code);
@@ -90,6 +93,11 @@ int endo_depth_warp_bwd_tiled(const float* grad_warped, const float* depth_1, co
                               const float* mask, const float* t, const float* R, const float* K,
                               float* grad_d1, float* grad_d2,
                               int n, int h, int w, float eps, int tile_h, int tile_w, void* stream);
+/* Test hook: blocks of the tiled kernels since the last reset whose source box did not fit the LDS staging buffers and that took
+ * the gather path instead (large / divergent motion, e.g. the gap-scaled poses of BASELINE configs[4]); per process and device.
+ * Copies two counters from the device (synchronises); either pointer may be null. */
+int endo_warp_fallback_blocks(long long* forward, long long* backward, int reset);
+
 
 /* ---------------------------------------------------------------------------------------------
  * SparseMaskedL1Loss.forward -- reference losses.py:62-66
@@ -145,6 +153,19 @@ int endo_loss_head(const float* pred_1, const float* pred_2, const float* bounda
                    float* losses, float* grad_pred_1, float* grad_pred_2, float* workspace,
                    int n, int h, int w, void* stream);
 
+/* Depth warp both ways + depth-consistency loss, forward AND backward, in one call -- reference models.py:454-554 (DepthWarpingLayer,
+ * once per direction), losses.py:112-146 (NormalizedDistanceLoss, once per direction), train.py:305-314, and their backward:
+ *   loss[0] = dcl_weight * 0.5 * (NDL(depth_1, warp(depth_2 -> 1)) + NDL(depth_2, warp(depth_1 -> 2)))
+ *   grad_depth_k = d loss / d depth_k  (through the loss terms, the sampling grids and the sampled images)
+ * depth_k: the (scaled) depth maps N x 1 x H x W; poses and intrinsics as endo_loss_head.  This is the chain BASELINE.json's second
+ * metric times ("depth-warp fwd+bwd ms / pair").  workspace: endo_warp_consistency_workspace_floats(n, h, w) floats, 16-byte aligned. */
+int64_t endo_warp_consistency_workspace_floats(int n, int h, int w);
+int endo_warp_consistency(const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                          const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics,
+                          float dcl_weight, float eps, float* loss, float* grad_depth_1, float* grad_depth_2,
+                          float* workspace, int n, int h, int w, void* stream);
+
+
 /* ---------------------------------------------------------------------------------------------
  * train.py glue that is pure elementwise work between the modules
  *   endo_mask_mul: out[n,c,hw] = a[n,c,hw] * mask[n,0,hw]   (train.py:272-273, 293-298)
@@ -175,28 +196,34 @@ int endo_net_create(endo_net** out, int n, int h, int w);
  * endo_net_group_stride() floats (what endo_net_tape_floats / endo_net_gradws_floats return).  groups <= 4. */
 int endo_net_create_grouped(endo_net** out, int n, int h, int w, int groups);
 int endo_net_groups(const endo_net* net);
-/* endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient chain and joined
- * before it returns.  0 puts them back in line on the caller's stream (clean per-kernel timings);
- * returns the previous setting.  Process-wide. */
-int endo_set_wgrad_overlap(int enable);
-/* Kernel-selection options, process-wide like the above; defaults come from the environment variable of the same name (without
- * the OPT_) at first use, so one build can be A/B-timed inside one job.  Returns the previous value, -1 for an unknown option.
- * Every setting but ENDO_OPT_MFMA_BF16 computes the same function; tests use ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
+/* Kernel-form / precision options of ONE network handle (the reference's modules are independent objects, train.py:191,
+ * 206-211: two models in one process, or a second thread configuring its own model, never change this one's arithmetic).
+ * endo_net_create* sets the defaults below; nothing is read from the environment.  endo_net_set_option returns the previous
+ * value, ENDO_E_BADARG for a null handle or an unknown option; it takes effect with the next endo_net_fwd / endo_net_bwd on
+ * that handle (a forward and the backward that differentiates it must run under the same ENDO_OPT_MFMA_BF16 value).
+ * Every setting but ENDO_OPT_MFMA_BF16 computes the same function up to fp32 summation order; tests use
+ * ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
  *   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 direct convolution, 1 Winograd F(2x2,3x3) (default), 3 / 4 = with 3 / 4 LDS stages
- *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd (default)
+ *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd with phase-skewed workers (default),
+ *                            2 Winograd, the round-2 kernel
  *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 1 = 16-byte DMA of the gradient tiles (default), 0 = dword
  *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024)
  *   ENDO_OPT_MFMA_BF16       NOT the same function: 1 = the dense layers' convolution kernels round their MFMA operands to bf16
  *                            (v_mfma_f32_16x16x16_bf16; fp32 accumulation, fp32 tensors in memory) -- the mixed-precision mode of
  *                            BASELINE configs[2], with its own tolerance; default 0 = fp32 operands.
- *                            Development values 2 * mask (mask bit 0 weight gradients, 1 forward, 2 data gradients) select families */
+ *                            Development values 2 * mask (mask bit 0 weight gradients, 1 forward, 2 data gradients) select families
+ *   ENDO_OPT_WGRAD_OVERLAP   endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient
+ *                            chain and joined before it returns: 1 (default); 0 puts them back in line on the
+ *                            caller's stream (clean per-kernel timings) */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2
 #define ENDO_OPT_WINO_MIN_TILES 3
 #define ENDO_OPT_MFMA_BF16 4
-#define ENDO_OPT_COUNT 5
-int endo_set_option(int option_id, int value);
+#define ENDO_OPT_WGRAD_OVERLAP 5
+#define ENDO_OPT_COUNT 6
+int endo_net_set_option(endo_net* net, int option_id, int value);
+int endo_net_get_option(const endo_net* net, int option_id);
 int64_t endo_net_group_stride(const endo_net* net);
 void endo_net_destroy(endo_net* net);
 int64_t endo_net_param_floats(void);                 /* 1 374 865 */

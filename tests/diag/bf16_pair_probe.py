@@ -7,16 +7,15 @@ dev = torch.device("cuda:0")
 batch = {k: v.to(dev) for k, v in ea.synthetic.make_batch(8, 256, 320, seed=0).items()}
 res = {}
 for mode in (0, 1):
-    ea._lib.load().endo_set_option(4, mode)
     torch.manual_seed(10085)
     model = ea.FCDenseNet57(1)
+    model.set_kernel_option(4, mode)
     ea.utils.kaiming_weight_zero_bias(model, mode="fan_in", activation_mode="relu", distribution="normal")
     model = model.to(dev).train()
     step = ea.train_step.TrainingStep(model, ea.optim.FusedClipSGD(model, lr=1e-3), 256, 320, sfl_weight=20.0, dcl_weight=0.1)
     losses_t, x, tape, pred, grad_pred = step._fused_iteration(batch)
     torch.cuda.synchronize()
     res[mode] = (losses_t.tolist(), pred.clone(), grad_pred.clone())
-ea._lib.load().endo_set_option(4, 0)
 p0, p1 = res[0][1], res[1][1]
 print("losses fp32", res[0][0], "bf16", res[1][0])
 print("pred rel L2 diff %.3e  max|diff|/max %.3e  pred min %.3e mean %.3e max %.3e" % (

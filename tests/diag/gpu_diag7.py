@@ -10,8 +10,6 @@ dev = torch.device("cuda:0")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 n, h, w = (int(a) for a in args[:3]) if len(args) >= 3 else (2, 128, 160)
 lib = ea._lib.load()
-if "--serial" in sys.argv:
-    lib.endo_set_wgrad_overlap(0)
 state = onet.perturb_affine(onet.synthetic_state(52), 53)
 rng = np.random.default_rng(6)
 x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
@@ -26,6 +24,8 @@ G64 = [t.detach() for t in torch.autograd.grad((y * cot.double()).sum(), [trace[
 model = ea.FCDenseNet57(1)
 model.load_state_dict(state)
 model = model.to(dev).train()
+if "--serial" in sys.argv:
+    model.set_kernel_option(5, 0)          # ENDO_OPT_WGRAD_OVERLAP
 yh = model(x.to(dev))
 (yh * cot.to(dev)).sum().backward()
 torch.cuda.synchronize()

@@ -3,6 +3,7 @@ same seeded inputs, against the committed golden fixtures, and -- at BASELINE.js
 through size-independent properties.  Tolerance: BASELINE.json north_star = 1e-4 relative (fp32);
 each assert states the tolerance it uses.  Run with ``pytest -m gpu`` on an MI355X."""
 
+import ctypes
 import importlib
 
 import numpy as np
@@ -243,6 +244,9 @@ def test_geometry_golden(golden):
 # ---------------------------------------------------------------------------------------------
 # network
 # ---------------------------------------------------------------------------------------------
+MODEL_OPTIONS = {}          # kernel options (include/endo_hip.h ENDO_OPT_*) given to the models make_model builds: see kernel_options
+
+
 def make_model(seed, positive_depth=False):
     state = onet.perturb_affine(onet.synthetic_state(seed), seed + 1)
     if positive_depth:
@@ -250,6 +254,8 @@ def make_model(seed, positive_depth=False):
     model = ea.FCDenseNet57(n_classes=1)
     missing = model.load_state_dict(state)
     assert not missing.missing_keys and not missing.unexpected_keys
+    for option_id, value in MODEL_OPTIONS.items():
+        model.set_kernel_option(option_id, value)
     return state, model.to(dev())
 
 
@@ -380,27 +386,56 @@ def test_network_backward(shape):
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
 
 
-OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES, OPT_MFMA_BF16 = 0, 1, 2, 3, 4
+OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES, OPT_MFMA_BF16, OPT_WGRAD_OVERLAP = 0, 1, 2, 3, 4, 5
 
 
 class kernel_options(object):
-    """``with kernel_options({id: value}):`` -- endo_set_option for the duration of a block (include/endo_hip.h)."""
+    """``with kernel_options({id: value}):`` -- every model make_model builds inside the block gets these options through
+    FCDenseNet57.set_kernel_option (endo_net_set_option on each of its handles, include/endo_hip.h).  Options are per model:
+    nothing outside the block, and no model built elsewhere, is affected."""
 
     def __init__(self, values):
-        self.values, self.old = values, {}
+        self.values, self.old = values, None
 
     def __enter__(self):
-        lib = ea._lib.load()
-        for k, v in self.values.items():
-            self.old[k] = lib.endo_set_option(k, v)
-            assert self.old[k] != -1 or v == -1
+        self.old = dict(MODEL_OPTIONS)
+        MODEL_OPTIONS.update(self.values)
         return self
 
     def __exit__(self, *exc):
-        lib = ea._lib.load()
-        for k, v in self.old.items():
-            lib.endo_set_option(k, v)
+        MODEL_OPTIONS.clear()
+        MODEL_OPTIONS.update(self.old)
         return False
+
+
+def test_kernel_options_are_per_model():
+    """Two models in one process (reference train.py:191: modules are independent objects): switching one to the direct kernels,
+    or to bf16 MFMA operands, must not change what the other computes -- bit for bit -- and the switched one must change."""
+    n, h, w = 2, 64, 96
+    _, a = make_model(81)
+    _, b = make_model(81)
+    x = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (n, 3, h, w)).astype(np.float32)).to(dev())
+    a.train(); b.train()
+    with torch.no_grad():
+        ya0, yb0 = a(x).clone(), b(x).clone()
+    assert torch.equal(ya0, yb0)
+    assert b.set_kernel_option(OPT_MFMA_BF16, 1) == 0 and b.kernel_option(OPT_MFMA_BF16) == 1 and a.kernel_option(OPT_MFMA_BF16) == 0
+    with torch.no_grad():
+        yb1, ya1 = b(x).clone(), a(x).clone()
+    assert torch.equal(ya1, ya0), "model a changed when model b's option was set"
+    assert not torch.equal(yb1, yb0), "model b did not switch to bf16 operands"
+    # a handle created AFTER the option was set (another input size) inherits it; the other model's new handle does not
+    x2 = x[:1, :, :32, :64].contiguous()
+    with torch.no_grad():
+        ya2, yb2 = a(x2), b(x2)
+    assert not torch.equal(ya2, yb2)
+    b.set_kernel_option(OPT_MFMA_BF16, 0)
+    with torch.no_grad():
+        assert torch.equal(b(x2), ya2) and torch.equal(b(x), ya0)
+    lib = ea._lib.load()
+    assert lib.endo_net_set_option(None, OPT_MFMA_BF16, 1) == -1
+    hnd = a._handle(n, h, w)[0]
+    assert lib.endo_net_set_option(hnd, 99, 1) == -1 and lib.endo_net_get_option(hnd, OPT_WINO_MIN_TILES) == 1024
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160), (1, 64, 128)])
@@ -872,12 +907,11 @@ def test_wgrad_overlap_is_transparent(shape):
     between the streams (a weight gradient reading a buffer the chain is rewriting) would show up as an O(1) difference
     in some tensor."""
     n, h, w = shape
-    lib = ea._lib.load()
     results = []
-    try:
+    if True:
         for overlap in (1, 0):
-            lib.endo_set_wgrad_overlap(overlap)
             _, model = make_model(57, positive_depth=True)
+            model.set_kernel_option(OPT_WGRAD_OVERLAP, overlap)
             model.train()
             opt = ea.optim.FusedClipSGD(model, lr=1.0e-3)
             step = ea.train_step.TrainingStep(model, opt, h, w)
@@ -891,8 +925,6 @@ def test_wgrad_overlap_is_transparent(shape):
                 step(batch, lr=1.0e-3)
             torch.cuda.synchronize()
             results.append((grads, model.flat_parameters().clone()))
-    finally:
-        lib.endo_set_wgrad_overlap(1)
     (g_on, p_on), (g_off, p_off) = results
     assert torch.isfinite(g_on).all() and torch.isfinite(p_on).all()
     assert_close(g_on, g_off, 2e-5, "gradients, overlap on vs off")
@@ -1147,6 +1179,217 @@ def test_train_step_full_size_golden(golden):
             check(err <= 1e-4, "%s: %.3e > 1e-4" % (name + stat, err))
         check(int(sd[name + ".num_batches_tracked"]) == 2, name + ".num_batches_tracked")
     assert not problems, "\n".join(problems)
+
+
+def test_train_step_full_size_golden_fused_path(golden):
+    """The code path bench.py TIMES, at the size it times: ``TrainingStep.__call__`` -> ``_fused_iteration`` (mask, grouped pair
+    forward, ``endo_loss_head``) -> host guard -> ``_fused_backward`` -> all-reduce hook -> ``FusedClipSGD.step`` -- against the
+    reference-generated fixture tests/golden/train_step_8x256x320.npz (reference train.py:272-328 run by make_golden.py with the
+    reference's modules, torch.optim.SGD and clip_grad_norm_).  test_train_step_full_size_golden drives the same kernels through
+    ``step.losses()`` + autograd + a separate ``opt.step()``; here nothing but ``step(batch)`` is called, so workspace sizing, the
+    ``grad_pred`` hand-over and the zero-before-sync ordering of the fused path are what is checked: loss terms 1e-4, total
+    gradient norm as in the module-path test, parameters after the update (per-tensor norms 2e-5 / sums 2e-4 absolute: the
+    update has norm lr * 10 = 1e-2, so that is ~1e-3 of it), BN running statistics 1e-4, two statistic updates per BN layer --
+    and the gradients left in the flat buffer against a twin model stepped through the module path (same kernels, same inputs:
+    fp32 atomic-order noise only)."""
+    g = golden("train_step_8x256x320.npz")
+    n, h, w, seed = (int(g[k]) for k in ("n", "h", "w", "seed"))
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(seed), seed + 1), bias=float(g["final_bias_shift"]))
+    models, steps, opts = [], [], []
+    for _ in range(2):
+        model = ea.FCDenseNet57(1)
+        model.load_state_dict(state)
+        model = model.to(dev()).train()
+        opt = ea.optim.FusedClipSGD(model, lr=float(g["lr"]))
+        steps.append(ea.train_step.TrainingStep(model, opt, h, w, sfl_weight=float(g["sfl_weight"]), dcl_weight=float(g["dcl_weight"]),
+                                                pair_forward=True))
+        models.append(model); opts.append(opt)
+    assert steps[0].fused_head and steps[0].pair_forward
+    batch = to_dev(synthetic.make_batch(n, h, w, seed=seed + 10, sparse_points=500))
+    out = steps[0](batch)                                   # THE timed path
+    torch.cuda.synchronize()
+    assert not out["skipped"]
+    problems = []
+
+    def check(ok, msg):
+        if not ok:
+            problems.append(msg)
+
+    for key in ("loss", "dcl", "sfl"):
+        err = abs(float(out[key]) - float(g[key])) / abs(float(g[key]))
+        print("%-5s fused path %.8f  reference %.8f  rel %.2e" % (key, float(out[key]), float(g[key]), err))
+        check(err <= 1e-4, "%s: rel err %.3e > 1e-4" % (key, err))
+    e = abs(float(out["grad_norm"]) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
+    r = abs(float(g["grad_norm"]) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
+    print("total gradient norm: fused path %.6f reference %.6f fp64 %.6f" % (float(out["grad_norm"]), float(g["grad_norm"]), float(g["o64_grad_norm"])))
+    check(e <= max(4.0 * r, 1e-4), "total gradient norm: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (e, r))
+    model = models[0]
+    norms = np.array([float(p.detach().double().norm()) for p in model.parameters()])
+    sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
+    check(np.abs(norms - g["param_norms"]).max() <= 2e-5, "parameter norms after the step: %.3e" % np.abs(norms - g["param_norms"]).max())
+    check(np.abs(sums - g["param_sums"]).max() <= 2e-4, "parameter sums after the step: %.3e" % np.abs(sums - g["param_sums"]).max())
+    sd = model.state_dict()
+    for name in (str(s) for s in g["buffers"]):
+        for stat in (".running_mean", ".running_var"):
+            err = rel_err(sd[name + stat], torch.from_numpy(g["buf::" + name + stat]))
+            check(err <= 1e-4, "%s: %.3e > 1e-4" % (name + stat, err))
+        check(int(sd[name + ".num_batches_tracked"]) == 2, name + ".num_batches_tracked")
+    # the twin through the module path: same kernels on the same inputs
+    loss, _, _, _ = steps[1].losses(batch)
+    opts[1].zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    g_fused, g_modules = models[0].flat_gradients(), models[1].flat_gradients()
+    check(abs(float(loss) - float(out["loss"])) <= 1e-6 * abs(float(loss)), "fused head loss vs modules: %.9f / %.9f" % (float(out["loss"]), float(loss)))
+    worst = 0.0
+    for (nm, pf), (_, pm) in zip(models[0].named_parameters(), models[1].named_parameters()):
+        scale = max(float(pm.grad.abs().max()), 1e-30)
+        worst = max(worst, float((pf.grad - pm.grad).abs().max()) / scale)
+    print("gradients, fused path vs module path: worst tensor %.2e of its maximum; flat buffers %.2e" % (worst, rel_err(g_fused, g_modules)))
+    check(rel_err(g_fused, g_modules) <= 1e-4, "flat gradient buffers, fused vs module path: %.3e" % rel_err(g_fused, g_modules))
+    opts[1].step()
+    assert_close(models[0].flat_parameters(), models[1].flat_parameters(), 1e-6, "parameters after the step, fused vs module path")
+    assert not problems, "\n".join(problems)
+
+
+def test_gap_scaled_pose_regime():
+    """BASELINE.json configs[4] ("adjacent range 5-30"): per-sample frame gaps U{5..30}, poses scaled by gap / 10
+    (synthetic.make_batch(gap_scale=(5, 30)), reference dataset.py:384-404 with train.py --adjacent_range 5 30) at the benchmark
+    batch 8 x 256 x 320.  Up to 3x the motion of configs[1]: source boxes of the LDS-staged warp kernels outgrow their staging
+    buffers and blocks fall back to the gather path -- asserted through endo_warp_fallback_blocks, so the fallback is known to
+    have run.  (a) The geometry + loss chain on smooth depths, values and input gradients, against the fp64 oracle (bounds of
+    test_geometry_and_losses_512x640).  (b) One full TrainingStep iteration against oracle.train_step: loss terms 1e-4."""
+    n, h, w = 8, 256, 320
+    lib = ea._lib.load()
+    batch = synthetic.make_batch(n, h, w, seed=120, sparse_points=500, gap_scale=(5, 30))
+    p1 = synthetic.smooth_depth(n, h, w, seed=220)
+    p2 = synthetic.smooth_depth(n, h, w, seed=320)
+    c1 = p1.double().requires_grad_(True)
+    c2 = p2.double().requires_grad_(True)
+    l_ref, dcl_ref, sfl_ref, _ = ostep.losses_from_depths(c1, c2, {k: v.double() for k, v in batch.items()})
+    l_ref.backward()
+    dbatch = to_dev(batch)
+    b = dbatch["boundaries"]
+    g1 = p1.to(dev()).requires_grad_(True)
+    g2 = p2.to(dev()).requires_grad_(True)
+    fwd, bwd = ctypes.c_longlong(), ctypes.c_longlong()
+    assert lib.endo_warp_fallback_blocks(None, None, 1) == 0
+    scaling, flow_layer, warp_layer = ea.DepthScalingLayer(), ea.FlowfromDepthLayer(), ea.DepthWarpingLayer()
+    sfl_fn, dcl_fn = ea.SparseMaskedL1Loss(), ea.NormalizedDistanceLoss(h, w)
+    s1, _ = scaling([g1, dbatch["sparse_depths_1"], dbatch["sparse_depth_masks_1"]])
+    s2, _ = scaling([g2, dbatch["sparse_depths_2"], dbatch["sparse_depth_masks_2"]])
+    f1 = flow_layer([s1, b, dbatch["translations_1_wrt_2"], dbatch["rotations_1_wrt_2"], dbatch["intrinsics"]]) * b
+    f2 = flow_layer([s2, b, dbatch["translations_2_wrt_1"], dbatch["rotations_2_wrt_1"], dbatch["intrinsics"]]) * b
+    sfl = 20.0 * 0.5 * (sfl_fn([dbatch["sparse_flows_1"] * b, f1, dbatch["sparse_flow_masks_1"] * b]) +
+                        sfl_fn([dbatch["sparse_flows_2"] * b, f2, dbatch["sparse_flow_masks_2"] * b]))
+    w21, i1 = warp_layer([s1, s2, b, dbatch["translations_1_wrt_2"], dbatch["rotations_1_wrt_2"], dbatch["intrinsics"]])
+    w12, i2 = warp_layer([s2, s1, b, dbatch["translations_2_wrt_1"], dbatch["rotations_2_wrt_1"], dbatch["intrinsics"]])
+    dcl = 0.1 * 0.5 * (dcl_fn([s1, w21, i1, dbatch["intrinsics"]]) + dcl_fn([s2, w12, i2, dbatch["intrinsics"]]))
+    (dcl + sfl).backward()
+    assert lib.endo_warp_fallback_blocks(ctypes.byref(fwd), ctypes.byref(bwd), 1) == 0
+    print("gap-scaled poses: %d forward / %d backward blocks of the tiled warp kernels took the gather fallback (of %d per pass)" % (
+        fwd.value, bwd.value, 2 * n * ((h + 15) // 16) * ((w + 31) // 32)))
+    assert fwd.value > 0 and bwd.value > 0, "the large-motion batch did not exercise the gather fallback of the tiled warp kernels"
+    assert_close(sfl, sfl_ref, 1e-4, "sparse flow loss, gap-scaled poses")
+    assert_close(dcl, dcl_ref, 1e-4, "depth consistency loss, gap-scaled poses")
+    for got, want, what in ((g1.grad, c1.grad, "grad pred 1, gap-scaled poses"), (g2.grad, c2.grad, "grad pred 2, gap-scaled poses")):
+        err = (got.detach().double().cpu() - want).abs() / float(want.abs().max())          # see test_depth_warping_tiles_512x640
+        assert float((err > 1e-4).double().mean()) <= 1e-3, what
+        assert float(torch.quantile(err.reshape(-1)[::3], 0.99)) <= 1e-5, what
+    # (b) the whole iteration on the same batch
+    state, model = make_model(83, positive_depth=True)
+    model.train()
+    opt = ea.optim.FusedClipSGD(model, lr=1.0e-3)
+    step = ea.train_step.TrainingStep(model, opt, h, w, sfl_weight=20.0, dcl_weight=0.1)
+    out = step(dbatch, lr=1.0e-3)
+    torch.cuda.synchronize()
+    assert lib.endo_warp_fallback_blocks(ctypes.byref(fwd), ctypes.byref(bwd), 1) == 0
+    ref = ostep.train_iteration(state, {}, batch, 1.0e-3)
+    assert not out["skipped"] and not ref["skipped"]
+    print("gap-scaled iteration: loss %.7f / oracle %.7f, dcl %.7f / %.7f, sfl %.7f / %.7f, grad norm %.5f / %.5f; fallback blocks %d / %d" % (
+        out["loss"], float(ref["loss"]), float(out["dcl"]), float(ref["dcl"]), float(out["sfl"]), float(ref["sfl"]),
+        float(out["grad_norm"]), float(ref["grad_norm"]), fwd.value, bwd.value))
+    assert abs(out["loss"] - float(ref["loss"])) <= 1e-4 * abs(float(ref["loss"]))
+    assert_close(out["dcl"], ref["dcl"], 1e-4, "dcl, gap-scaled iteration")
+    assert_close(out["sfl"], ref["sfl"], 1e-4, "sfl, gap-scaled iteration")
+    assert_close(out["grad_norm"], ref["grad_norm"], 5e-3, "grad norm, gap-scaled iteration")
+
+
+def test_warp_consistency_call():
+    """endo_warp_consistency (losses.warp_consistency): depth warp both ways + NormalizedDistanceLoss both ways, forward and backward
+    in one call -- the chain of BASELINE.json's second metric -- against the modules under autograd (same kernels: 1e-6) and against
+    the fp64 oracle (reference models.py:454-554, losses.py:112-146)."""
+    for (n, h, w, seed) in ((2, 64, 96, 50), (8, 256, 320, 51), (2, 37, 53, 52)):
+        batch, p1, p2, _ = geometry_inputs(n, h, w, seed)
+        db = to_dev(batch)
+        g1 = p1.to(dev()).requires_grad_(True)
+        g2 = p2.to(dev()).requires_grad_(True)
+        warp, dcl = ea.DepthWarpingLayer(), ea.NormalizedDistanceLoss(h, w)
+        w21, i1 = warp([g1, g2, db["boundaries"], db["translations_1_wrt_2"], db["rotations_1_wrt_2"], db["intrinsics"]])
+        w12, i2 = warp([g2, g1, db["boundaries"], db["translations_2_wrt_1"], db["rotations_2_wrt_1"], db["intrinsics"]])
+        want = 0.7 * 0.5 * (dcl([g1, w21, i1, db["intrinsics"]]) + dcl([g2, w12, i2, db["intrinsics"]]))
+        want.backward()
+        loss, d1, d2 = ea.losses.warp_consistency(g1.detach(), g2.detach(), db["boundaries"], db["translations_1_wrt_2"],
+                                                  db["rotations_1_wrt_2"], db["translations_2_wrt_1"], db["rotations_2_wrt_1"],
+                                                  db["intrinsics"], dcl_weight=0.7)
+        assert_close(loss, want.detach(), 1e-6, "warp_consistency loss vs modules %s" % ((n, h, w),))
+        assert_close(d1, g1.grad, 1e-6, "warp_consistency grad 1 vs modules")
+        assert_close(d2, g2.grad, 1e-5, "warp_consistency grad 2 vs modules")          # atomics: order of the scatter-adds
+        if h * w <= 64 * 96:
+            c1, c2 = p1.double().requires_grad_(True), p2.double().requires_grad_(True)
+            b64 = {k: v.double() for k, v in batch.items()}
+            r21, j1 = ogeo.depth_warping(c1, c2, b64["boundaries"], b64["translations_1_wrt_2"], b64["rotations_1_wrt_2"], b64["intrinsics"], 1e-8)
+            r12, j2 = ogeo.depth_warping(c2, c1, b64["boundaries"], b64["translations_2_wrt_1"], b64["rotations_2_wrt_1"], b64["intrinsics"], 1e-8)
+            ref = 0.7 * 0.5 * (olos.normalized_distance(c1, r21, j1, b64["intrinsics"]) + olos.normalized_distance(c2, r12, j2, b64["intrinsics"]))
+            ref.backward()
+            assert_close(loss, ref.detach(), 1e-5, "warp_consistency loss vs fp64 oracle")
+            assert_close(d1, c1.grad, 1e-4, "warp_consistency grad 1 vs fp64 oracle")
+            assert_close(d2, c2.grad, 1e-4, "warp_consistency grad 2 vs fp64 oracle")
+    lib = ea._lib.load()
+    assert lib.endo_warp_consistency(*([None] * 8), 1.0, 1e-8, *([None] * 4), 1, 8, 8, None) == -1
+
+
+BF16_FULL_GRAD_TOL = 1e-1          # provisional: tightened to <= 2x the measured worst tensor below once a GPU run has printed it
+
+
+def test_bf16_operand_pair_at_benchmark_batch():
+    """The bf16-operand mode at the per-GPU workload bench.py --config 2 times: the grouped pair pass at 2 x 8 x 256 x 320 (16 samples
+    per launch: the n-split weight gradient's bf16 form, the fused bf16 data gradients and the 32x16 forward tiles only these grids
+    select), each frame's depth and the summed parameter gradients against the CPU oracle on the patterns the pass itself took
+    (fp32 oracle, as test_full_size_pair_backward_on_pattern: fp64 at this size costs minutes and 40 GB; its own ~1e-5 is far below
+    the mode's tolerance)."""
+    n, h, w = 8, 256, 320
+    with kernel_options({OPT_MFMA_BF16: 1}):
+        state, model = make_model(58)
+    rng = np.random.default_rng(14)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    model.train()
+    y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+    patterns = pattern_of(y1, model, n, h, w, groups=2)
+    ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+    torch.cuda.synchronize()
+    params = dict(model.named_parameters())
+    names = onet.trainable_names()
+    total = None
+    worst_depth = 0.0
+    for x, cot, pat, got in zip(xs, cots, patterns, (y1, y2)):
+        st = {k: v.clone() for k, v in state.items()}
+        for nm in names:
+            st[nm].requires_grad_(True)
+        y = onet.forward(st, x, training=True, pattern=pat)
+        worst_depth = max(worst_depth, rel_err(got, y.detach()))
+        assert_close(got, y.detach(), BF16_FWD_TOL, "bf16 operands at 8x256x320: depth of one frame vs the oracle on the same pattern")
+        grads = torch.autograd.grad((y * cot).sum(), [st[nm] for nm in names])
+        total = list(grads) if total is None else [a + b for a, b in zip(total, grads)]
+        del y, grads, st
+    report = assert_grads_on_pattern(params, dict(zip(names, (t.double() for t in total))), None, BF16_FULL_GRAD_TOL,
+                                     "bf16 operands, 2 x 8x256x320 pair backward")
+    errors = sorted(r[0] for r in report)
+    print("bf16 operands at the benchmark batch: depth err %.2e, gradient errors median %.2e, worst %.2e (%s)" % (
+        worst_depth, errors[len(errors) // 2], errors[-1], max(report)[2]))
+    assert errors[len(errors) // 2] <= 1.5e-2
+    assert errors[-1] > 1e-4, "the bf16 kernels did not run"
 
 
 def test_full_size_pair_backward_on_pattern():

@@ -14,12 +14,16 @@ of 16 B/lane streaming reads, which is what every kernel here issues (global_loa
 is doubled.  Calibration points inside these very runs: final_bwd_data_kernel writes 192 planes = 491 520 KiB and
 WRITE_SIZE says 491 520.0; final_fwd_kernel reads the same 192 planes and FETCH_SIZE says 245 778 (x2 = 491 556)."""
 import json
+import os
 import re
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_id import source_id          # noqa: E402 -- ties the file to the kernel sources it was measured on (bench.py checks it)
+
 FAMILIES = [
-    ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_wino8_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,")),
+    ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_wino8_kernel|dgrad_wino3_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,")),
     ("conv3x3_dense_fwd", re.compile(r"wino_fwd_kernel|conv_dma_kernel<3, \d+, 1, 1, 0,|finalize_partial_kernel")),
     ("wgrad_dense", re.compile(r"wgrad_nsplit_kernel|wgrad_nsplit_reduce_kernel|wgrad_taps_kernel<12, 1>|wgrad_mfma_kernel<3, 1, 1, 0>")),
 ]
@@ -57,7 +61,7 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     steps = int(sys.argv[4])
-    out = {"note": sys.argv[5] if len(sys.argv) > 5 else "", "steps": steps,
+    out = {"note": sys.argv[5] if len(sys.argv) > 5 else "", "steps": steps, "source": source_id(),
            "unit": "bytes (2*FETCH_SIZE + WRITE_SIZE, KiB -> B); families per step, kernels per dispatch",
            "families": {}, "kernels": {}}
     for name in sorted(set(fetch) | set(write)):

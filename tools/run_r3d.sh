@@ -1,0 +1,10 @@
+mkdir -p gpurun_out/r3d
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set -d /tmp/sq$i -o s -- $R/tools/bin/wino_bench_noslp 144 16 256 320 1 > $R/gpurun_out/r3d/run$i.txt 2> $R/gpurun_out/r3d/sq$i.err
+done
+python3 $R/tools/pmc_sq_report.py $R/gpurun_out/r3d/sq_counters.txt /tmp/sq1/s_results.db /tmp/sq2/s_results.db /tmp/sq3/s_results.db > $R/gpurun_out/r3d/sq.log 2>&1
+cat $R/gpurun_out/r3d/sq_counters.txt | cut -c1-400

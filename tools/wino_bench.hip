@@ -1,0 +1,147 @@
+// Winograd data-gradient microbenchmark (development tool, not part of the product): times dgrad_wino8_kernel and its
+// diagnostic / candidate variants on one dense block's base-channel pass and cross-checks their outputs.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fno-slp-vectorize tools/wino_bench.hip -o tools/bin/wino_bench
+//   tools/bin/wino_bench [c0] [n] [h] [w]     (c0 = base channels of the block: 48 / 144 at level 0, 96 / 192 at level 1)
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <functional>
+
+#include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_wino_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_wino3_kernels.h"
+
+using namespace endo;
+
+endo::ProfScope::ProfScope(int f, hipStream_t s, double, double) : family(f), stream(s), slot(nullptr) {}
+endo::ProfScope::~ProfScope() {}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+static float* dev_random(size_t n, float lo, float hi, unsigned seed) {
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) { s = s * 1664525u + 1013904223u; h[i] = lo + (hi - lo) * ((s >> 8) & 0xFFFF) / 65535.0f; }
+    float* d; CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+struct Variant { std::string name; std::function<int(hipStream_t)> run; };
+
+static void bench(std::vector<Variant>& vs, float* out, size_t out_n, double* scratch, size_t scratch_n, double flops) {
+    std::vector<float> ref, cur(out_n);
+    std::vector<double> sref, scur(scratch_n);
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (auto& v : vs) {
+        CK(hipMemset(out, 0, out_n * sizeof(float)));
+        CK(hipMemset(scratch, 0, scratch_n * sizeof(double)));
+        int rc = v.run(0);
+        if (rc) { printf("%-52s launch failed rc=%d\n", v.name.c_str(), rc); continue; }
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { printf("%-52s FAILED: %s\n", v.name.c_str(), hipGetErrorString(e)); exit(1); }
+        CK(hipMemcpy(cur.data(), out, out_n * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(scur.data(), scratch, scratch_n * sizeof(double), hipMemcpyDeviceToHost));
+        double maxdiff = 0, maxref = 0, sdiff = 0, smax = 0;
+        if (ref.empty()) { ref = cur; sref = scur; }
+        for (size_t i = 0; i < out_n; ++i) { maxdiff = fmax(maxdiff, fabs((double)cur[i] - ref[i])); maxref = fmax(maxref, fabs((double)ref[i])); }
+        for (size_t i = 0; i < scratch_n; ++i) { sdiff = fmax(sdiff, fabs(scur[i] - sref[i])); smax = fmax(smax, fabs(sref[i])); }
+        for (int i = 0; i < 3; ++i) v.run(0);
+        CK(hipDeviceSynchronize());
+        const int reps = 10;
+        float best = 1e30f, tot = 0.f;
+        for (int rr = 0; rr < 3; ++rr) {
+            CK(hipEventRecord(a, 0));
+            for (int i = 0; i < reps; ++i) v.run(0);
+            CK(hipEventRecord(b, 0));
+            CK(hipEventSynchronize(b));
+            float ms; CK(hipEventElapsedTime(&ms, a, b));
+            best = fminf(best, ms / reps); tot += ms / reps;
+        }
+        printf("%-52s %8.1f us (best %8.1f)  %6.1f TFLOP/s   out diff %.2e / %.2e   sums diff %.2e / %.2e\n", v.name.c_str(), tot / 3 * 1e3, best * 1e3,
+               flops / (tot / 3 * 1e-3) / 1e12, maxdiff, maxref, sdiff, smax);
+        fflush(stdout);
+    }
+}
+
+int main(int argc, char** argv) {
+    const int c0 = argc > 1 ? atoi(argv[1]) : 144;
+    const int n = argc > 2 ? atoi(argv[2]) : 16;
+    const int h = argc > 3 ? atoi(argv[3]) : 256;
+    const int w = argc > 4 ? atoi(argv[4]) : 320;
+    const int mode = argc > 5 ? atoi(argv[5]) : 0;          // 0 = everything, 1 = product candidates only
+    const int64_t plane = (int64_t)h * w;
+    const int cin_last = c0 + 36;
+    printf("dense block base pass: N=%d %dx%d C0=%d, 4 layers x 12 dY maps\n", n, h, w, c0);
+    float* xbuf = dev_random((size_t)n * c0 * plane, -1.f, 1.f, 1);
+    float* gbuf = dev_random((size_t)n * 48 * plane, -1.f, 1.f, 2);
+    float* obuf; CK(hipMalloc(&obuf, (size_t)n * c0 * plane * sizeof(float)));
+    float* gamma = dev_random(cin_last, 0.8f, 1.2f, 5);
+    float* beta = dev_random(cin_last, -0.1f, 0.1f, 6);
+    float* saved; CK(hipMalloc(&saved, 2 * cin_last * sizeof(float)));
+    std::vector<float> hs(2 * cin_last); for (int c = 0; c < cin_last; ++c) { hs[2 * c] = 0.01f * (c % 7); hs[2 * c + 1] = 1.7f; }
+    CK(hipMemcpy(saved, hs.data(), hs.size() * sizeof(float), hipMemcpyHostToDevice));
+    const size_t scratch_n = (size_t)4 * 2 * cin_last * kBnSlots;
+    double* scratch; CK(hipMalloc(&scratch, scratch_n * sizeof(double)));
+    // four layers' weights W[12][cin_l][3][3], cin_l = c0 + 12 l
+    size_t woff[4], wtot = 0;
+    for (int l = 0; l < 4; ++l) { woff[l] = wtot; wtot += (size_t)12 * (c0 + 12 * l) * 9; }
+    float* wgt = dev_random(wtot, -0.05f, 0.05f, 3);
+
+    WinoDgradTable tb{};
+    tb.layers = 4;
+    int64_t uoff = 0; int start = 0;
+    for (int l = 0; l < 4; ++l) {
+        tb.start[l] = start; tb.cin[l] = c0 + 12 * l; tb.groups[l] = c0 / 16; tb.w_off[l] = woff[l]; tb.u_off[l] = uoff;
+        start += 16 * tb.groups[l] * 12; uoff += (int64_t)tb.groups[l] * kWinoDgradSlice;
+    }
+    tb.start[4] = start;
+    float* ubuf; CK(hipMalloc(&ubuf, uoff * sizeof(float)));
+    float* ubuf1; CK(hipMalloc(&ubuf1, uoff * sizeof(float)));
+    dgrad_wino_weights_kernel<<<(start + 255) / 256, 256>>>(tb, wgt, ubuf, 0);
+    dgrad_wino_weights_kernel<<<(start + 255) / 256, 256>>>(tb, wgt, ubuf1, 1 << 20);
+    CK(hipDeviceSynchronize());
+
+    DgradBlockParams p{};
+    p.n = n; p.h = h; p.w = w;
+    p.g = gbuf; p.g_ns = 48 * plane; p.g_cs = (int)plane; p.g_w = w;
+    p.x = xbuf; p.out = obuf; p.ns = c0 * plane; p.cs = (int)plane; p.count = c0; p.acc_from = 1 << 30; p.w_ci_off = 0;
+    for (int j = 0; j < 4; ++j) {
+        p.wgt[j] = wgt + woff[j]; p.w_cin[j] = c0 + 12 * j; p.saved[j] = saved; p.gamma[j] = gamma; p.beta[j] = beta;
+        p.scratch[j] = scratch + (size_t)j * 2 * cin_last * kBnSlots;
+    }
+    p.slot_stride = 2 * cin_last;
+    p.group_n = 0; p.gs = 0;
+    const float* const u[4] = {ubuf + tb.u_off[0], ubuf + tb.u_off[1], ubuf + tb.u_off[2], ubuf + tb.u_off[3]};
+    const float* const u1[4] = {ubuf1 + tb.u_off[0], ubuf1 + tb.u_off[1], ubuf1 + tb.u_off[2], ubuf1 + tb.u_off[3]};
+    const double flops = 2.0 * n * plane * c0 * 12 * 9 * 4;
+
+    std::vector<Variant> vs;
+    vs.push_back({"dgrad_block8<4> direct (reference values)", [&](hipStream_t s) { return launch_dgrad_block8<4>(p, s); }});
+    vs.push_back({"dgrad_wino8<4> (round-2 library)", [&](hipStream_t s) { return launch_dgrad_wino8<4>(p, u, s); }});
+    vs.push_back({"dgrad_wino3<4> (library)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 0>(p, u1, s); }});
+    vs.push_back({"dgrad_wino3<4> OPT16 (weight DMA at V end)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 16>(p, u1, s); }});
+    vs.push_back({"dgrad_wino3<4> OPT32 (setprio 1 in M phases)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 32>(p, u1, s); }});
+    vs.push_back({"wino3 no mem (7)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 7, 0>(p, u1, s); }});
+    vs.push_back({"wino3 no mem, no V arithmetic (71)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 71, 0>(p, u1, s); }});
+    vs.push_back({"wino3 no mem, no M phase (135)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 135, 0>(p, u1, s); }});
+    vs.push_back({"wino3 no mem, neither (199)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 199, 0>(p, u1, s); }});
+    if (mode == 0) {
+        vs.push_back({"wino8 no atomics (4)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 4>(p, u, s); }});
+        vs.push_back({"wino8 no stores (2)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 2>(p, u, s); }});
+        vs.push_back({"wino8 no x loads (1)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 1>(p, u, s); }});
+        vs.push_back({"wino8 no atomics/stores/loads (7)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 7>(p, u, s); }});
+        vs.push_back({"wino8 7 + weights once (15)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 15>(p, u, s); }});
+        vs.push_back({"wino8 15 + no barrier (31)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 31>(p, u, s); }});
+        vs.push_back({"wino8 31 + trivial epilogue (159)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 159>(p, u, s); }});
+        vs.push_back({"wino8 31 + no transform (95)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 95>(p, u, s); }});
+        vs.push_back({"wino8 31 + no MFMA (63)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 63>(p, u, s); }});
+        vs.push_back({"wino8 MFMA only-ish (223)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 223>(p, u, s); }});
+        vs.push_back({"wino8 trivial epilogue only (128)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 128>(p, u, s); }});
+        vs.push_back({"wino8 no transform only (64)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 64>(p, u, s); }});
+        vs.push_back({"wino8 no barrier only (16)", [&](hipStream_t s) { return launch_dgrad_wino8<4, 16>(p, u, s); }});
+    }
+    bench(vs, p.out, (size_t)c0 * plane, scratch, scratch_n, flops);
+    return 0;
+}
