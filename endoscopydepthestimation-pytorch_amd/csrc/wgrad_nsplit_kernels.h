@@ -242,64 +242,81 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         if (chunk + 1 < c_end) do_chunk(chunk + 1, Slot1{});
     }
 
-    // partial[((block * groups_total + group) * 7 + m) * 4 + r][lane] = D[row 16 m + 4 lk + r][ci = 16 group + li]
-    float* out = partial + (static_cast<int64_t>(blockIdx.x) * groups_total + group0) * (kNsMG * 256);
+    // partial[(group * 7 + m) * blocks + block][r][lane] = D[row 16 m + 4 lk + r][ci = 16 group + li]: row-block major, so that the
+    // reduce kernel streams one contiguous run of `blocks` 1 KB rows per (group, m) instead of gathering them 86 KB apart
+    const int64_t nblocks = gridDim.x;
 #pragma unroll
     for (int g = 0; g < NG; ++g)
         if (g < ngw) {
 #pragma unroll
-            for (int m = 0; m < kNsMG; ++m)
+            for (int m = 0; m < kNsMG; ++m) {
+                float* out = partial + ((static_cast<int64_t>(group0 + g) * kNsMG + m) * nblocks + blockIdx.x) * 256;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[((g * kNsMG + m) * 4 + r) * 64 + lane] = acc[g][m][r];
+                for (int r = 0; r < 4; ++r) out[r * 64 + lane] = acc[g][m][r];
+            }
         }
 }
 
-// grid (groups_total * 7, slices): thread (r, lane) of row block (group, m) adds the partials of its slice of blocks
+// grid (groups_total * 7, slices): the partial rows of row block (group, m) are one contiguous run of `blocks` x 256 floats; a
+// block of the grid adds its slice of them -- float4 per lane, four rows in flight per thread block pass, a fixed order per
+// (slice, element) -- and adds the slice's sum to the flat gradient (one atomic per element and slice).
 __global__ void __launch_bounds__(256) wgrad_nsplit_reduce_kernel(const float* __restrict__ partial, int blocks, int groups_total, int cin,
                                                                   float* __restrict__ dw) {
+    __shared__ f32x4 s_part[4][64];
     const int gm = blockIdx.x;
     const int group = gm / kNsMG, m7 = gm - group * kNsMG;
     const int per = (blocks + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = min(blocks, b0 + per);
-    const float* src = partial + (static_cast<int64_t>(group) * kNsMG + m7) * 256 + threadIdx.x;
-    const int64_t stride = static_cast<int64_t>(groups_total) * kNsMG * 256;
-    float s0 = 0.f, s1 = 0.f;
-    int b = b0;
-    for (; b + 1 < b1; b += 2) {
-        s0 += src[b * stride];
-        s1 += src[(b + 1) * stride];
+    if (b0 >= b1) return;
+    const int q = threadIdx.x & 63, sub = threadIdx.x >> 6;          // float4 q of a row; rows b0 + sub, b0 + sub + 4, ...
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial + (static_cast<int64_t>(gm) * blocks) * 256) + q;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int b = b0 + sub;
+    for (; b + 4 < b1; b += 8) {
+        s0 += src[static_cast<int64_t>(b) * 64];
+        s1 += src[static_cast<int64_t>(b + 4) * 64];
     }
-    if (b < b1) s0 += src[b * stride];
-    const int lane = threadIdx.x & 63, r = threadIdx.x >> 6;
+    if (b < b1) s0 += src[static_cast<int64_t>(b) * 64];
+    s_part[sub][q] = s0 + s1;
+    __syncthreads();
+    // element e = 4 q + k of the row: r = e >> 6, lane = e & 63  ->  thread t sums the four partial rows of element t
+    const int e = threadIdx.x;
+    const float* sp = reinterpret_cast<const float*>(s_part);
+    const float total = (sp[e] + sp[256 + e]) + (sp[512 + e] + sp[768 + e]);
+    const int lane = e & 63, r = e >> 6;
     const int m = 16 * m7 + 4 * (lane >> 4) + r;
     const int ci = 16 * group + (lane & 15);
-    if (m < 108 && ci < cin && b0 < b1) {
+    if (m < 108 && ci < cin) {
         const int co = m / 9, tap = m - co * 9;
-        atomicAdd(dw + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, s0 + s1);
+        atomicAdd(dw + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, total);
     }
 }
 
-constexpr int kNsMaxBlocks = 512;            // at NG = 3 (2 blocks per CU)
-constexpr int64_t kNsScratchFloats = static_cast<int64_t>(kNsMaxBlocks) * 12 * kNsMG * 256;   // blocks * groups <= 512 * 12
+constexpr int kNsMinChunks = 2048;           // launches with fewer row chunks go to the tap-folded kernel
+#ifndef ENDO_NS_BLOCKS3
+#define ENDO_NS_BLOCKS3 512                  // blocks of an NG = 3 launch (in-job A/B: 512 = 2 per CU, 768 = 3 per CU)
+#endif
+constexpr int kNsMaxBlocks = 1024;
+constexpr int64_t kNsScratchFloats = static_cast<int64_t>(kNsMaxBlocks) * 12 * kNsMG * 256;   // blocks * groups <= 1024 * 12
 
 inline bool wgrad_nsplit_ok(const WgradParams& p) {
     const bool aligned = (p.w % 4 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
                          (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
     const long chunks = static_cast<long>((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
-    return aligned && p.cout == 12 && chunks >= 4 * kNsMaxBlocks;
+    return aligned && p.cout == 12 && chunks >= kNsMinChunks;
 }
 
 template <int NG, int EXP = 0, int BF = 0>
 inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int passes, hipStream_t stream) {
     const int chunks_total = ((p.w + kNsSeg - 1) / kNsSeg) * p.h * p.n;
-    int blocks = (NG == 3 ? 512 : NG == 2 ? 768 : 1024) / passes;   // resident blocks per CU by register count: 2 / 3 / 4
+    int blocks = (NG == 3 ? ENDO_NS_BLOCKS3 : NG == 2 ? 768 : 1024) / passes;   // resident blocks per CU by register count: 2 / 3 / 4
     const int per = (chunks_total + blocks - 1) / blocks;
     blocks = (chunks_total + per - 1) / per;
     const int groups_total = (p.cin + 15) / 16;
     wgrad_nsplit_kernel<NG, EXP, BF><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
     ENDO_LAUNCH_CHECK();
-    wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 8), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
+    wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 16), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

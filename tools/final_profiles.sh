@@ -1,22 +1,27 @@
+# The profile set committed under profiles/ (run on an MI355X box through gpurun): tools/final_profiles.sh <tag>, e.g. r03_f
 set -x
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02c
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
+CMD="rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.err
-python3 $R/tools/summarize_rocprof.py /tmp/kt/kt_results.db $O/kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-python3 $R/tools/summarize_rocprof.py --by-grid /tmp/kt/kt_results.db $O/kernel_stats_by_grid.txt
-python3 $R/tools/gpu_busy.py /tmp/kt/kt_results.db > $O/gpu_busy.txt 2>&1
+python3 $R/tools/summarize_rocprof.py /tmp/kt/kt_results.db $O/${TAG}_kernel_stats.txt "$CMD" 7
+python3 $R/tools/summarize_rocprof.py --by-grid /tmp/kt/kt_results.db $O/${TAG}_kernel_stats_by_grid.txt
+python3 $R/tools/gpu_busy.py /tmp/kt/kt_results.db > $O/${TAG}_gpu_busy.txt 2>&1
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o f -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pf.err
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw -o w -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pw.err
-python3 $R/tools/pmc_traffic.py /tmp/pf/f_results.db /tmp/pw/w_results.db $O/pmc_traffic.json 7 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline" > $O/pmc_traffic.log 2>&1
+python3 $R/tools/pmc_traffic.py /tmp/pf/f_results.db /tmp/pw/w_results.db $O/${TAG}_pmc_traffic.json 7 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline" > $O/pmc_traffic.log 2>&1
 i=0
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $set -d /tmp/sq$i -o s -- python3 $R/tools/pmc_workload.py 1 > /dev/null 2> $O/sq$i.err
 done
-python3 $R/tools/pmc_sq_report.py $O/sq_counters.txt /tmp/sq1/s_results.db /tmp/sq2/s_results.db /tmp/sq3/s_results.db > $O/sq.log 2>&1
+python3 $R/tools/pmc_sq_report.py $O/${TAG}_sq_counters.txt /tmp/sq1/s_results.db /tmp/sq2/s_results.db /tmp/sq3/s_results.db > $O/sq.log 2>&1
 cd $R
-python bench.py > $O/bench.json 2> $O/bench.err
-tail -1 $O/bench.json | cut -c1-600
+# the bench line reads profiles/*_pmc_traffic.json and *_kernel_stats.json of THIS source revision: put them in place first
+cp $O/${TAG}_pmc_traffic.json $O/${TAG}_kernel_stats.json $R/profiles/
+python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
+tail -1 $O/${TAG}_bench.json | cut -c1-900
 ls -la $O

@@ -1,8 +1,15 @@
 #!/usr/bin/env python3
 """Turn a rocprofv3 --kernel-trace --stats result database (rocpd sqlite) into the per-kernel text
-summary committed under profiles/.   usage: summarize_rocprof.py <results.db> <out.txt> [note]"""
+summary committed under profiles/.   usage: summarize_rocprof.py <results.db> <out.txt> [note] [steps in the profiled run]
+With a step count it also writes <out>.json: dispatches per step (all kernels / the library's own), tied to the kernel sources by
+their hash (tools/source_id.py) -- bench.py's `dispatches_per_step` reads the newest such file and refuses a stale one."""
+import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from source_id import source_id          # noqa: E402
 
 
 def main():
@@ -21,6 +28,16 @@ def main():
         for r in rows:
             f.write("%-100s %7d %11.3f %6.2f %10.1f %10.1f %10.1f %5d %5d %7d\n" % (
                 r[0][:100], r[1], r[2] / 1e6, 100.0 * r[2] / total, r[3] / 1e3, r[4] / 1e3, r[5] / 1e3, r[6] or 0, r[7] or 0, r[8] or 0))
+    if len(sys.argv) > 4:
+        steps = int(sys.argv[4])
+        own = sum(r[1] for r in rows if "endo::" in r[0])
+        doc = {"command": note, "steps_in_the_profiled_run": steps, "source": source_id(),
+               "dispatches_per_step": sum(r[1] for r in rows) / steps, "library_kernel_dispatches_per_step": own / steps,
+               "kernel_time_ms_per_step": total / 1e6 / steps,
+               "note": "all kernels of the process (bench.py's own micro-benchmarks after the timed region included) / steps; "
+                       "library = kernels of namespace endo"}
+        with open(os.path.splitext(out_path)[0] + ".json", "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
 
 
 def by_grid():
