@@ -86,8 +86,12 @@ struct WinoFwdGeom {
     static constexpr int kCols = kTileX + 2 * kLeft;          // 40
     static constexpr int kRows = kTileY + 2;
     static constexpr int kPlane = kRows * kCols;
-    static constexpr int kCS = ((kPlane - 16 + 31) / 32) * 32 + 16;          // channel stride == 16 (mod 32) dwords
-    static constexpr int kUnits = kPlane / 4;                 // 16-byte DMA units per channel
+    // channel stride == 32 (mod 64) dwords: the patch reads are three aligned 8-byte reads per row (below), whose 64-bank map puts the
+    // two channels of a half-wave (lk, lk + 1) on disjoint halves -- conflict-free.  (Round 2 read columns 0 and 3 of the patch as
+    // dwords at a stride of 2 with a channel stride == 16 (mod 32): the two channels met on the same 16 odd banks, a 2-way conflict
+    // on every such read -- SQ_LDS_BANK_CONFLICT 32 % of SQ_LDS_IDX_ACTIVE in profiles/r02_c_sq_counters.txt.)
+    static constexpr int kCS = ((kPlane - 32 + 63) / 64) * 64 + 32;
+    static constexpr int kUnits = kCS / 4;                    // 16-byte DMA units per channel, the kCS - kPlane pad floats included
     static constexpr int kPos = (kUnits + kConvThreads - 1) / kConvThreads;
     static constexpr int kUUnits = KC * kWinoUStride / 4;
     static constexpr int kUPos = (kUUnits + kConvThreads - 1) / kConvThreads;
@@ -167,7 +171,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
                 const int rx = (u - ry * (G::kCols / 4)) * 4;
                 const int gy = y0 - 1 + ry;
                 const int gx = x0 - G::kLeft + rx;
-                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+                if (ry < G::kRows && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
                     d_ptr[k] = in_n + static_cast<int64_t>(c) * p.in_cs + gy * p.in_w + gx;
                     d_stride[k] = static_cast<unsigned>(KC) * static_cast<unsigned>(p.in_cs) * 4u;
                 }
@@ -208,7 +212,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
 #pragma unroll
             for (int xi = 0; xi < 16; ++xi) b[xi] = (EXP & 16) ? static_cast<float>(xi + lane) : b_base[xi * 16];
             // the lane's patch rows: LDS rows 2 t0 .. 2 t0 + 2R + 1 of its R tile rows (consecutive tile rows share two rows),
-            // LDS columns 2i+3 .. 2i+6: columns (1, 2) of the patch as one aligned 8-byte read, columns 0 and 3 as dword reads.
+            // LDS columns 2i+3 .. 2i+6 out of the three aligned pairs (2i+2, 2i+3), (2i+4, 2i+5), (2i+6, 2i+7): 8-byte reads only.
             // BN + ReLU once per value; max(NaN, 0) = 0 turns the NaN pad into the zero padding of the post-activation tensor.
             const float* a_base = s_in + (quad * 4 + lk) * G::kCS + (2 * wave * R) * G::kCols + 2 * li + 2;
             f32x2 mid[2 * R + 2], end[2 * R + 2];
@@ -218,8 +222,10 @@ __global__ void __launch_bounds__(kConvThreads, MINW) wino_fwd_kernel(const Conv
                 if constexpr ((EXP & 8) != 0) {
                     m = f32x2{sc + row, mn + row}; e = f32x2{bt + row, sc - row};
                 } else {
+                    const f32x2 left = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols);
+                    const f32x2 right = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 4);
                     m = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 2);
-                    e = f32x2{a_base[row * G::kCols + 1], a_base[row * G::kCols + 4]};
+                    e = f32x2{left[1], right[0]};
                 }
                 if constexpr ((EXP & 2) == 0) {
                     m = __builtin_elementwise_fma(m - mn2, sc2, bt2);
