@@ -220,7 +220,7 @@ def dispatches_per_step():
         return {"value": None, "source": "unreadable: " + name}
     if (doc.get("source") or {}).get("csrc_sha256") != csrc_sha256():
         return {"value": None, "source": "stale: %s belongs to other kernel sources -- regenerate it with tools/final_profiles.sh" % name}
-    return {"value": doc["library_kernel_dispatches_per_step"], "all_kernels_of_the_profiled_process": doc["dispatches_per_step"],
+    return {"value": doc["dispatches_per_step"], "library_kernels": doc["library_kernel_dispatches_per_step"],
             "kernel_time_ms_per_step": doc["kernel_time_ms_per_step"], "source": name}
 
 
