@@ -1,0 +1,404 @@
+// bf16-STORAGE kernel family, first bricks (round 3; BASELINE configs[2] / [4]): convolutions over channels-last bf16
+// level buffers on the bf16 matrix cores.
+//
+// Why another family and another layout.  fp32 matrix instructions run on the vector FMA lanes of this part, so the
+// fp32 path is bound by the SUM of its matrix and vector work; v_mfma_f32_16x16x32_bf16 is a separate unit at 16x the rate.  With
+// bf16 operands a lane supplies 8 consecutive k per instruction, and for a convolution k runs over INPUT CHANNELS -- which the
+// planar (NCHW) buffers of the fp32 family put a whole plane apart.  Here a level buffer is [n][h][w][t] bf16 (NHWC: the t channels
+// of a pixel are contiguous): a lane's 8 k are one 16-byte read, a dense layer reads one contiguous run of Cin channels per pixel
+// and appends its 12 outputs as 24 contiguous bytes.
+//
+// MFMA roles (v_mfma_f32_16x16x32_bf16, fp32 accumulation): A[i = cout][k = channel] = weights, B[k = channel][j = pixel] =
+// activations, D[i = cout][j = pixel]: a lane ends up with 4 consecutive output channels of ONE pixel -- an 8-byte NHWC store.
+// A block owns a 16 x 32 pixel tile (4 waves x 4 rows); per K-chunk of 32 input channels the haloed tile (18 x 34 pixels x 64 B)
+// is staged through registers into LDS with BatchNorm + ReLU applied ONCE per element on the way (the fp32 kernels apply it on
+// every fragment read; here each staged element is read for 9 taps) and out-of-image pixels written as the zeros of the padded
+// post-activation tensor (reference models.py:22-25 pads relu(bn(x))).  16-byte slots are XOR-swizzled by (x >> 1) & 3 so that the
+// fragment reads (one ds_read_b128 per lane: 16 lanes x 64-byte stride) are conflict-free.  A fragment read at LDS row r serves
+// the three output rows r, r - 1, r - 2 (ky taps): 36 fragment + 9 weight reads feed 72 MFMAs per wave and chunk.
+//
+// Per-pixel budget of the widest dense layer (level 0, Cin = 180), in cycles of one SIMD: HBM 106 (360 B at 8 TB/s over 1024 SIMDs),
+// matrix 54, vector 39 (unpack / fma / max / pack once per element) -- HBM-bound, ~5x under the fp32 Winograd kernel's 845.
+#pragma once
+
+#include "common.h"
+
+namespace endo {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kBfTileX = 32, kBfTileY = 16;          // output pixels per block
+constexpr int kBfKC = 32;                            // input channels per K-chunk (one MFMA k extent)
+constexpr int kBfThreads = 256;
+
+struct Conv16Params {
+    int n, h, w;                     // output grid
+    const uint16_t* in;              // bf16 NHWC input level buffer
+    int64_t in_ns;                   // elements between samples
+    int in_t;                        // channels per input pixel record
+    int in_h, in_w;                  // input grid (== h, w unless `ups`)
+    int ic0, cin;                    // the layer reads channels [ic0, ic0 + cin)
+    const float* bn;                 // [cin][2] = (scale, shift): z = max(x * scale + shift, 0); null = raw input (unless in_sums)
+    // BatchNorm of the input from statistics instead of a table (reference models.py:22: nn.BatchNorm2d in front of every dense /
+    // transition-down convolution): training != 0: batch statistics from in_sums ([cin][2] fp64 sum, sum^2 over `count` values per
+    // channel), running statistics updated (momentum, unbiased variance) and (mean, rstd) saved by the first block; 0: running
+    // statistics.  scale = gamma * rstd, shift = beta - mean * scale.
+    const double* in_sums;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* saved;                    // [cin][2] (mean, rstd) or null
+    double count;
+    float eps, momentum;
+    int training;
+    int use_stats;                   // 1: the block above applies (bn is ignored)
+    const uint16_t* wgt;             // [chunk][tap][nt][16 cout][32 k] bf16, k >= cin and cout >= `cout` zero
+    const float* bias;               // [cout] or null
+    uint16_t* out;                   // bf16 NHWC output level buffer
+    int64_t out_ns;
+    int out_t;
+    int oc0, cout;
+    double* out_sums;                // [cout][2] sum, sum^2 of the STORED (bf16-rounded) values, or null
+    int ups;                         // 1: nearest x2 upsampling of the input on the way in (transition up, models.py:73)
+    // POOL epilogue (transition down, models.py:64: MaxPool2d(2)): out is the (h / 2) x (w / 2) grid; out_idx: one byte per pooled
+    // value, [n][h / 2][w / 2][cout], the position 2 dy + dx of the maximum inside its window (first maximum in row-major order)
+    uint8_t* out_idx;
+};
+
+__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+// two floats -> two bf16 (round to nearest even) in one dword, low half first
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+// byte offset of the 16-byte slot (channel part 0..3 of the chunk) of tile pixel (row, x) in the staged tile
+template <int COLS>
+__device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row * COLS + x) * 4 + (part ^ ((x >> 1) & 3))) * 16; }
+
+// KS = 3 (pad 1) or 1; NT = 16-cout tiles per block (grid.y covers ceil(cout / (16 NT)) of them); POOL = 1: 2 x 2 max-pool epilogue
+template <int KS, int NT, int POOL = 0>
+__global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Params p) {
+    constexpr int kHalo = KS / 2;
+    constexpr int kRows = kBfTileY + 2 * kHalo, kCols = kBfTileX + 2 * kHalo;
+    constexpr int kPix = kRows * kCols;
+    constexpr int kUnits = kPix * 4;                                   // 16-byte units of a chunk
+    constexpr int kIter = (kUnits + kBfThreads - 1) / kBfThreads;
+    constexpr int kTaps = KS * KS;
+    constexpr int kWUnits = kTaps * NT * 16 * 4;                       // 16-byte units of a chunk's weight slice
+    constexpr int kWIter = (kWUnits + kBfThreads - 1) / kBfThreads;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char* s_act = smem16;                                     // [kRows][kCols][4 slots][16 B]
+    unsigned char* s_w = s_act + kPix * 64;                            // [tap][nt][16 cout][4 slots][16 B]
+    float* s_bn = reinterpret_cast<float*>(s_w + kWUnits * 16);        // [cin padded to 32][2]
+    float* s_red = s_bn;                                               // reused after the K loop: [4 waves][NT * 16][2]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX;
+    const int tile = blockIdx.x;
+    const int x0 = (tile % tiles_x) * kBfTileX, y0 = (tile / tiles_x) * kBfTileY;
+    const int n = blockIdx.z;
+    const int co_base = blockIdx.y * NT * 16;
+    const int nchunks = (p.cin + kBfKC - 1) / kBfKC;
+    const uint16_t* in_n = p.in + n * p.in_ns + p.ic0;
+
+    const bool has_bn = p.bn != nullptr || p.use_stats != 0;
+    const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    for (int c = tid; c < nchunks * kBfKC; c += kBfThreads) {
+        float sc = 0.f, sh = 0.f;
+        if (c < p.cin) {
+            if (p.use_stats) {
+                double mean, var;
+                if (p.training) {
+                    mean = p.in_sums[2 * c] / p.count;
+                    var = p.in_sums[2 * c + 1] / p.count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                } else {
+                    mean = p.running_mean[c];
+                    var = p.running_var[c];
+                }
+                const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(p.eps)));
+                const float mean_f = static_cast<float>(mean);
+                sc = p.gamma[c] * rstd;
+                sh = fmaf(-mean_f, sc, p.beta[c]);
+                if (first_block) {
+                    if (p.saved) { p.saved[2 * c] = mean_f; p.saved[2 * c + 1] = rstd; }
+                    if (p.training) {
+                        const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
+                        p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * mean_f;
+                        p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
+                    }
+                }
+            } else {
+                sc = p.bn ? p.bn[2 * c] : 1.f; sh = p.bn ? p.bn[2 * c + 1] : 0.f;
+            }
+        }
+        s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
+    }
+
+    // this thread's units of a chunk: tile pixel, channel part, source address (the same every chunk, channels advance)
+    int u_src[kIter];            // element offset of the unit's pixel in the input sample, -1 = outside the image / no unit
+    int u_dst[kIter];            // byte offset in s_act
+#pragma unroll
+    for (int i = 0; i < kIter; ++i) {
+        const int u = tid + i * kBfThreads;
+        u_src[i] = -1; u_dst[i] = -1;
+        if (u < kUnits) {
+            const int px = u >> 2, part = u & 3;
+            const int ry = px / kCols, rx = px - ry * kCols;
+            const int gy = y0 - kHalo + ry, gx = x0 - kHalo + rx;
+            u_dst[i] = bf_slot<kCols>(ry, rx, part);
+            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+                const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+                u_src[i] = (sy * p.in_w + sx) * p.in_t + part * 8;
+            }
+        }
+    }
+
+    u32x4_t raw[kIter];
+    u32x4_t wraw[kWIter];
+    auto issue_loads = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            raw[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (u_src[i] >= 0) {
+                // channels past the end of the record never belong to the layer (cin <= in_t - ic0), but the last unit of the last chunk may
+                // straddle cin: it is read as far as the record goes and masked below
+                const uint16_t* src = in_n + u_src[i] + chunk * kBfKC;
+                const int cpart = chunk * kBfKC + ((tid + i * kBfThreads) & 3) * 8;
+                if (cpart + 8 <= p.cin) raw[i] = *reinterpret_cast<const u32x4_t*>(src);
+                else if (cpart < p.cin) {          // cin is a multiple of 4: the unit holds 4 valid channels
+                    const u32x2_t half = *reinterpret_cast<const u32x2_t*>(src);
+                    raw[i] = u32x4_t{half[0], half[1], 0u, 0u};
+                }
+            }
+        }
+        const uint16_t* wsrc = p.wgt + (static_cast<int64_t>(chunk) * gridDim.y + blockIdx.y) * (kWUnits * 8);
+#pragma unroll
+        for (int i = 0; i < kWIter; ++i) {
+            const int u = tid + i * kBfThreads;
+            wraw[i] = u < kWUnits ? *reinterpret_cast<const u32x4_t*>(wsrc + u * 8) : u32x4_t{0u, 0u, 0u, 0u};
+        }
+    };
+    auto write_stage = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            if (u_dst[i] < 0) continue;
+            u32x4_t v = raw[i];
+            if (has_bn) {
+                const int c0 = chunk * kBfKC + ((tid + i * kBfThreads) & 3) * 8;
+                const bool inside = u_src[i] >= 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float2 a = *reinterpret_cast<const float2*>(s_bn + 2 * (c0 + 2 * k));
+                    const float2 b = *reinterpret_cast<const float2*>(s_bn + 2 * (c0 + 2 * k + 1));
+                    float z0 = fmaxf(fmaf(bf16_lo(v[k]), a.x, a.y), 0.f);
+                    float z1 = fmaxf(fmaf(bf16_hi(v[k]), b.x, b.y), 0.f);
+                    if (!inside) { z0 = 0.f; z1 = 0.f; }          // the zero padding of the post-activation tensor
+                    v[k] = pack_bf16x2(z0, z1);
+                }
+            }
+            *reinterpret_cast<u32x4_t*>(s_act + u_dst[i]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < kWIter; ++i) {
+            const int u = tid + i * kBfThreads;
+            if (u < kWUnits) {
+                // global order [tap][nt][cout 16][part 4]; LDS slot swizzled by the cout like the activation tile by x
+                const int part = u & 3, co = (u >> 2) & 15, rest = u >> 6;
+                *reinterpret_cast<u32x4_t*>(s_w + ((rest * 16 + co) * 4 + (part ^ ((co >> 1) & 3))) * 16) = wraw[i];
+            }
+        }
+    };
+
+    f32x4_t acc[4][2][NT];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[r][hh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    __syncthreads();          // s_bn
+    issue_loads(0);
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        write_stage(chunk);
+        __syncthreads();
+        if (chunk + 1 < nchunks) issue_loads(chunk + 1);
+        // ---- this wave's 4 output rows x 32 pixels: LDS row lr (tile row 4 wave + lr) feeds output rows lr - ky ----
+#pragma unroll
+        for (int lr = 0; lr < 4 + 2 * kHalo; ++lr) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    const int lx = 16 * hh + li + kx;
+                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(s_act + bf_slot<kCols>(4 * wave + lr, lx, lk));
+#pragma unroll
+                    for (int ky = 0; ky < KS; ++ky) {
+                        const int r = lr - ky;
+                        if (r < 0 || r >= 4) continue;
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const int wrow = (ky * KS + kx) * NT + t;
+                            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s_w + ((wrow * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
+                            acc[r][hh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r][hh][t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores (4 consecutive couts of one pixel per lane), statistics of the stored values ----
+    float s1[NT][4], s2[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; }
+    uint16_t* out_n = p.out + n * p.out_ns + p.oc0;
+    if constexpr (POOL != 0) {
+        // 2 x 2 max pool of the accumulators: rows 2 rp, 2 rp + 1 of the lane, columns li (even) and li + 1 (the neighbouring lane)
+        const int hp = p.h >> 1, wp = p.w >> 1;
+#pragma unroll
+        for (int rp = 0; rp < 2; ++rp)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int yp = (y0 >> 1) + 2 * wave + rp, xp = (x0 + 16 * hh + li) >> 1;
+                const bool pix_ok = yp < hp && xp < wp && (li & 1) == 0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int co = co_base + 16 * t + 4 * lk;
+                    float best[4];
+                    unsigned code = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float v00 = acc[2 * rp][hh][t][i], v10 = acc[2 * rp + 1][hh][t][i];
+                        const float v01 = __shfl_xor(v00, 1, 64), v11 = __shfl_xor(v10, 1, 64);
+                        float b = v00; unsigned c = 0;
+                        if (v01 > b) { b = v01; c = 1; }
+                        if (v10 > b) { b = v10; c = 2; }
+                        if (v11 > b) { b = v11; c = 3; }
+                        best[i] = b; code |= c << (8 * i);
+                    }
+                    if (co >= p.cout || !pix_ok) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) best[i] += p.bias ? p.bias[co + i] : 0.f;
+                    const unsigned lo = pack_bf16x2(best[0], best[1]), hi = pack_bf16x2(best[2], best[3]);
+                    const int64_t pix = static_cast<int64_t>(yp) * wp + xp;
+                    *reinterpret_cast<u32x2_t*>(out_n + pix * p.out_t + co) = u32x2_t{lo, hi};
+                    *reinterpret_cast<unsigned*>(p.out_idx + (static_cast<int64_t>(n) * hp * wp + pix) * p.cout + co) = code;
+                    const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
+                }
+            }
+    } else
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int y = y0 + 4 * wave + r, x = x0 + 16 * hh + li;
+            const bool pix_ok = y < p.h && x < p.w;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co_base + 16 * t + 4 * lk;
+                if (co >= p.cout) continue;          // cout is a multiple of 4
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = acc[r][hh][t][i] + (p.bias ? p.bias[co + i] : 0.f);
+                const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+                if (pix_ok) {
+                    *reinterpret_cast<u32x2_t*>(out_n + (static_cast<int64_t>(y) * p.w + x) * p.out_t + co) = u32x2_t{lo, hi};
+                    const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
+                }
+            }
+        }
+    if (p.out_sums) {
+        // reduce over the 16 pixels of a lane group (li), then over the waves through LDS, one fp64 atomic per channel, sum and block
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) {
+                    s1[t][i] += __shfl_xor(s1[t][i], off, 64);
+                    s2[t][i] += __shfl_xor(s2[t][i], off, 64);
+                }
+            }
+        if (li == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    s_red[((wave * NT * 16) + 16 * t + 4 * lk + i) * 2] = s1[t][i];
+                    s_red[((wave * NT * 16) + 16 * t + 4 * lk + i) * 2 + 1] = s2[t][i];
+                }
+        }
+        __syncthreads();
+        for (int e = tid; e < NT * 16 * 2; e += kBfThreads) {
+            const int ch = e >> 1;
+            if (co_base + ch < p.cout) {
+                double tsum = 0.0;
+                for (int wv = 0; wv < 4; ++wv) tsum += static_cast<double>(s_red[(wv * NT * 16 + ch) * 2 + (e & 1)]);
+                atomicAdd(p.out_sums + 2 * (co_base + ch) + (e & 1), tsum);
+            }
+        }
+    }
+}
+
+template <int KS, int NT>
+inline size_t bf16_conv_smem(int cin) {
+    constexpr int kHalo = KS / 2;
+    constexpr int kPix = (kBfTileY + 2 * kHalo) * (kBfTileX + 2 * kHalo);
+    const int cpad = (cin + kBfKC - 1) / kBfKC * kBfKC;
+    const size_t bn = sizeof(float) * 2 * cpad, red = sizeof(float) * 4 * NT * 16 * 2;
+    return static_cast<size_t>(kPix) * 64 + static_cast<size_t>(KS * KS * NT) * 16 * 64 + (bn > red ? bn : red);
+}
+
+template <int KS, int NT, int POOL = 0>
+inline int launch_bf16_conv(const Conv16Params& p, hipStream_t stream) {
+    const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kBfTileY - 1) / kBfTileY);
+    const int ngroups = (p.cout + NT * 16 - 1) / (NT * 16);
+    const size_t smem = bf16_conv_smem<KS, NT>(p.cin);
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   static_cast<int>(smem)));
+    bf16_conv_kernel<KS, NT, POOL><<<dim3(tiles, ngroups, p.n), kBfThreads, smem, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- weights: W[cout][cin][KS][KS] fp32 -> [chunk][group][tap][nt][16 cout][32 k] bf16 (zero padded) --------------------------------
+// (the kernel indexes (chunk * gridDim.y + blockIdx.y) * (taps * NT * 16 * 32) + ((tap * NT + nt) * 16 + cout) * 32 + k)
+__global__ void __launch_bounds__(256) bf16_conv_weights_kernel(const float* __restrict__ w, int cout, int cin, int ks, int nt,
+                                                                uint16_t* __restrict__ out) {
+    const int taps = ks * ks;
+    const int nchunks = (cin + kBfKC - 1) / kBfKC;
+    const int ngroups = (cout + nt * 16 - 1) / (nt * 16);
+    const int64_t total = static_cast<int64_t>(nchunks) * ngroups * taps * nt * 16 * 32;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int k = e & 31, co16 = (e >> 5) & 15;
+        int64_t rest = e >> 9;
+        const int t = rest % nt; rest /= nt;
+        const int tap = rest % taps; rest /= taps;
+        const int grp = rest % ngroups;
+        const int chunk = rest / ngroups;
+        const int co = (grp * nt + t) * 16 + co16, ci = chunk * kBfKC + k;
+        float v = 0.f;
+        if (co < cout && ci < cin) v = w[(static_cast<int64_t>(co) * cin + ci) * taps + tap];
+        out[e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
+}
+
+}  // namespace endo

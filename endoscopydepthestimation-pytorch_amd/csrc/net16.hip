@@ -1,0 +1,392 @@
+// bf16-storage kernel family: host side (round 3).  What exists: layout conversion, the channels-last convolution (dense layer,
+// transition up, transition down with its max-pool, first convolution), the final 1x1 + |.|, and on top of them the FORWARD pass of
+// FCDenseNet57 (reference models.py:171-187) over bf16 level buffers -- training-mode (batch statistics, running-statistics
+// update) and inference.  The backward pass over this layout is the next round's work; nothing here is on the fp32
+// product path.
+#include <vector>
+
+#include "bf16_conv_kernels.h"
+
+extern "C" int64_t endo_net_param_offset(int index);
+extern "C" int64_t endo_net_bn_offset(int bn_index, int which);
+
+namespace endo {
+
+constexpr int k16Levels = 5, k16Layers = 4, k16Growth = 12, k16First = 48, k16New = 48;
+inline int c16_down_in(int level) { return k16First + k16New * level; }
+inline int c16_level_channels(int level) { return level < k16Levels ? 144 + c16_down_in(level) : 288 + k16New; }
+
+struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; };      // w16: element offset of the converted weights
+struct Bn16 { int64_t g, b; int c; int64_t run_mean, run_var; int64_t saved; };
+
+// the reference's module order (models.py:100-170, the order of .parameters()): offsets come from the fp32 family's own table
+struct Table16 {
+    Conv16 first, final_;
+    Conv16 down_conv[k16Levels][k16Layers], td_conv[k16Levels], bott_conv[k16Layers], tu_conv[k16Levels], up_conv[k16Levels][k16Layers];
+    Bn16 down_bn[k16Levels][k16Layers], td_bn[k16Levels], bott_bn[k16Layers], up_bn[k16Levels][k16Layers];
+    std::vector<Conv16*> convs;
+    int64_t w16_elems = 0, saved_floats = 0;
+};
+
+static const Table16& table16() {
+    static Table16* t = [] {
+        Table16* tb = new Table16();
+        int pi = 0, bi = 0;
+        int64_t saved = 0;
+        auto conv = [&](Conv16& c, int cout, int cin, int ks, bool mfma) {
+            c.cout = cout; c.cin = cin; c.ks = ks; c.nt = cout <= 16 ? 1 : 3;
+            c.w = endo_net_param_offset(pi++); c.b = endo_net_param_offset(pi++);
+            c.w16 = -1;
+            if (mfma) {
+                const int cin_k = cin < 4 ? 4 : cin;          // the first convolution's 3 input channels travel as 4 (+ 4 zero) of an 8-channel record
+                c.w16 = tb->w16_elems;
+                const int64_t groups = (cout + c.nt * 16 - 1) / (c.nt * 16), chunks = (cin_k + kBfKC - 1) / kBfKC;
+                tb->w16_elems += chunks * groups * ks * ks * c.nt * 16 * 32;
+                tb->convs.push_back(&c);
+            }
+        };
+        auto bn = [&](Bn16& b, int c) {
+            b.c = c;
+            b.g = endo_net_param_offset(pi++); b.b = endo_net_param_offset(pi++);
+            b.run_mean = endo_net_bn_offset(bi, 0); b.run_var = endo_net_bn_offset(bi, 1); ++bi;
+            b.saved = saved; saved += 2 * c;
+        };
+        conv(tb->first, k16First, 3, 3, true);
+        for (int l = 0; l < k16Levels; ++l)
+            for (int j = 0; j < k16Layers; ++j) { bn(tb->down_bn[l][j], c16_down_in(l) + k16Growth * j); conv(tb->down_conv[l][j], k16Growth, c16_down_in(l) + k16Growth * j, 3, true); }
+        for (int l = 0; l < k16Levels; ++l) { bn(tb->td_bn[l], c16_down_in(l) + k16New); conv(tb->td_conv[l], c16_down_in(l) + k16New, c16_down_in(l) + k16New, 1, true); }
+        for (int j = 0; j < k16Layers; ++j) { bn(tb->bott_bn[j], 288 + k16Growth * j); conv(tb->bott_conv[j], k16Growth, 288 + k16Growth * j, 3, true); }
+        for (int i = 0; i < k16Levels; ++i) conv(tb->tu_conv[i], k16New, k16New, 3, true);
+        for (int i = 0; i < k16Levels; ++i) {
+            const int l = k16Levels - 1 - i;
+            for (int j = 0; j < k16Layers; ++j) { const int cin = 96 + c16_down_in(l) + k16Growth * j; bn(tb->up_bn[i][j], cin); conv(tb->up_conv[i][j], k16Growth, cin, 3, true); }
+        }
+        conv(tb->final_, 1, 192, 1, false);
+        tb->saved_floats = saved;
+        return tb;
+    }();
+    return *t;
+}
+
+// every MFMA convolution's weights, fp32 -> the kernel's bf16 layout, in ONE launch (the parameters change every step)
+struct W16Table {
+    int layers;
+    int64_t start[64];          // prefix sum of output elements
+    int64_t w[63], out[63];
+    int cout[63], cin[63], cin_k[63], ks[63], nt[63];
+};
+
+__global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t, const float* __restrict__ params, uint16_t* __restrict__ w16) {
+    const int64_t total = t.start[t.layers];
+    for (int64_t item = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; item < total; item += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        int l = 0;
+        while (item >= t.start[l + 1]) ++l;
+        const int64_t e = item - t.start[l];
+        const int taps = t.ks[l] * t.ks[l], nt = t.nt[l];
+        const int ngroups = (t.cout[l] + nt * 16 - 1) / (nt * 16);
+        const int k = e & 31, co16 = (e >> 5) & 15;
+        int64_t rest = e >> 9;
+        const int tt = rest % nt; rest /= nt;
+        const int tap = rest % taps; rest /= taps;
+        const int grp = rest % ngroups;
+        const int chunk = rest / ngroups;
+        const int co = (grp * nt + tt) * 16 + co16, ci = chunk * kBfKC + k;
+        float v = 0.f;
+        if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + ci) * taps + tap];
+        w16[t.out[l] + e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
+}
+
+// x: fp32 [n][3][h][w] -> bf16 [n][h][w][8] (channels 3..7 zero): the first convolution's input record
+__global__ void __launch_bounds__(256) bf16_pack_input_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int plane) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
+        const float* xp = x + static_cast<int64_t>(n) * 3 * plane + i;
+        const unsigned a = pack_bf16x2(xp[0], xp[plane]), b = pack_bf16x2(xp[2 * static_cast<int64_t>(plane)], 0.f);
+        *reinterpret_cast<u32x4_t*>(out + (static_cast<int64_t>(n) * plane + i) * 8) = u32x4_t{a, b, 0u, 0u};
+    }
+}
+
+// final 1x1 convolution 192 -> 1 and |.| (reference models.py:167, 186): 8 lanes per pixel, 24 channels each
+__global__ void __launch_bounds__(256) bf16_final_fwd_kernel(const uint16_t* __restrict__ u, int64_t ns, int plane, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int sub = threadIdx.x & 7;
+    float wv[24];
+#pragma unroll
+    for (int k = 0; k < 24; ++k) wv[k] = w[sub * 24 + k];
+    for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; px < plane; px += (gridDim.x * blockDim.x) >> 3) {
+        const uint16_t* src = u + n * ns + static_cast<int64_t>(px) * 192 + sub * 24;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + 8 * j);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc = fmaf(bf16_lo(v[k]), wv[8 * j + 2 * k], acc);
+                acc = fmaf(bf16_hi(v[k]), wv[8 * j + 2 * k + 1], acc);
+            }
+        }
+        acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+        if (sub == 0) {
+            const float z = acc + bias[0];
+            pre[static_cast<int64_t>(n) * plane + px] = z;
+            out[static_cast<int64_t>(n) * plane + px] = fabsf(z);
+        }
+    }
+}
+
+// fp32 NCHW [n][c][h][w] -> channels [oc0, oc0 + c) of a bf16 NHWC buffer with `t` channels per pixel
+__global__ void __launch_bounds__(256) bf16_pack_nhwc_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int c, int plane, int t, int oc0) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane * c; i += gridDim.x * blockDim.x) {
+        const int ch = i % c, px = i / c;
+        const float v = x[(static_cast<int64_t>(n) * c + ch) * plane + px];
+        out[(static_cast<int64_t>(n) * plane + px) * t + oc0 + ch] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
+}
+
+__global__ void __launch_bounds__(256) bf16_unpack_nhwc_kernel(const uint16_t* __restrict__ in, float* __restrict__ x, int c, int plane, int t, int ic0) {
+    const int n = blockIdx.y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane * c; i += gridDim.x * blockDim.x) {
+        const int ch = i % c, px = i / c;
+        x[(static_cast<int64_t>(n) * c + ch) * plane + px] = bf16_lo(in[(static_cast<int64_t>(n) * plane + px) * t + ic0 + ch]);
+    }
+}
+
+}  // namespace endo
+
+using namespace endo;
+
+extern "C" int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int oc0, void* stream) {
+    if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || oc0 < 0 || oc0 + c > t) return ENDO_E_BADARG;
+    bf16_pack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(x, static_cast<uint16_t*>(out), c, h * w, t, oc0);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int ic0, void* stream) {
+    if (!x || !in || n <= 0 || c <= 0 || h <= 0 || w <= 0 || ic0 < 0 || ic0 + c > t) return ENDO_E_BADARG;
+    bf16_unpack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(in), x, c, h * w, t, ic0);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int64_t endo_bf16_conv_weight_elems(int cout, int cin, int ks) {
+    if (cout <= 0 || cin <= 0 || (ks != 1 && ks != 3)) return -1;
+    const int nt = cout <= 16 ? 1 : 3;
+    const int64_t groups = (cout + nt * 16 - 1) / (nt * 16), chunks = (cin + kBfKC - 1) / kBfKC;
+    return chunks * groups * ks * ks * nt * 16 * 32;
+}
+
+extern "C" int endo_bf16_conv_weights(const float* w, int cout, int cin, int ks, void* out, void* stream) {
+    if (!w || !out || endo_bf16_conv_weight_elems(cout, cin, ks) < 0) return ENDO_E_BADARG;
+    const int nt = cout <= 16 ? 1 : 3;
+    bf16_conv_weights_kernel<<<256, 256, 0, static_cast<hipStream_t>(stream)>>>(w, cout, cin, ks, nt, static_cast<uint16_t*>(out));
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// One convolution over channels-last bf16 buffers (reference models.py:22-25 / 73-74: [BN -> ReLU ->] [nearest x2 ->] conv KS x KS + bias).
+// in: [n][in_h][in_w][in_t] bf16, channels [ic0, ic0 + cin); out: [n][h][w][out_t] bf16, channels [oc0, oc0 + cout) (cout % 4 == 0,
+// cin % 4 == 0, ic0 % 8 == 0, in_t % 8 == 0, oc0 % 4 == 0); bn: [cin][2] (scale, shift) or null; wgt from endo_bf16_conv_weights;
+// out_sums: [cout][2] fp64 (sum, sum^2 of the stored values, ACCUMULATED) or null; ups: input is (h / 2) x (w / 2), nearest x2.
+extern "C" int endo_bf16_conv(const void* in, int in_t, int ic0, int cin, const float* bn, const void* wgt, const float* bias, void* out, int out_t,
+                              int oc0, int cout, double* out_sums, int n, int h, int w, int ks, int ups, void* stream_) {
+    if (!in || !wgt || !out || n <= 0 || h <= 0 || w <= 0 || (ks != 1 && ks != 3) || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || (ic0 & 7) ||
+        (in_t & 7) || (oc0 & 3) || (out_t & 3) || ic0 + cin > in_t || oc0 + cout > out_t || (ups && ((h | w) & 1)))
+        return ENDO_E_BADARG;
+    Conv16Params p{};
+    p.n = n; p.h = h; p.w = w;
+    p.in_h = ups ? h / 2 : h; p.in_w = ups ? w / 2 : w;
+    p.in = static_cast<const uint16_t*>(in); p.in_t = in_t; p.in_ns = static_cast<int64_t>(p.in_h) * p.in_w * in_t; p.ic0 = ic0; p.cin = cin;
+    p.bn = bn; p.wgt = static_cast<const uint16_t*>(wgt); p.bias = bias;
+    p.out = static_cast<uint16_t*>(out); p.out_t = out_t; p.out_ns = static_cast<int64_t>(h) * w * out_t; p.oc0 = oc0; p.cout = cout;
+    p.out_sums = out_sums; p.ups = ups;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    if (ks == 3) return cout <= 16 ? launch_bf16_conv<3, 1>(p, stream) : launch_bf16_conv<3, 3>(p, stream);
+    return cout <= 16 ? launch_bf16_conv<1, 1>(p, stream) : launch_bf16_conv<1, 3>(p, stream);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// FCDenseNet57 forward over bf16 level buffers (reference models.py:171-187)
+// ---------------------------------------------------------------------------------------------
+struct endo_net16 {
+    int n, h, w;
+    struct Level { int h, w, t; int64_t plane; int64_t act; int64_t sums; } lv[k16Levels + 1];      // act: bytes, sums: doubles (from sums_off)
+    int64_t in_off;            // bytes: the packed input [n][h][w][8] bf16
+    int64_t idx_off[k16Levels];
+    int64_t pre_off;           // bytes: final pre-activation fp32
+    int64_t saved_off;         // bytes: BN (mean, rstd) fp32
+    int64_t sums_off, sums_bytes;
+    int64_t w16_off;           // bytes
+    int64_t tape_bytes;
+};
+
+extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
+    if (!out || n <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32)) return ENDO_E_BADARG;
+    const Table16& tb = table16();
+    endo_net16* net = new (std::nothrow) endo_net16();
+    if (!net) return ENDO_E_BADARG;
+    net->n = n; net->h = h; net->w = w;
+    auto align = [](int64_t v) { return (v + 255) / 256 * 256; };
+    int64_t off = 0, sums = 0;
+    for (int l = 0; l <= k16Levels; ++l) {
+        auto& lv = net->lv[l];
+        lv.h = h >> l; lv.w = w >> l; lv.t = c16_level_channels(l); lv.plane = static_cast<int64_t>(lv.h) * lv.w;
+        lv.act = off; off += align(static_cast<int64_t>(n) * lv.plane * lv.t * 2);
+        lv.sums = sums; sums += 2 * lv.t;
+    }
+    net->in_off = off; off += align(static_cast<int64_t>(n) * net->lv[0].plane * 16);
+    for (int l = 0; l < k16Levels; ++l) { net->idx_off[l] = off; off += align(static_cast<int64_t>(n) * net->lv[l + 1].plane * (c16_down_in(l) + k16New)); }
+    net->pre_off = off; off += align(static_cast<int64_t>(n) * net->lv[0].plane * 4);
+    net->saved_off = off; off += align(tb.saved_floats * 4);
+    net->sums_off = off; net->sums_bytes = sums * 8; off += align(net->sums_bytes);
+    net->w16_off = off; off += align(tb.w16_elems * 2);
+    net->tape_bytes = off;
+    *out = net;
+    return 0;
+}
+extern "C" void endo_net16_destroy(endo_net16* net) { delete net; }
+extern "C" int64_t endo_net16_tape_bytes(const endo_net16* net) { return net ? net->tape_bytes : 0; }
+
+namespace {
+
+struct Ctx16 {
+    const endo_net16* net;
+    const float* params;
+    float* bn_running;
+    char* tape;
+    int training;
+    hipStream_t stream;
+    uint16_t* act(int level) const { return reinterpret_cast<uint16_t*>(tape + net->lv[level].act); }
+    double* sums(int level) const { return reinterpret_cast<double*>(tape + net->sums_off) + net->lv[level].sums; }
+    const uint16_t* w16(const Conv16& c) const { return reinterpret_cast<const uint16_t*>(tape + net->w16_off) + c.w16; }
+    float* saved(const Bn16& b) const { return reinterpret_cast<float*>(tape + net->saved_off) + b.saved; }
+};
+
+void fill_io(const Ctx16& c, Conv16Params& p, int in_level, int ic0, int cin, int out_level, int oc0, const Conv16& cv) {
+    const auto& li = c.net->lv[in_level];
+    const auto& lo = c.net->lv[out_level];
+    p.n = c.net->n;
+    p.in = c.act(in_level); p.in_t = li.t; p.in_h = li.h; p.in_w = li.w; p.in_ns = li.plane * li.t; p.ic0 = ic0; p.cin = cin;
+    p.wgt = c.w16(cv); p.bias = c.params + cv.b;
+    p.out = c.act(out_level); p.out_t = lo.t; p.out_ns = lo.plane * lo.t; p.oc0 = oc0; p.cout = cv.cout;
+    p.out_sums = c.training ? c.sums(out_level) + 2 * oc0 : nullptr;
+}
+
+void fill_bn(const Ctx16& c, Conv16Params& p, const Bn16& b, int level, int ic0) {
+    const auto& lv = c.net->lv[level];
+    p.use_stats = 1;
+    p.in_sums = c.sums(level) + 2 * ic0;
+    p.gamma = c.params + b.g; p.beta = c.params + b.b;
+    p.running_mean = c.bn_running + b.run_mean; p.running_var = c.bn_running + b.run_var;
+    p.saved = c.saved(b);
+    p.count = static_cast<double>(c.net->n) * lv.plane;
+    p.eps = 1.0e-5f; p.momentum = 0.1f; p.training = c.training;
+}
+
+// dense layer: BN -> ReLU -> conv3x3 -> +12 channels (models.py:19-28, 44-52)
+int dense16(const Ctx16& c, int level, int ic0, int oc0, const Bn16& b, const Conv16& cv) {
+    Conv16Params p{};
+    fill_io(c, p, level, ic0, cv.cin, level, oc0, cv);
+    p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
+    fill_bn(c, p, b, level, ic0);
+    return launch_bf16_conv<3, 1>(p, c.stream);
+}
+
+// transition down: BN -> ReLU -> conv1x1 -> maxpool2 into the next level (models.py:56-67)
+int td16(const Ctx16& c, int level, const Bn16& b, const Conv16& cv) {
+    const int next = level + 1;
+    Conv16Params p{};
+    fill_io(c, p, level, 48, cv.cin, next, next < k16Levels ? 48 : 0, cv);
+    p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
+    fill_bn(c, p, b, level, 48);
+    p.out_idx = reinterpret_cast<uint8_t*>(c.tape + c.net->idx_off[level]);
+    return launch_bf16_conv<1, 3, 1>(p, c.stream);
+}
+
+// transition up: nearest x2 -> conv3x3 48 -> 48 into channels [0, 48) of the finer level (models.py:70-80)
+int tu16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16& cv) {
+    Conv16Params p{};
+    fill_io(c, p, src_level, src_c0, cv.cin, level, 0, cv);
+    p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
+    p.ups = 1;
+    return launch_bf16_conv<3, 3>(p, c.stream);
+}
+
+}  // namespace
+
+// x: fp32 [n][3][H][W] (already multiplied by the boundary, train.py:272-273; rounded to bf16 on the way in); out: fp32 [n][1][H][W] >= 0.
+// training != 0: batch statistics + running-statistics update (momentum 0.1, eps 1e-5); 0: running statistics.  tape:
+// endo_net16_tape_bytes() bytes, 256-byte aligned.  H, W multiples of 32.
+extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape_, int training,
+                              void* stream_) {
+    if (!net || !params || !bn_running || !x || !out || !tape_) return ENDO_E_BADARG;
+    const Table16& tb = table16();
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Ctx16 c{net, params, bn_running, static_cast<char*>(tape_), training, stream};
+    ENDO_CHECK(hipMemsetAsync(c.tape + net->sums_off, 0, net->sums_bytes, stream));
+    {   // weights of all 56 MFMA convolutions -> bf16
+        W16Table t{};
+        t.layers = static_cast<int>(tb.convs.size());
+        if (t.layers > 63) return ENDO_E_BADARG;
+        int64_t start = 0;
+        for (int l = 0; l < t.layers; ++l) {
+            const Conv16& cv = *tb.convs[l];
+            const int cin_k = cv.cin < 4 ? 4 : cv.cin;
+            const int64_t groups = (cv.cout + cv.nt * 16 - 1) / (cv.nt * 16), chunks = (cin_k + kBfKC - 1) / kBfKC;
+            t.start[l] = start; t.w[l] = cv.w; t.out[l] = cv.w16; t.cout[l] = cv.cout; t.cin[l] = cv.cin; t.cin_k[l] = cin_k; t.ks[l] = cv.ks; t.nt[l] = cv.nt;
+            start += chunks * groups * cv.ks * cv.ks * cv.nt * 16 * 32;
+        }
+        t.start[t.layers] = start;
+        bf16_all_weights_kernel<<<1024, 256, 0, stream>>>(t, params, reinterpret_cast<uint16_t*>(c.tape + net->w16_off));
+        ENDO_LAUNCH_CHECK();
+    }
+    int rc;
+    {   // first conv 3 -> 48 into level-0 channels [48, 96)
+        uint16_t* xin = reinterpret_cast<uint16_t*>(c.tape + net->in_off);
+        bf16_pack_input_kernel<<<dim3(256, net->n), 256, 0, stream>>>(x, xin, static_cast<int>(net->lv[0].plane));
+        ENDO_LAUNCH_CHECK();
+        Conv16Params p{};
+        p.n = net->n; p.h = net->h; p.w = net->w;
+        p.in = xin; p.in_t = 8; p.in_h = net->h; p.in_w = net->w; p.in_ns = net->lv[0].plane * 8; p.ic0 = 0; p.cin = 4;
+        p.wgt = c.w16(tb.first); p.bias = params + tb.first.b;
+        p.out = c.act(0); p.out_t = net->lv[0].t; p.out_ns = net->lv[0].plane * net->lv[0].t; p.oc0 = 48; p.cout = k16First;
+        p.out_sums = training ? c.sums(0) + 2 * 48 : nullptr;
+        rc = launch_bf16_conv<3, 3>(p, stream);
+        if (rc) return rc;
+    }
+    for (int l = 0; l < k16Levels; ++l) {
+        for (int j = 0; j < k16Layers; ++j) {
+            rc = dense16(c, l, 48, 48 + c16_down_in(l) + k16Growth * j, tb.down_bn[l][j], tb.down_conv[l][j]);
+            if (rc) return rc;
+        }
+        rc = td16(c, l, tb.td_bn[l], tb.td_conv[l]);
+        if (rc) return rc;
+    }
+    for (int j = 0; j < k16Layers; ++j) {
+        rc = dense16(c, k16Levels, 0, 288 + k16Growth * j, tb.bott_bn[j], tb.bott_conv[j]);
+        if (rc) return rc;
+    }
+    for (int i = 0; i < k16Levels; ++i) {
+        const int l = k16Levels - 1 - i, src = l + 1;
+        const int src_c0 = (i == 0) ? 288 : 96 + c16_down_in(src);
+        rc = tu16(c, l, src, src_c0, tb.tu_conv[i]);
+        if (rc) return rc;
+        for (int j = 0; j < k16Layers; ++j) {
+            rc = dense16(c, l, 0, 96 + c16_down_in(l) + k16Growth * j, tb.up_bn[i][j], tb.up_conv[i][j]);
+            if (rc) return rc;
+        }
+    }
+    {
+        const auto& lv = net->lv[0];
+        int bx = static_cast<int>((lv.plane * 8 + 255) / 256);
+        bx = bx > 2048 ? 2048 : bx;
+        bf16_final_fwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(c.act(0), lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w,
+                                                                     params + tb.final_.b, reinterpret_cast<float*>(c.tape + net->pre_off), out);
+        ENDO_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -268,7 +268,9 @@ class FCDenseNet(nn.Module):
         old = options.get(option_id, self._OPTION_DEFAULTS[option_id])
         options[option_id] = value
         lib = _lib.load()
-        for hnd, _, _ in self._handles.values():
+        for key, (hnd, _, _) in self._handles.items():
+            if key[0] == "bf16":
+                continue
             rc = lib.endo_net_set_option(hnd, option_id, value)
             if rc < 0:
                 raise RuntimeError("endo_net_set_option(%d, %d) failed: %d" % (option_id, value, rc))
@@ -280,8 +282,8 @@ class FCDenseNet(nn.Module):
     def __del__(self):
         try:
             lib = _lib.load()
-            for hnd, _, _ in self._handles.values():
-                lib.endo_net_destroy(hnd)
+            for key, (hnd, _, _) in self._handles.items():
+                (lib.endo_net16_destroy if key[0] == "bf16" else lib.endo_net_destroy)(hnd)
             self._handles = {}
         except Exception:
             pass
@@ -353,6 +355,37 @@ class FCDenseNet(nn.Module):
         if torch.is_grad_enabled():
             return _NetFunction.apply(x, self._anchor, self)
         out, _ = self._run_forward(x)
+        return out
+
+    def forward_bf16_storage(self, x):
+        """The forward pass over bf16 level buffers (``endo_net16_fwd``: channels-last bf16 activations, bf16 matrix cores with
+        fp32 accumulation, fp32 BatchNorm statistics and output; the first bricks of the bf16-storage family of BASELINE configs[2],
+        DESIGN.md 7).  Same parameters, same running-statistics semantics (``.train()``: batch statistics and an update; ``.eval()``:
+        running statistics, the evaluate.py path) -- a different function numerically (every activation is rounded to 8 significant
+        bits), with its own tolerance (tests/test_gpu_bf16.py).  No gradient: the backward pass over this layout is not built yet, so
+        this is an inference / no-grad forward; H and W must be multiples of 32."""
+        lib = _lib.load()
+        x = _lib.dev_f32(x, "FCDenseNet57 input")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise RuntimeError("expected N x 3 x H x W input")
+        if x.device != self._flat.device:
+            raise RuntimeError("model and input are on different devices; call model.cuda() first")
+        if not self._views_intact():
+            self._flatten()
+        n, _, h, w = x.shape
+        key = ("bf16", n, h, w)
+        if key not in self._handles:
+            hnd = ctypes.c_void_p()
+            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w), "endo_net16_create(%d,%d,%d)" % (n, h, w))
+            self._handles[key] = (hnd, int(lib.endo_net16_tape_bytes(hnd)), 0)
+        hnd, tape_bytes, _ = self._handles[key]
+        tape = torch.empty(tape_bytes, dtype=torch.uint8, device=x.device)
+        out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
+        with torch.no_grad():
+            _lib.check(lib.endo_net16_fwd(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out), _lib.ptr(tape),
+                                          1 if self.training else 0, _lib.stream()), "endo_net16_fwd")
+        if self.training:
+            self._nbt.add_(1)
         return out
 
     def forward_pair(self, x1, x2):

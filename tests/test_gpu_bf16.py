@@ -1,0 +1,211 @@
+"""bf16-storage family, first bricks (include/endo_hip.h endo_bf16_*): the channels-last bf16 convolution against the
+reference arithmetic evaluated in fp64 on the SAME bf16-rounded inputs and weights (reference models.py:19-28 DenseLayer = BN -> ReLU
+-> conv3x3 + bias; models.py:70-80 TransitionUp = nearest x2 -> conv3x3; models.py:56-67 TransitionDown's 1x1 convolution).  The
+kernel accumulates in fp32 and rounds its output to bf16 once, so the bound is bf16's half ulp of the output (2^-9 relative) plus fp32
+accumulation noise: 6e-3 of the output's maximum."""
+
+import ctypes
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=False):
+    """x: [n][C][in_h][in_w] fp32 planar (all in_t channels); returns (out planar fp32 of the cout channels, sums or None)."""
+    lib = ea._lib.load()
+    n = x.shape[0]
+    in_h, in_w = x.shape[2], x.shape[3]
+    cout = weight.shape[0]
+    xin = torch.zeros((n, in_h, in_w, in_t), dtype=torch.bfloat16, device=dev())
+    assert lib.endo_bf16_pack_nhwc(x.to(dev()).contiguous().data_ptr(), xin.data_ptr(), n, in_t, in_h, in_w, in_t, 0, None) == 0
+    wl = torch.empty(int(lib.endo_bf16_conv_weight_elems(cout, cin, ks)), dtype=torch.bfloat16, device=dev())
+    assert lib.endo_bf16_conv_weights(weight.to(dev()).contiguous().data_ptr(), cout, cin, ks, wl.data_ptr(), None) == 0
+    out = torch.full((n, h, w, out_t), float("nan"), dtype=torch.bfloat16, device=dev())
+    s = torch.zeros((cout, 2), dtype=torch.float64, device=dev()) if sums else None
+    b = bias.to(dev()) if bias is not None else None
+    bnd = bn.to(dev()).contiguous() if bn is not None else None
+    rc = lib.endo_bf16_conv(xin.data_ptr(), in_t, ic0, cin, bnd.data_ptr() if bnd is not None else None, wl.data_ptr(),
+                            b.data_ptr() if b is not None else None, out.data_ptr(), out_t, oc0, cout,
+                            s.data_ptr() if s is not None else None, n, h, w, ks, ups, None)
+    assert rc == 0, rc
+    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev())
+    assert lib.endo_bf16_unpack_nhwc(out.data_ptr(), y.data_ptr(), n, cout, h, w, out_t, oc0, None) == 0
+    torch.cuda.synchronize()
+    # nothing outside the slice was written
+    untouched = torch.ones(out_t, dtype=torch.bool)
+    untouched[oc0:oc0 + cout] = False
+    assert torch.isnan(out.float()[..., untouched.to(dev())]).all()
+    return y.cpu(), (s.cpu() if s is not None else None)
+
+
+def reference(x, ic0, cin, weight, bias, bn, ks, ups):
+    import torch.nn.functional as F
+    a = bf16_round(x[:, ic0:ic0 + cin]).double()
+    if bn is not None:
+        a = torch.clamp_min(a * bn[:, 0].double().view(1, -1, 1, 1) + bn[:, 1].double().view(1, -1, 1, 1), 0.0)
+        a = bf16_round(a.float()).double()          # the staged activations are bf16
+    if ups:
+        a = F.interpolate(a, scale_factor=2, mode="nearest")
+    return F.conv2d(a, bf16_round(weight).double(), bias.double() if bias is not None else None, padding=ks // 2)
+
+
+CASES = [
+    # n, h, w, in_t, ic0, cin, cout, out_t, oc0, ks, ups, bn
+    (2, 32, 64, 192, 48, 60, 12, 192, 108, 3, 0, True),          # a dense layer: cin not a multiple of 8 (60 = 7.5 units), outputs at 108
+    (1, 37, 53, 96, 0, 48, 12, 96, 48, 3, 0, True),              # sizes that are not multiples of the tile
+    (2, 16, 20, 384, 48, 288, 12, 384, 336, 3, 0, True),         # a coarse level, 9 K-chunks
+    (2, 32, 64, 96, 48, 48, 48, 192, 0, 3, 1, False),            # transition up: nearest x2 + conv 48 -> 48, raw input
+    (1, 24, 40, 144, 48, 96, 96, 96, 0, 1, 0, True),             # 1 x 1, 96 -> 96 (two cout groups of 48)
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_cin%d_cout%d_ks%d%s" % (c[0], c[1], c[2], c[5], c[6], c[9], "_ups" if c[10] else ""))
+def test_bf16_conv_against_fp64(case):
+    n, h, w, in_t, ic0, cin, cout, out_t, oc0, ks, ups, use_bn = case
+    rng = np.random.default_rng(7)
+    in_h, in_w = (h // 2, w // 2) if ups else (h, w)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, in_t, in_h, in_w)).astype(np.float32))
+    weight = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
+    bias = torch.from_numpy(rng.uniform(-0.1, 0.1, cout).astype(np.float32))
+    bn = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, cin) * rng.choice([-1, 1], cin), rng.uniform(-0.3, 0.3, cin)], axis=1).astype(np.float32)) if use_bn else None
+    y, s = run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=True)
+    ref = reference(x, ic0, cin, weight, bias, bn, ks, ups)
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    print("bf16 conv %s: max err / max |ref| = %.2e" % (case, err))
+    assert err <= 6e-3
+    # statistics of the stored values
+    want = torch.stack([y.double().sum(dim=(0, 2, 3)), (y.double() ** 2).sum(dim=(0, 2, 3))], dim=1)
+    assert float((s - want).abs().max() / want.abs().max()) <= 1e-5
+
+
+def test_bf16_conv_dense_layer_timing():
+    """Not a pass / fail performance gate: prints the time of the widest dense layer of the network (level 0, Cin = 180 -> 12, 16
+    samples of 256 x 320) in the bf16-storage brick next to the fp32 Winograd kernel's 470 us (profiles/r03_j_kernel_stats_by_grid.txt),
+    and checks the result against fp64 on a sub-block."""
+    lib = ea._lib.load()
+    n, h, w, t, ic0, cin, cout, oc0 = 16, 256, 320, 192, 0, 180, 12, 180
+    g = torch.Generator(device=dev()).manual_seed(3)
+    xin = (torch.rand((n, h, w, t), device=dev(), generator=g) * 2 - 1).to(torch.bfloat16)
+    weight = torch.randn((cout, cin, 3, 3), device=dev(), generator=g) * (2.0 / (cin * 9)) ** 0.5
+    bn = torch.stack([torch.rand(cin, device=dev(), generator=g) + 0.5, torch.rand(cin, device=dev(), generator=g) * 0.2 - 0.1], dim=1).contiguous()
+    bias = torch.zeros(cout, device=dev())
+    wl = torch.empty(int(lib.endo_bf16_conv_weight_elems(cout, cin, 3)), dtype=torch.bfloat16, device=dev())
+    assert lib.endo_bf16_conv_weights(weight.data_ptr(), cout, cin, 3, wl.data_ptr(), None) == 0
+    sums = torch.zeros((cout, 2), dtype=torch.float64, device=dev())
+
+    def run():
+        return lib.endo_bf16_conv(xin.data_ptr(), t, ic0, cin, bn.data_ptr(), wl.data_ptr(), bias.data_ptr(), xin.data_ptr(), t, oc0, cout,
+                                  sums.data_ptr(), n, h, w, 3, 0, None)
+    for _ in range(3):
+        assert run() == 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    gb = n * h * w * (cin + cout) * 2 / 1e9
+    print("bf16-storage dense layer, level 0, Cin 180 -> 12, 16 x 256 x 320: %.1f us = %.2f TB/s of algorithmic bytes, %.1f TFLOP/s" % (
+        us, gb / us * 1e3 / 1e3 * 1e3 / 1e3, 2.0 * n * h * w * cin * cout * 9 / us / 1e6))
+    # correctness on the first sample's top-left block
+    y = torch.empty((1, cout, h, w), dtype=torch.float32, device=dev())
+    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), y.data_ptr(), 1, cout, h, w, t, oc0, None) == 0
+    x0 = xin[0, :40, :40, :cin].float().permute(2, 0, 1).unsqueeze(0).cpu()
+    ref = reference(x0, 0, cin, weight.cpu(), bias.cpu(), bn.cpu(), 3, 0)[0, :, :32, :32]
+    err = float((y[0, :, :32, :32].cpu().double() - ref).abs().max() / ref.abs().max())
+    assert err <= 6e-3, err
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole forward pass over bf16 level buffers
+# ---------------------------------------------------------------------------------------------
+BF16_STORAGE_FWD_TOL = 5e-2          # depth against the fp64 oracle, max error / max depth; measured values are printed by the test
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 128, 160), (2, 256, 320)])
+def test_bf16_storage_forward(shape):
+    """FCDenseNet57.forward_bf16_storage (endo_net16_fwd; reference models.py:171-187) against the fp64 oracle and against the fp32
+    HIP path on the same parameters and input: training mode (batch statistics; the running statistics after the call against the
+    fp32 path's) and eval mode (running statistics).  A different function from the fp32 path -- activations carry 8 significant
+    bits through 57 convolutions -- with its own stated tolerance."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w = shape
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(23)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    models = []
+    for _ in range(2):
+        m = ea.FCDenseNet57(1)
+        m.load_state_dict(state)
+        models.append(m.to(dev()))
+    ref32, bf = models
+    for mode in ("train", "eval"):
+        getattr(ref32, mode)(); getattr(bf, mode)()
+        with torch.no_grad():
+            y32 = ref32(x.to(dev()))
+            y16 = bf.forward_bf16_storage(x.to(dev()))
+        torch.cuda.synchronize()
+        st64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
+        if mode == "eval":          # the oracle's running statistics after one training-mode call, as both models have them now
+            for k, v in ref32.state_dict().items():
+                if "running" in k:
+                    st64[k] = v.double().cpu()
+        y64 = onet.forward(st64, x.double(), training=(mode == "train"))
+        e16 = float((y16.double().cpu() - y64).abs().max() / y64.abs().max())
+        e32 = float((y32.double().cpu() - y64).abs().max() / y64.abs().max())
+        rel_l2 = float((y16.double().cpu() - y64).norm() / y64.norm())
+        print("bf16-storage forward %s %s: max err / max depth %.2e (fp32 path %.1e), relative L2 %.2e" % (shape, mode, e16, e32, rel_l2))
+        assert torch.isfinite(y16).all()
+        assert e16 <= BF16_STORAGE_FWD_TOL, (mode, e16)
+        assert rel_l2 <= 2e-2, (mode, rel_l2)
+        if mode == "train":
+            sd32, sd16 = ref32.state_dict(), bf.state_dict()
+            worst = 0.0
+            for k in sd32:
+                if "running" in k:
+                    worst = max(worst, float((sd16[k] - sd32[k]).abs().max() / (sd32[k].abs().max() + 1e-6)))
+                elif "num_batches" in k:
+                    assert int(sd16[k]) == int(sd32[k]) == 1
+            print("   running statistics, bf16-storage vs fp32 path: worst relative difference %.2e" % worst)
+            assert worst <= 5e-2
+
+
+def test_bf16_storage_forward_timing():
+    """Prints (no gate) the forward time of the benchmark batch -- 16 frames of 256 x 320, one call -- over bf16 level buffers next to
+    the fp32 path's grouped pair forward (5.9 ms of a training step, profiles/r03_i_stream_timeline.txt)."""
+    n, h, w = 16, 256, 320
+    m = ea.FCDenseNet57(1)
+    ea.utils.kaiming_weight_zero_bias(m, mode="fan_in", activation_mode="relu", distribution="normal")
+    m = m.to(dev()).train()
+    x = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
+    res = {}
+    for name, fn in (("bf16 storage", lambda: m.forward_bf16_storage(x)), ("fp32", lambda: m.forward_pair(x[:8], x[8:]))):
+        with torch.no_grad():
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 10
+    print("forward of 16 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (res["bf16 storage"], res["fp32"]))
