@@ -41,11 +41,11 @@ SIGNATURES = {
     "endo_warp_consistency_workspace_floats": (_L, [_I, _I, _I]),
     "endo_warp_consistency": (_I, [_P] * 8 + [_F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
     "endo_warp_fallback_blocks": (_I, [_P, _P, _I]),
-    "endo_bf16_pack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "endo_bf16_unpack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "endo_bf16_pack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "endo_bf16_unpack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "endo_bf16_conv_weight_elems": (_L, [_I, _I, _I]),
     "endo_bf16_conv_weights": (_I, [_P, _I, _I, _I, _P, _P]),
-    "endo_bf16_conv": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "endo_bf16_conv": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "endo_net16_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
     "endo_net16_destroy": (None, [_P]),
     "endo_net16_tape_bytes": (_L, [_P]),

@@ -8,9 +8,14 @@
 // of a pixel are contiguous): a lane's 8 k are one 16-byte read, a dense layer reads one contiguous run of Cin channels per pixel
 // and appends its 12 outputs as 24 contiguous bytes.
 //
+// Channel blocks.  A buffer is [n][t / blk][h][w][blk]: blk = t is plain NHWC; the level buffers use blk = 32 (64-byte records, one
+// K-chunk of one pixel, neighbouring pixels adjacent): with NHWC a K-chunk touches 64 bytes of every 384-byte pixel record, the other
+// half of each 128-byte line is fetched again by the next chunk after the L2 has dropped it -- measured 2.1x the algorithmic bytes
+// at level 0 (profiles/r03_p_bf16_conv_layout.txt); blocked, a chunk of a tile row is one contiguous run.
+//
 // MFMA roles (v_mfma_f32_16x16x32_bf16, fp32 accumulation): A[i = cout][k = channel] = weights, B[k = channel][j = pixel] =
 // activations, D[i = cout][j = pixel]: a lane ends up with 4 consecutive output channels of ONE pixel -- an 8-byte NHWC store.
-// A block owns a 16 x 32 pixel tile (4 waves x 4 rows); per K-chunk of 32 input channels the haloed tile (18 x 34 pixels x 64 B)
+// A block owns a 16 x 32 pixel tile (WAVES waves x 16 / WAVES rows); per K-chunk of 32 input channels the haloed tile (18 x 34 pixels x 64 B)
 // is staged through registers into LDS with BatchNorm + ReLU applied ONCE per element on the way (the fp32 kernels apply it on
 // every fragment read; here each staged element is read for 9 taps) and out-of-image pixels written as the zeros of the padded
 // post-activation tensor (reference models.py:22-25 pads relu(bn(x))).  16-byte slots are XOR-swizzled by (x >> 1) & 3 so that the
@@ -31,13 +36,14 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
 constexpr int kBfTileX = 32, kBfTileY = 16;          // output pixels per block
 constexpr int kBfKC = 32;                            // input channels per K-chunk (one MFMA k extent)
-constexpr int kBfThreads = 256;
+
 
 struct Conv16Params {
     int n, h, w;                     // output grid
     const uint16_t* in;              // bf16 NHWC input level buffer
     int64_t in_ns;                   // elements between samples
-    int in_t;                        // channels per input pixel record
+    int in_t;                        // channels of the input buffer
+    int in_blk;                      // channels per block of the input buffer (0 = in_t: plain channels-last); see the layout note above
     int in_h, in_w;                  // input grid (== h, w unless `ups`)
     int ic0, cin;                    // the layer reads channels [ic0, ic0 + cin)
     const float* bn;                 // [cin][2] = (scale, shift): z = max(x * scale + shift, 0); null = raw input (unless in_sums)
@@ -55,11 +61,15 @@ struct Conv16Params {
     float eps, momentum;
     int training;
     int use_stats;                   // 1: the block above applies (bn is ignored)
+    // BatchNorm parameter (gamma, beta, running, saved) of the layer's input channel c < rot_n is (c + rot) % rot_n: the up path keeps
+    // [skip | transition-up output] in the buffer where the reference concatenates [transition-up output, skip] (models.py:183)
+    int rot, rot_n;
     const uint16_t* wgt;             // [chunk][tap][nt][16 cout][32 k] bf16, k >= cin and cout >= `cout` zero
     const float* bias;               // [cout] or null
     uint16_t* out;                   // bf16 NHWC output level buffer
     int64_t out_ns;
     int out_t;
+    int out_blk;                     // channels per block of the output buffer (0 = out_t)
     int oc0, cout;
     double* out_sums;                // [cout][2] sum, sum^2 of the STORED (bf16-rounded) values, or null
     int ups;                         // 1: nearest x2 upsampling of the input on the way in (transition up, models.py:73)
@@ -82,39 +92,47 @@ template <int COLS>
 __device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row * COLS + x) * 4 + (part ^ ((x >> 1) & 3))) * 16; }
 
 // KS = 3 (pad 1) or 1; NT = 16-cout tiles per block (grid.y covers ceil(cout / (16 NT)) of them); POOL = 1: 2 x 2 max-pool epilogue
-template <int KS, int NT, int POOL = 0>
-__global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Params p) {
+// WAVES = waves per block (4 or 8): the 16 tile rows are dealt R = 16 / WAVES to a wave; 8 waves halve the registers a thread needs
+// for its share of the staged loads.  WPE = waves per SIMD the register allocation must leave room for.
+//
+// One tile per block.  A persistent version (a few blocks per CU walking the tiles with one continuous (tile, chunk) pipeline, XCD-banded
+// tile order, statistics flushed once per block) was built and measured: no faster at equal occupancy and 60 registers over the
+// 128-register budget of two 8-wave blocks per CU (profiles/r03_o_bf16_conv_variants.txt); not kept.
+// EXP: diagnostic masks of tools/bf16_conv_variants (1 = no matrix phase, 2 = no activation loads, 4 = no BatchNorm arithmetic and LDS stage writes); 0 in the product
+template <int KS, int NT, int POOL = 0, int WAVES = 8, int WPE = 4, int EXP = 0>
+__global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE))) bf16_conv_kernel(const Conv16Params p) {
+    constexpr int kThreads = 64 * WAVES;
+    constexpr int R = kBfTileY / WAVES;
     constexpr int kHalo = KS / 2;
     constexpr int kRows = kBfTileY + 2 * kHalo, kCols = kBfTileX + 2 * kHalo;
     constexpr int kPix = kRows * kCols;
     constexpr int kUnits = kPix * 4;                                   // 16-byte units of a chunk
-    constexpr int kIter = (kUnits + kBfThreads - 1) / kBfThreads;
+    constexpr int kIter = (kUnits + kThreads - 1) / kThreads;
     constexpr int kTaps = KS * KS;
     constexpr int kWUnits = kTaps * NT * 16 * 4;                       // 16-byte units of a chunk's weight slice
-    constexpr int kWIter = (kWUnits + kBfThreads - 1) / kBfThreads;
+    constexpr int kWIter = (kWUnits + kThreads - 1) / kThreads;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     unsigned char* s_act = smem16;                                     // [kRows][kCols][4 slots][16 B]
     unsigned char* s_w = s_act + kPix * 64;                            // [tap][nt][16 cout][4 slots][16 B]
     float* s_bn = reinterpret_cast<float*>(s_w + kWUnits * 16);        // [cin padded to 32][2]
-    float* s_red = s_bn;                                               // reused after the K loop: [4 waves][NT * 16][2]
+    float* s_red = s_bn;                                               // reused after the K loop: [WAVES][NT * 16][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
-    const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX;
-    const int tile = blockIdx.x;
-    const int x0 = (tile % tiles_x) * kBfTileX, y0 = (tile / tiles_x) * kBfTileY;
-    const int n = blockIdx.z;
+    const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX, tiles_y = (p.h + kBfTileY - 1) / kBfTileY;
+    const int tiles_img = tiles_x * tiles_y;
     const int co_base = blockIdx.y * NT * 16;
     const int nchunks = (p.cin + kBfKC - 1) / kBfKC;
-    const uint16_t* in_n = p.in + n * p.in_ns + p.ic0;
+    const int in_plane = p.in_h * p.in_w;
 
     const bool has_bn = p.bn != nullptr || p.use_stats != 0;
     const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
-    for (int c = tid; c < nchunks * kBfKC; c += kBfThreads) {
+    for (int c = tid; c < nchunks * kBfKC; c += kThreads) {
         float sc = 0.f, sh = 0.f;
         if (c < p.cin) {
+            const int pc = c < p.rot_n ? (c + p.rot < p.rot_n ? c + p.rot : c + p.rot - p.rot_n) : c;
             if (p.use_stats) {
                 double mean, var;
                 if (p.training) {
@@ -122,58 +140,69 @@ __global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Param
                     var = p.in_sums[2 * c + 1] / p.count - mean * mean;
                     if (var < 0.0) var = 0.0;
                 } else {
-                    mean = p.running_mean[c];
-                    var = p.running_var[c];
+                    mean = p.running_mean[pc];
+                    var = p.running_var[pc];
                 }
                 const float rstd = static_cast<float>(1.0 / sqrt(var + static_cast<double>(p.eps)));
                 const float mean_f = static_cast<float>(mean);
-                sc = p.gamma[c] * rstd;
-                sh = fmaf(-mean_f, sc, p.beta[c]);
+                sc = p.gamma[pc] * rstd;
+                sh = fmaf(-mean_f, sc, p.beta[pc]);
                 if (first_block) {
-                    if (p.saved) { p.saved[2 * c] = mean_f; p.saved[2 * c + 1] = rstd; }
+                    if (p.saved) { p.saved[2 * pc] = mean_f; p.saved[2 * pc + 1] = rstd; }
                     if (p.training) {
                         const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                        p.running_mean[c] = (1.0f - p.momentum) * p.running_mean[c] + p.momentum * mean_f;
-                        p.running_var[c] = (1.0f - p.momentum) * p.running_var[c] + p.momentum * static_cast<float>(unbiased);
+                        p.running_mean[pc] = (1.0f - p.momentum) * p.running_mean[pc] + p.momentum * mean_f;
+                        p.running_var[pc] = (1.0f - p.momentum) * p.running_var[pc] + p.momentum * static_cast<float>(unbiased);
                     }
                 }
             } else {
-                sc = p.bn ? p.bn[2 * c] : 1.f; sh = p.bn ? p.bn[2 * c + 1] : 0.f;
+                sc = p.bn ? p.bn[2 * pc] : 1.f; sh = p.bn ? p.bn[2 * pc + 1] : 0.f;
             }
         }
         s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
     }
 
-    // this thread's units of a chunk: tile pixel, channel part, source address (the same every chunk, channels advance)
-    int u_src[kIter];            // element offset of the unit's pixel in the input sample, -1 = outside the image / no unit
-    int u_dst[kIter];            // byte offset in s_act
+    // this thread's units of a chunk: the LDS slot (the same for every tile and chunk, -1 = no unit) and, per tile, the element offset
+    // of the unit's pixel record inside its channel block (-1 = outside the image / no unit); the channel part is tid & 3 for all of
+    // them (the thread count is a multiple of 4)
+    int u_dst[kIter];
+    int u_off[kIter];
 #pragma unroll
     for (int i = 0; i < kIter; ++i) {
-        const int u = tid + i * kBfThreads;
-        u_src[i] = -1; u_dst[i] = -1;
+        const int u = tid + i * kThreads;
+        u_dst[i] = -1;
         if (u < kUnits) {
             const int px = u >> 2, part = u & 3;
             const int ry = px / kCols, rx = px - ry * kCols;
-            const int gy = y0 - kHalo + ry, gx = x0 - kHalo + rx;
             u_dst[i] = bf_slot<kCols>(ry, rx, part);
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
-                const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
-                u_src[i] = (sy * p.in_w + sx) * p.in_t + part * 8;
-            }
         }
     }
+    auto tile_offsets = [&](int y0, int x0, int (&off)[kIter]) {
+#pragma unroll
+        for (int i = 0; i < kIter; ++i) {
+            const int px = (tid + i * kThreads) >> 2;
+            const int ry = (px * 241) >> 13 /* px / 34 for px < 612 */, rx = px - ry * kCols;
+            static_assert(kCols == 34 || kCols == 32, "tile pixel row from the unit index");
+            const int ry_ = kCols == 34 ? ry : px >> 5, rx_ = kCols == 34 ? rx : px & 31;
+            const int gy = y0 - kHalo + ry_, gx = x0 - kHalo + rx_;
+            const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+            off[i] = (u_dst[i] < 0 || gy < 0 || gy >= p.h || gx < 0 || gx >= p.w) ? -1 : (sy * p.in_w + sx) * p.in_blk;
+        }
+    };
 
     u32x4_t raw[kIter];
     u32x4_t wraw[kWIter];
-    auto issue_loads = [&](int chunk) {
+    auto issue_loads = [&](int chunk, int n, const int (&off)[kIter]) {
+        // the thread's 8 channels of this chunk: block and position inside the block
+        const int cpart = chunk * kBfKC + (tid & 3) * 8;
+        const int cb = (p.ic0 + cpart) / p.in_blk;
+        const uint16_t* base = p.in + n * p.in_ns + static_cast<int64_t>(cb) * in_plane * p.in_blk + (p.ic0 + cpart - cb * p.in_blk);
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
             raw[i] = u32x4_t{0u, 0u, 0u, 0u};
-            if (u_src[i] >= 0) {
-                // channels past the end of the record never belong to the layer (cin <= in_t - ic0), but the last unit of the last chunk may
-                // straddle cin: it is read as far as the record goes and masked below
-                const uint16_t* src = in_n + u_src[i] + chunk * kBfKC;
-                const int cpart = chunk * kBfKC + ((tid + i * kBfThreads) & 3) * 8;
+            if ((EXP & 2) == 0 && off[i] >= 0) {
+                // the last unit of the last chunk may straddle cin: it is read as far as the layer goes and the rest stays zero
+                const uint16_t* src = base + off[i];
                 if (cpart + 8 <= p.cin) raw[i] = *reinterpret_cast<const u32x4_t*>(src);
                 else if (cpart < p.cin) {          // cin is a multiple of 4: the unit holds 4 valid channels
                     const u32x2_t half = *reinterpret_cast<const u32x2_t*>(src);
@@ -184,33 +213,41 @@ __global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Param
         const uint16_t* wsrc = p.wgt + (static_cast<int64_t>(chunk) * gridDim.y + blockIdx.y) * (kWUnits * 8);
 #pragma unroll
         for (int i = 0; i < kWIter; ++i) {
-            const int u = tid + i * kBfThreads;
+            const int u = tid + i * kThreads;
             wraw[i] = u < kWUnits ? *reinterpret_cast<const u32x4_t*>(wsrc + u * 8) : u32x4_t{0u, 0u, 0u, 0u};
         }
     };
     auto write_stage = [&](int chunk) {
+        float sc[8], sh[8];
+        if (has_bn) {
+            const float* cst = s_bn + 2 * (chunk * kBfKC + (tid & 3) * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4_t q = *reinterpret_cast<const f32x4_t*>(cst + 4 * k);
+                sc[2 * k] = q[0]; sh[2 * k] = q[1]; sc[2 * k + 1] = q[2]; sh[2 * k + 1] = q[3];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
-            if (u_dst[i] < 0) continue;
+            if (u_dst[i] < 0 || (EXP & 4) != 0) continue;
             u32x4_t v = raw[i];
             if (has_bn) {
-                const int c0 = chunk * kBfKC + ((tid + i * kBfThreads) & 3) * 8;
-                const bool inside = u_src[i] >= 0;
+                if (u_off[i] >= 0) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float2 a = *reinterpret_cast<const float2*>(s_bn + 2 * (c0 + 2 * k));
-                    const float2 b = *reinterpret_cast<const float2*>(s_bn + 2 * (c0 + 2 * k + 1));
-                    float z0 = fmaxf(fmaf(bf16_lo(v[k]), a.x, a.y), 0.f);
-                    float z1 = fmaxf(fmaf(bf16_hi(v[k]), b.x, b.y), 0.f);
-                    if (!inside) { z0 = 0.f; z1 = 0.f; }          // the zero padding of the post-activation tensor
-                    v[k] = pack_bf16x2(z0, z1);
+                    for (int k = 0; k < 4; ++k) {
+                        const float z0 = fmaxf(fmaf(bf16_lo(v[k]), sc[2 * k], sh[2 * k]), 0.f);
+                        const float z1 = fmaxf(fmaf(bf16_hi(v[k]), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        v[k] = pack_bf16x2(z0, z1);
+                    }
+                } else {
+                    v = u32x4_t{0u, 0u, 0u, 0u};          // the zero padding of the post-activation tensor
                 }
             }
             *reinterpret_cast<u32x4_t*>(s_act + u_dst[i]) = v;
         }
 #pragma unroll
         for (int i = 0; i < kWIter; ++i) {
-            const int u = tid + i * kBfThreads;
+            const int u = tid + i * kThreads;
             if (u < kWUnits) {
                 // global order [tap][nt][cout 16][part 4]; LDS slot swizzled by the cout like the activation tile by x
                 const int part = u & 3, co = (u >> 2) & 15, rest = u >> 6;
@@ -219,112 +256,126 @@ __global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Param
         }
     };
 
-    f32x4_t acc[4][2][NT];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[r][hh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    __syncthreads();          // s_bn
-    issue_loads(0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        write_stage(chunk);
-        __syncthreads();
-        if (chunk + 1 < nchunks) issue_loads(chunk + 1);
-        // ---- this wave's 4 output rows x 32 pixels: LDS row lr (tile row 4 wave + lr) feeds output rows lr - ky ----
-#pragma unroll
-        for (int lr = 0; lr < 4 + 2 * kHalo; ++lr) {
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int kx = 0; kx < KS; ++kx) {
-                    const int lx = 16 * hh + li + kx;
-                    const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(s_act + bf_slot<kCols>(4 * wave + lr, lx, lk));
-#pragma unroll
-                    for (int ky = 0; ky < KS; ++ky) {
-                        const int r = lr - ky;
-                        if (r < 0 || r >= 4) continue;
-#pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            const int wrow = (ky * KS + kx) * NT + t;
-                            const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s_w + ((wrow * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
-                            acc[r][hh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r][hh][t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: + bias, round to bf16, 8-byte NHWC stores (4 consecutive couts of one pixel per lane), statistics of the stored values ----
+    f32x4_t acc[R][2][NT];
     float s1[NT][4], s2[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; }
-    uint16_t* out_n = p.out + n * p.out_ns + p.oc0;
-    if constexpr (POOL != 0) {
-        // 2 x 2 max pool of the accumulators: rows 2 rp, 2 rp + 1 of the lane, columns li (even) and li + 1 (the neighbouring lane)
-        const int hp = p.h >> 1, wp = p.w >> 1;
+    const int64_t out_plane = POOL != 0 ? static_cast<int64_t>(p.h >> 1) * (p.w >> 1) : static_cast<int64_t>(p.h) * p.w;
+
+    __syncthreads();          // s_bn
+    const int n = blockIdx.z;
+    const int y0 = (blockIdx.x / tiles_x) * kBfTileY, x0 = (blockIdx.x % tiles_x) * kBfTileX;
+    tile_offsets(y0, x0, u_off);
+    issue_loads(0, n, u_off);
+    {
 #pragma unroll
-        for (int rp = 0; rp < 2; ++rp)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int yp = (y0 >> 1) + 2 * wave + rp, xp = (x0 + 16 * hh + li) >> 1;
-                const bool pix_ok = yp < hp && xp < wp && (li & 1) == 0;
+            for (int hh = 0; hh < 2; ++hh)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int co = co_base + 16 * t + 4 * lk;
-                    float best[4];
-                    unsigned code = 0;
+                for (int t = 0; t < NT; ++t) acc[r][hh][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            write_stage(chunk);
+            __syncthreads();
+            if (chunk + 1 < nchunks) issue_loads(chunk + 1, n, u_off);
+            // ---- this wave's R output rows x 32 pixels: LDS row lr (tile row R wave + lr) feeds output rows lr - ky ----
+            if constexpr ((EXP & 1) == 0)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const float v00 = acc[2 * rp][hh][t][i], v10 = acc[2 * rp + 1][hh][t][i];
-                        const float v01 = __shfl_xor(v00, 1, 64), v11 = __shfl_xor(v10, 1, 64);
-                        float b = v00; unsigned c = 0;
-                        if (v01 > b) { b = v01; c = 1; }
-                        if (v10 > b) { b = v10; c = 2; }
-                        if (v11 > b) { b = v11; c = 3; }
-                        best[i] = b; code |= c << (8 * i);
+            for (int lr = 0; lr < R + 2 * kHalo; ++lr) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) {
+                        const int lx = 16 * hh + li + kx;
+                        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(s_act + bf_slot<kCols>(R * wave + lr, lx, lk));
+#pragma unroll
+                        for (int ky = 0; ky < KS; ++ky) {
+                            const int r = lr - ky;
+                            if (r < 0 || r >= R) continue;
+#pragma unroll
+                            for (int t = 0; t < NT; ++t) {
+                                const int wrow = (ky * KS + kx) * NT + t;
+                                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s_w + ((wrow * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
+                                acc[r][hh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r][hh][t], 0, 0, 0);
+                            }
+                        }
                     }
-                    if (co >= p.cout || !pix_ok) continue;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) best[i] += p.bias ? p.bias[co + i] : 0.f;
-                    const unsigned lo = pack_bf16x2(best[0], best[1]), hi = pack_bf16x2(best[2], best[3]);
-                    const int64_t pix = static_cast<int64_t>(yp) * wp + xp;
-                    *reinterpret_cast<u32x2_t*>(out_n + pix * p.out_t + co) = u32x2_t{lo, hi};
-                    *reinterpret_cast<unsigned*>(p.out_idx + (static_cast<int64_t>(n) * hp * wp + pix) * p.cout + co) = code;
-                    const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
                 }
             }
-    } else
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int y = y0 + 4 * wave + r, x = x0 + 16 * hh + li;
-            const bool pix_ok = y < p.h && x < p.w;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int co = co_base + 16 * t + 4 * lk;
-                if (co >= p.cout) continue;          // cout is a multiple of 4
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = acc[r][hh][t][i] + (p.bias ? p.bias[co + i] : 0.f);
-                const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
-                if (pix_ok) {
-                    *reinterpret_cast<u32x2_t*>(out_n + (static_cast<int64_t>(y) * p.w + x) * p.out_t + co) = u32x2_t{lo, hi};
-                    const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
-                }
-            }
+            __syncthreads();
         }
+
+        // ---- the tile's outputs: + bias, round to bf16, 8-byte stores (4 consecutive couts of one pixel per lane), statistics of the
+        // stored values ----
+        uint16_t* out_n = p.out + n * p.out_ns;
+        auto out_ptr = [&](int64_t pix, int co) {          // 4 consecutive channels never straddle a block (oc0, blk multiples of 4)
+            const int ca = p.oc0 + co, cb = ca / p.out_blk;
+            return out_n + (cb * out_plane + pix) * p.out_blk + (ca - cb * p.out_blk);
+        };
+        if constexpr (POOL != 0) {
+            // 2 x 2 max pool of the accumulators: rows 2 rp, 2 rp + 1 of the lane, columns li (even) and li + 1 (the neighbouring lane)
+            const int hp = p.h >> 1, wp = p.w >> 1;
+#pragma unroll
+            for (int rp = 0; rp < R / 2; ++rp)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int yp = (y0 >> 1) + (R / 2) * wave + rp, xp = (x0 + 16 * hh + li) >> 1;
+                    const bool pix_ok = yp < hp && xp < wp && (li & 1) == 0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co = co_base + 16 * t + 4 * lk;
+                        float best[4];
+                        unsigned code = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v00 = acc[2 * rp][hh][t][i], v10 = acc[2 * rp + 1][hh][t][i];
+                            const float v01 = __shfl_xor(v00, 1, 64), v11 = __shfl_xor(v10, 1, 64);
+                            float bst = v00; unsigned c = 0;
+                            if (v01 > bst) { bst = v01; c = 1; }
+                            if (v10 > bst) { bst = v10; c = 2; }
+                            if (v11 > bst) { bst = v11; c = 3; }
+                            best[i] = bst; code |= c << (8 * i);
+                        }
+                        if (co >= p.cout || !pix_ok) continue;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) best[i] += p.bias ? p.bias[co + i] : 0.f;
+                        const unsigned lo = pack_bf16x2(best[0], best[1]), hi = pack_bf16x2(best[2], best[3]);
+                        const int64_t pix = static_cast<int64_t>(yp) * wp + xp;
+                        *reinterpret_cast<u32x2_t*>(out_ptr(pix, co)) = u32x2_t{lo, hi};
+                        *reinterpret_cast<unsigned*>(p.out_idx + (static_cast<int64_t>(n) * hp * wp + pix) * p.cout + co) = code;
+                        const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int y = y0 + R * wave + r, x = x0 + 16 * hh + li;
+                    const bool pix_ok = y < p.h && x < p.w;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co = co_base + 16 * t + 4 * lk;
+                        if (co >= p.cout) continue;          // cout is a multiple of 4
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = acc[r][hh][t][i] + (p.bias ? p.bias[co + i] : 0.f);
+                        const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+                        if (pix_ok) {
+                            *reinterpret_cast<u32x2_t*>(out_ptr(static_cast<int64_t>(y) * p.w + x, co)) = u32x2_t{lo, hi};
+                            const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
+                        }
+                    }
+                }
+        }
+    }
+
     if (p.out_sums) {
         // reduce over the 16 pixels of a lane group (li), then over the waves through LDS, one fp64 atomic per channel, sum and block
 #pragma unroll
@@ -347,34 +398,38 @@ __global__ void __launch_bounds__(kBfThreads) bf16_conv_kernel(const Conv16Param
                 }
         }
         __syncthreads();
-        for (int e = tid; e < NT * 16 * 2; e += kBfThreads) {
+        for (int e = tid; e < NT * 16 * 2; e += kThreads) {
             const int ch = e >> 1;
             if (co_base + ch < p.cout) {
                 double tsum = 0.0;
-                for (int wv = 0; wv < 4; ++wv) tsum += static_cast<double>(s_red[(wv * NT * 16 + ch) * 2 + (e & 1)]);
+                for (int wv = 0; wv < WAVES; ++wv) tsum += static_cast<double>(s_red[(wv * NT * 16 + ch) * 2 + (e & 1)]);
                 atomicAdd(p.out_sums + 2 * (co_base + ch) + (e & 1), tsum);
             }
         }
     }
 }
 
-template <int KS, int NT>
+template <int KS, int NT, int WAVES>
 inline size_t bf16_conv_smem(int cin) {
     constexpr int kHalo = KS / 2;
     constexpr int kPix = (kBfTileY + 2 * kHalo) * (kBfTileX + 2 * kHalo);
     const int cpad = (cin + kBfKC - 1) / kBfKC * kBfKC;
-    const size_t bn = sizeof(float) * 2 * cpad, red = sizeof(float) * 4 * NT * 16 * 2;
+    const size_t bn = sizeof(float) * 2 * cpad, red = sizeof(float) * WAVES * NT * 16 * 2;
     return static_cast<size_t>(kPix) * 64 + static_cast<size_t>(KS * KS * NT) * 16 * 64 + (bn > red ? bn : red);
 }
 
-template <int KS, int NT, int POOL = 0>
-inline int launch_bf16_conv(const Conv16Params& p, hipStream_t stream) {
+template <int KS, int NT, int POOL = 0, int WAVES = 8, int WPE = 4, int EXP = 0>
+inline int launch_bf16_conv(const Conv16Params& p_, hipStream_t stream) {
+    Conv16Params p = p_;
+    if (p.in_blk <= 0) p.in_blk = p.in_t;
+    if (p.out_blk <= 0) p.out_blk = p.out_t;
+    if ((p.in_blk & 7) || (p.out_blk & 3) || (p.ic0 & 7) || (p.oc0 & 3) || p.in_t % p.in_blk || p.out_t % p.out_blk) return ENDO_E_BADARG;
     const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kBfTileY - 1) / kBfTileY);
     const int ngroups = (p.cout + NT * 16 - 1) / (NT * 16);
-    const size_t smem = bf16_conv_smem<KS, NT>(p.cin);
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t smem = bf16_conv_smem<KS, NT, WAVES>(p.cin);
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, POOL, WAVES, WPE, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(smem)));
-    bf16_conv_kernel<KS, NT, POOL><<<dim3(tiles, ngroups, p.n), kBfThreads, smem, stream>>>(p);
+    bf16_conv_kernel<KS, NT, POOL, WAVES, WPE, EXP><<<dim3(tiles, ngroups, p.n), 64 * WAVES, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -382,7 +437,7 @@ inline int launch_bf16_conv(const Conv16Params& p, hipStream_t stream) {
 // ---- weights: W[cout][cin][KS][KS] fp32 -> [chunk][group][tap][nt][16 cout][32 k] bf16 (zero padded) --------------------------------
 // (the kernel indexes (chunk * gridDim.y + blockIdx.y) * (taps * NT * 16 * 32) + ((tap * NT + nt) * 16 + cout) * 32 + k)
 __global__ void __launch_bounds__(256) bf16_conv_weights_kernel(const float* __restrict__ w, int cout, int cin, int ks, int nt,
-                                                                uint16_t* __restrict__ out) {
+                                                                uint16_t* __restrict__ out, int rot, int rot_n) {
     const int taps = ks * ks;
     const int nchunks = (cin + kBfKC - 1) / kBfKC;
     const int ngroups = (cout + nt * 16 - 1) / (nt * 16);
@@ -396,7 +451,8 @@ __global__ void __launch_bounds__(256) bf16_conv_weights_kernel(const float* __r
         const int chunk = rest / ngroups;
         const int co = (grp * nt + t) * 16 + co16, ci = chunk * kBfKC + k;
         float v = 0.f;
-        if (co < cout && ci < cin) v = w[(static_cast<int64_t>(co) * cin + ci) * taps + tap];
+        const int pci = ci < rot_n ? (ci + rot < rot_n ? ci + rot : ci + rot - rot_n) : ci;
+        if (co < cout && ci < cin) v = w[(static_cast<int64_t>(co) * cin + pci) * taps + tap];
         out[e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
     }
 }

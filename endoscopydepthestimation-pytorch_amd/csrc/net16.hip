@@ -14,9 +14,18 @@ namespace endo {
 
 constexpr int k16Levels = 5, k16Layers = 4, k16Growth = 12, k16First = 48, k16New = 48;
 inline int c16_down_in(int level) { return k16First + k16New * level; }
-inline int c16_level_channels(int level) { return level < k16Levels ? 144 + c16_down_in(level) : 288 + k16New; }
+constexpr int k16Blk = 32;                                                    // channels per block of a level buffer (bf16_conv_kernels.h)
+inline int c16_skip(int level) { return c16_down_in(level) + k16New; }        // channels a level hands to the up path (models.py:176-177)
+// Level buffer, l < 5: [0, S) the down path (dense-block input, then its 48 new maps: the skip), [S, S + 48) the transition-up output,
+// [S + 48, S + 96) the up block's new maps, S = c16_skip(l); every dense layer reads a run that starts at channel 0.  The reference
+// concatenates [transition-up output, skip] (models.py:183): the up layers' parameters are indexed through (rot = 48, rot_n = S + 48).
+// Bottleneck: [0, 288) input, [288, 336) new.  Padded to whole blocks.
+inline int c16_level_channels(int level) {
+    const int c = level < k16Levels ? 96 + c16_skip(level) : 288 + k16New;
+    return (c + k16Blk - 1) / k16Blk * k16Blk;
+}
 
-struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; };      // w16: element offset of the converted weights
+struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; int rot, rot_n; };      // w16: element offset of the converted weights
 struct Bn16 { int64_t g, b; int c; int64_t run_mean, run_var; int64_t saved; };
 
 // the reference's module order (models.py:100-170, the order of .parameters()): offsets come from the fp32 family's own table
@@ -36,7 +45,7 @@ static const Table16& table16() {
         auto conv = [&](Conv16& c, int cout, int cin, int ks, bool mfma) {
             c.cout = cout; c.cin = cin; c.ks = ks; c.nt = cout <= 16 ? 1 : 3;
             c.w = endo_net_param_offset(pi++); c.b = endo_net_param_offset(pi++);
-            c.w16 = -1;
+            c.w16 = -1; c.rot = 0; c.rot_n = 0;
             if (mfma) {
                 const int cin_k = cin < 4 ? 4 : cin;          // the first convolution's 3 input channels travel as 4 (+ 4 zero) of an 8-channel record
                 c.w16 = tb->w16_elems;
@@ -59,9 +68,14 @@ static const Table16& table16() {
         for (int i = 0; i < k16Levels; ++i) conv(tb->tu_conv[i], k16New, k16New, 3, true);
         for (int i = 0; i < k16Levels; ++i) {
             const int l = k16Levels - 1 - i;
-            for (int j = 0; j < k16Layers; ++j) { const int cin = 96 + c16_down_in(l) + k16Growth * j; bn(tb->up_bn[i][j], cin); conv(tb->up_conv[i][j], k16Growth, cin, 3, true); }
+            for (int j = 0; j < k16Layers; ++j) {
+                const int cin = 96 + c16_down_in(l) + k16Growth * j;
+                bn(tb->up_bn[i][j], cin); conv(tb->up_conv[i][j], k16Growth, cin, 3, true);
+                tb->up_conv[i][j].rot = k16New; tb->up_conv[i][j].rot_n = c16_skip(l) + k16New;
+            }
         }
         conv(tb->final_, 1, 192, 1, false);
+        tb->final_.rot = k16New; tb->final_.rot_n = c16_skip(0) + k16New;
         tb->saved_floats = saved;
         return tb;
     }();
@@ -73,7 +87,7 @@ struct W16Table {
     int layers;
     int64_t start[64];          // prefix sum of output elements
     int64_t w[63], out[63];
-    int cout[63], cin[63], cin_k[63], ks[63], nt[63];
+    int cout[63], cin[63], cin_k[63], ks[63], nt[63], rot[63], rot_n[63];
 };
 
 __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t, const float* __restrict__ params, uint16_t* __restrict__ w16) {
@@ -92,7 +106,8 @@ __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t,
         const int chunk = rest / ngroups;
         const int co = (grp * nt + tt) * 16 + co16, ci = chunk * kBfKC + k;
         float v = 0.f;
-        if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + ci) * taps + tap];
+        const int pci = ci < t.rot_n[l] ? (ci + t.rot[l] < t.rot_n[l] ? ci + t.rot[l] : ci + t.rot[l] - t.rot_n[l]) : ci;
+        if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + pci) * taps + tap];
         w16[t.out[l] + e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
     }
 }
@@ -107,20 +122,25 @@ __global__ void __launch_bounds__(256) bf16_pack_input_kernel(const float* __res
     }
 }
 
-// final 1x1 convolution 192 -> 1 and |.| (reference models.py:167, 186): 8 lanes per pixel, 24 channels each
+// final 1x1 convolution 192 -> 1 and |.| (reference models.py:167, 186) over the level-0 buffer ([6 blocks][plane][32]): 8 lanes per
+// pixel, 24 channels (three 8-channel units) each; the weight of buffer channel c is w[(c + rot) % rot_n] for c < rot_n
 __global__ void __launch_bounds__(256) bf16_final_fwd_kernel(const uint16_t* __restrict__ u, int64_t ns, int plane, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ pre, float* __restrict__ out) {
+                                                             const float* __restrict__ bias, int rot, int rot_n, float* __restrict__ pre,
+                                                             float* __restrict__ out) {
     const int n = blockIdx.y;
     const int sub = threadIdx.x & 7;
     float wv[24];
 #pragma unroll
-    for (int k = 0; k < 24; ++k) wv[k] = w[sub * 24 + k];
+    for (int k = 0; k < 24; ++k) {
+        const int c = sub * 24 + k;
+        wv[k] = w[c < rot_n ? (c + rot < rot_n ? c + rot : c + rot - rot_n) : c];
+    }
     for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; px < plane; px += (gridDim.x * blockDim.x) >> 3) {
-        const uint16_t* src = u + n * ns + static_cast<int64_t>(px) * 192 + sub * 24;
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(src + 8 * j);
+            const int c0 = sub * 24 + 8 * j;
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(u + n * ns + (static_cast<int64_t>(c0 >> 5) * plane + px) * k16Blk + (c0 & 31));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 acc = fmaf(bf16_lo(v[k]), wv[8 * j + 2 * k], acc);
@@ -136,21 +156,27 @@ __global__ void __launch_bounds__(256) bf16_final_fwd_kernel(const uint16_t* __r
     }
 }
 
-// fp32 NCHW [n][c][h][w] -> channels [oc0, oc0 + c) of a bf16 NHWC buffer with `t` channels per pixel
-__global__ void __launch_bounds__(256) bf16_pack_nhwc_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int c, int plane, int t, int oc0) {
+// fp32 NCHW [n][c][h][w] -> channels [oc0, oc0 + c) of a bf16 buffer [n][t / blk][h][w][blk] (blk = t: channels-last)
+__global__ void __launch_bounds__(256) bf16_pack_nhwc_kernel(const float* __restrict__ x, uint16_t* __restrict__ out, int c, int plane, int t, int blk,
+                                                             int oc0) {
     const int n = blockIdx.y;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane * c; i += gridDim.x * blockDim.x) {
         const int ch = i % c, px = i / c;
         const float v = x[(static_cast<int64_t>(n) * c + ch) * plane + px];
-        out[(static_cast<int64_t>(n) * plane + px) * t + oc0 + ch] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+        const int ca = oc0 + ch, cb = ca / blk;
+        out[static_cast<int64_t>(n) * plane * t + (static_cast<int64_t>(cb) * plane + px) * blk + (ca - cb * blk)] =
+            static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
     }
 }
 
-__global__ void __launch_bounds__(256) bf16_unpack_nhwc_kernel(const uint16_t* __restrict__ in, float* __restrict__ x, int c, int plane, int t, int ic0) {
+__global__ void __launch_bounds__(256) bf16_unpack_nhwc_kernel(const uint16_t* __restrict__ in, float* __restrict__ x, int c, int plane, int t, int blk,
+                                                               int ic0) {
     const int n = blockIdx.y;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane * c; i += gridDim.x * blockDim.x) {
         const int ch = i % c, px = i / c;
-        x[(static_cast<int64_t>(n) * c + ch) * plane + px] = bf16_lo(in[(static_cast<int64_t>(n) * plane + px) * t + ic0 + ch]);
+        const int ca = ic0 + ch, cb = ca / blk;
+        x[(static_cast<int64_t>(n) * c + ch) * plane + px] =
+            bf16_lo(in[static_cast<int64_t>(n) * plane * t + (static_cast<int64_t>(cb) * plane + px) * blk + (ca - cb * blk)]);
     }
 }
 
@@ -158,20 +184,22 @@ __global__ void __launch_bounds__(256) bf16_unpack_nhwc_kernel(const uint16_t* _
 
 using namespace endo;
 
-extern "C" int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int oc0, void* stream) {
-    if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || oc0 < 0 || oc0 + c > t) return ENDO_E_BADARG;
-    bf16_pack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(x, static_cast<uint16_t*>(out), c, h * w, t, oc0);
+// blk: channels per block of the buffer ([n][t / blk][h][w][blk]); 0 or t = plain channels-last
+extern "C" int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int blk, int oc0, void* stream) {
+    if (blk <= 0) blk = t;
+    if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || oc0 < 0 || oc0 + c > t || t % blk) return ENDO_E_BADARG;
+    bf16_pack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(x, static_cast<uint16_t*>(out), c, h * w, t, blk, oc0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int ic0, void* stream) {
-    if (!x || !in || n <= 0 || c <= 0 || h <= 0 || w <= 0 || ic0 < 0 || ic0 + c > t) return ENDO_E_BADARG;
-    bf16_unpack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(in), x, c, h * w, t, ic0);
+extern "C" int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream) {
+    if (blk <= 0) blk = t;
+    if (!x || !in || n <= 0 || c <= 0 || h <= 0 || w <= 0 || ic0 < 0 || ic0 + c > t || t % blk) return ENDO_E_BADARG;
+    bf16_unpack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(in), x, c, h * w, t, blk, ic0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
-
 extern "C" int64_t endo_bf16_conv_weight_elems(int cout, int cin, int ks) {
     if (cout <= 0 || cin <= 0 || (ks != 1 && ks != 3)) return -1;
     const int nt = cout <= 16 ? 1 : 3;
@@ -182,30 +210,31 @@ extern "C" int64_t endo_bf16_conv_weight_elems(int cout, int cin, int ks) {
 extern "C" int endo_bf16_conv_weights(const float* w, int cout, int cin, int ks, void* out, void* stream) {
     if (!w || !out || endo_bf16_conv_weight_elems(cout, cin, ks) < 0) return ENDO_E_BADARG;
     const int nt = cout <= 16 ? 1 : 3;
-    bf16_conv_weights_kernel<<<256, 256, 0, static_cast<hipStream_t>(stream)>>>(w, cout, cin, ks, nt, static_cast<uint16_t*>(out));
+    bf16_conv_weights_kernel<<<256, 256, 0, static_cast<hipStream_t>(stream)>>>(w, cout, cin, ks, nt, static_cast<uint16_t*>(out), 0, 0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
-// One convolution over channels-last bf16 buffers (reference models.py:22-25 / 73-74: [BN -> ReLU ->] [nearest x2 ->] conv KS x KS + bias).
-// in: [n][in_h][in_w][in_t] bf16, channels [ic0, ic0 + cin); out: [n][h][w][out_t] bf16, channels [oc0, oc0 + cout) (cout % 4 == 0,
-// cin % 4 == 0, ic0 % 8 == 0, in_t % 8 == 0, oc0 % 4 == 0); bn: [cin][2] (scale, shift) or null; wgt from endo_bf16_conv_weights;
+// One convolution over bf16 buffers (reference models.py:22-25 / 73-74: [BN -> ReLU ->] [nearest x2 ->] conv KS x KS + bias).
+// in: [n][in_t / in_blk][in_h][in_w][in_blk] bf16, channels [ic0, ic0 + cin); out: [n][out_t / out_blk][h][w][out_blk] bf16, channels
+// [oc0, oc0 + cout) (blk 0 = t: channels-last; cout % 4 == 0, cin % 4 == 0, ic0 % 8 == 0, in_blk % 8 == 0, oc0 % 4 == 0, out_blk % 4 == 0); bn: [cin][2] (scale, shift) or null; wgt from endo_bf16_conv_weights;
 // out_sums: [cout][2] fp64 (sum, sum^2 of the stored values, ACCUMULATED) or null; ups: input is (h / 2) x (w / 2), nearest x2.
-extern "C" int endo_bf16_conv(const void* in, int in_t, int ic0, int cin, const float* bn, const void* wgt, const float* bias, void* out, int out_t,
-                              int oc0, int cout, double* out_sums, int n, int h, int w, int ks, int ups, void* stream_) {
+extern "C" int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int cin, const float* bn, const void* wgt, const float* bias, void* out,
+                              int out_t, int out_blk, int oc0, int cout, double* out_sums, int n, int h, int w, int ks, int ups, void* stream_) {
     if (!in || !wgt || !out || n <= 0 || h <= 0 || w <= 0 || (ks != 1 && ks != 3) || cin <= 0 || cout <= 0 || (cin & 3) || (cout & 3) || (ic0 & 7) ||
         (in_t & 7) || (oc0 & 3) || (out_t & 3) || ic0 + cin > in_t || oc0 + cout > out_t || (ups && ((h | w) & 1)))
         return ENDO_E_BADARG;
     Conv16Params p{};
     p.n = n; p.h = h; p.w = w;
     p.in_h = ups ? h / 2 : h; p.in_w = ups ? w / 2 : w;
+    p.in_blk = in_blk; p.out_blk = out_blk;
     p.in = static_cast<const uint16_t*>(in); p.in_t = in_t; p.in_ns = static_cast<int64_t>(p.in_h) * p.in_w * in_t; p.ic0 = ic0; p.cin = cin;
     p.bn = bn; p.wgt = static_cast<const uint16_t*>(wgt); p.bias = bias;
     p.out = static_cast<uint16_t*>(out); p.out_t = out_t; p.out_ns = static_cast<int64_t>(h) * w * out_t; p.oc0 = oc0; p.cout = cout;
     p.out_sums = out_sums; p.ups = ups;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
-    if (ks == 3) return cout <= 16 ? launch_bf16_conv<3, 1>(p, stream) : launch_bf16_conv<3, 3>(p, stream);
-    return cout <= 16 ? launch_bf16_conv<1, 1>(p, stream) : launch_bf16_conv<1, 3>(p, stream);
+    if (ks == 3) return cout <= 16 ? launch_bf16_conv<3, 1, 0, 8, 4>(p, stream) : launch_bf16_conv<3, 3, 0, 8, 2>(p, stream);
+    return cout <= 16 ? launch_bf16_conv<1, 1, 0, 8, 4>(p, stream) : launch_bf16_conv<1, 3, 0, 8, 4>(p, stream);
 }
 
 
@@ -270,9 +299,9 @@ void fill_io(const Ctx16& c, Conv16Params& p, int in_level, int ic0, int cin, in
     const auto& li = c.net->lv[in_level];
     const auto& lo = c.net->lv[out_level];
     p.n = c.net->n;
-    p.in = c.act(in_level); p.in_t = li.t; p.in_h = li.h; p.in_w = li.w; p.in_ns = li.plane * li.t; p.ic0 = ic0; p.cin = cin;
-    p.wgt = c.w16(cv); p.bias = c.params + cv.b;
-    p.out = c.act(out_level); p.out_t = lo.t; p.out_ns = lo.plane * lo.t; p.oc0 = oc0; p.cout = cv.cout;
+    p.in = c.act(in_level); p.in_t = li.t; p.in_blk = k16Blk; p.in_h = li.h; p.in_w = li.w; p.in_ns = li.plane * li.t; p.ic0 = ic0; p.cin = cin;
+    p.wgt = c.w16(cv); p.bias = c.params + cv.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
+    p.out = c.act(out_level); p.out_t = lo.t; p.out_blk = k16Blk; p.out_ns = lo.plane * lo.t; p.oc0 = oc0; p.cout = cv.cout;
     p.out_sums = c.training ? c.sums(out_level) + 2 * oc0 : nullptr;
 }
 
@@ -293,27 +322,27 @@ int dense16(const Ctx16& c, int level, int ic0, int oc0, const Bn16& b, const Co
     fill_io(c, p, level, ic0, cv.cin, level, oc0, cv);
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
     fill_bn(c, p, b, level, ic0);
-    return launch_bf16_conv<3, 1>(p, c.stream);
+    return launch_bf16_conv<3, 1, 0, 8, 4>(p, c.stream);
 }
 
 // transition down: BN -> ReLU -> conv1x1 -> maxpool2 into the next level (models.py:56-67)
 int td16(const Ctx16& c, int level, const Bn16& b, const Conv16& cv) {
     const int next = level + 1;
     Conv16Params p{};
-    fill_io(c, p, level, 48, cv.cin, next, next < k16Levels ? 48 : 0, cv);
+    fill_io(c, p, level, 0, cv.cin, next, 0, cv);
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
-    fill_bn(c, p, b, level, 48);
+    fill_bn(c, p, b, level, 0);
     p.out_idx = reinterpret_cast<uint8_t*>(c.tape + c.net->idx_off[level]);
-    return launch_bf16_conv<1, 3, 1>(p, c.stream);
+    return launch_bf16_conv<1, 3, 1, 8, 4>(p, c.stream);
 }
 
-// transition up: nearest x2 -> conv3x3 48 -> 48 into channels [0, 48) of the finer level (models.py:70-80)
+// transition up: nearest x2 -> conv3x3 48 -> 48 into channels [S, S + 48) of the finer level (models.py:70-80)
 int tu16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16& cv) {
     Conv16Params p{};
-    fill_io(c, p, src_level, src_c0, cv.cin, level, 0, cv);
+    fill_io(c, p, src_level, src_c0, cv.cin, level, c16_skip(level), cv);
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
     p.ups = 1;
-    return launch_bf16_conv<3, 3>(p, c.stream);
+    return launch_bf16_conv<3, 3, 0, 8, 2>(p, c.stream);
 }
 
 }  // namespace
@@ -337,7 +366,7 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
             const Conv16& cv = *tb.convs[l];
             const int cin_k = cv.cin < 4 ? 4 : cv.cin;
             const int64_t groups = (cv.cout + cv.nt * 16 - 1) / (cv.nt * 16), chunks = (cin_k + kBfKC - 1) / kBfKC;
-            t.start[l] = start; t.w[l] = cv.w; t.out[l] = cv.w16; t.cout[l] = cv.cout; t.cin[l] = cv.cin; t.cin_k[l] = cin_k; t.ks[l] = cv.ks; t.nt[l] = cv.nt;
+            t.start[l] = start; t.w[l] = cv.w; t.out[l] = cv.w16; t.cout[l] = cv.cout; t.cin[l] = cv.cin; t.cin_k[l] = cin_k; t.ks[l] = cv.ks; t.nt[l] = cv.nt; t.rot[l] = cv.rot; t.rot_n[l] = cv.rot_n;
             start += chunks * groups * cv.ks * cv.ks * cv.nt * 16 * 32;
         }
         t.start[t.layers] = start;
@@ -353,14 +382,14 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
         p.n = net->n; p.h = net->h; p.w = net->w;
         p.in = xin; p.in_t = 8; p.in_h = net->h; p.in_w = net->w; p.in_ns = net->lv[0].plane * 8; p.ic0 = 0; p.cin = 4;
         p.wgt = c.w16(tb.first); p.bias = params + tb.first.b;
-        p.out = c.act(0); p.out_t = net->lv[0].t; p.out_ns = net->lv[0].plane * net->lv[0].t; p.oc0 = 48; p.cout = k16First;
-        p.out_sums = training ? c.sums(0) + 2 * 48 : nullptr;
-        rc = launch_bf16_conv<3, 3>(p, stream);
+        p.out = c.act(0); p.out_t = net->lv[0].t; p.out_blk = k16Blk; p.out_ns = net->lv[0].plane * net->lv[0].t; p.oc0 = 0; p.cout = k16First;
+        p.out_sums = training ? c.sums(0) : nullptr;
+        rc = launch_bf16_conv<3, 3, 0, 8, 2>(p, stream);
         if (rc) return rc;
     }
     for (int l = 0; l < k16Levels; ++l) {
         for (int j = 0; j < k16Layers; ++j) {
-            rc = dense16(c, l, 48, 48 + c16_down_in(l) + k16Growth * j, tb.down_bn[l][j], tb.down_conv[l][j]);
+            rc = dense16(c, l, 0, c16_down_in(l) + k16Growth * j, tb.down_bn[l][j], tb.down_conv[l][j]);
             if (rc) return rc;
         }
         rc = td16(c, l, tb.td_bn[l], tb.td_conv[l]);
@@ -372,11 +401,11 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
     }
     for (int i = 0; i < k16Levels; ++i) {
         const int l = k16Levels - 1 - i, src = l + 1;
-        const int src_c0 = (i == 0) ? 288 : 96 + c16_down_in(src);
+        const int src_c0 = (i == 0) ? 288 : c16_skip(src) + k16New;
         rc = tu16(c, l, src, src_c0, tb.tu_conv[i]);
         if (rc) return rc;
         for (int j = 0; j < k16Layers; ++j) {
-            rc = dense16(c, l, 0, 96 + c16_down_in(l) + k16Growth * j, tb.up_bn[i][j], tb.up_conv[i][j]);
+            rc = dense16(c, l, 0, c16_skip(l) + k16New + k16Growth * j, tb.up_bn[i][j], tb.up_conv[i][j]);
             if (rc) return rc;
         }
     }
@@ -385,7 +414,7 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
         int bx = static_cast<int>((lv.plane * 8 + 255) / 256);
         bx = bx > 2048 ? 2048 : bx;
         bf16_final_fwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(c.act(0), lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w,
-                                                                     params + tb.final_.b, reinterpret_cast<float*>(c.tape + net->pre_off), out);
+                                                                     params + tb.final_.b, tb.final_.rot, tb.final_.rot_n, reinterpret_cast<float*>(c.tape + net->pre_off), out);
         ENDO_LAUNCH_CHECK();
     }
     return 0;

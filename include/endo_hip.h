@@ -358,23 +358,24 @@ int endo_prof_read(int family, double* total_ms, int64_t* launches, double* tota
 const char* endo_prof_family_name(int family);
 
 /* ---------------------------------------------------------------------------------------------
- * bf16-STORAGE family, first bricks (BASELINE configs[2] / [4]) -- not yet a network: channels-last bf16 level
- * buffers ([n][h][w][t] bf16) and the convolution over them on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32
- * accumulation), with BatchNorm + ReLU applied once per staged element (reference models.py:19-28: DenseLayer; 70-80: TransitionUp).
- *   endo_bf16_pack_nhwc / unpack_nhwc   fp32 NCHW <-> a channel slice of a bf16 NHWC buffer (round to nearest even)
+ * bf16-STORAGE family (BASELINE configs[2] / [4]): bf16 level buffers in 32-channel blocks
+ * ([n][t / blk][h][w][blk] bf16; blk = t is plain channels-last) and the convolution over them on the bf16 matrix cores
+ * (v_mfma_f32_16x16x32_bf16, fp32 accumulation), with BatchNorm + ReLU applied once per staged element (reference models.py:19-28:
+ * DenseLayer; 70-80: TransitionUp).
+ *   endo_bf16_pack_nhwc / unpack_nhwc   fp32 NCHW <-> a channel slice of a bf16 buffer (round to nearest even); blk 0 = t
  *   endo_bf16_conv_weights              W[cout][cin][ks][ks] fp32 -> the kernel's bf16 layout (endo_bf16_conv_weight_elems elements)
  *   endo_bf16_conv                      out[.., oc0 : oc0 + cout] = conv_ks([nearest x2]([relu(x * scale + shift)])) + bias
  *                                       bn: [cin][2] fp32 (scale, shift) or null; out_sums: [cout][2] fp64, accumulated, or null
- * Constraints: ks in {1, 3}; cin, cout, oc0, out_t multiples of 4; ic0, in_t multiples of 8.
+ * Constraints: ks in {1, 3}; cin, cout, oc0, out_blk multiples of 4; ic0, in_blk multiples of 8; t a multiple of blk.
  * ------------------------------------------------------------------------------------------- */
-int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int oc0, void* stream);
-int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int ic0, void* stream);
+int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int blk, int oc0, void* stream);
+int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream);
 int64_t endo_bf16_conv_weight_elems(int cout, int cin, int ks);
 int endo_bf16_conv_weights(const float* w, int cout, int cin, int ks, void* out, void* stream);
-int endo_bf16_conv(const void* in, int in_t, int ic0, int cin, const float* bn, const void* wgt, const float* bias, void* out, int out_t,
-                   int oc0, int cout, double* out_sums, int n, int h, int w, int ks, int ups, void* stream);
+int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int cin, const float* bn, const void* wgt, const float* bias, void* out,
+                   int out_t, int out_blk, int oc0, int cout, double* out_sums, int n, int h, int w, int ks, int ups, void* stream);
 /* FCDenseNet57 FORWARD over bf16 level buffers (reference models.py:171-187): same parameters / running statistics / input / output
- * tensors as endo_net_fwd (fp32), activations stored as bf16 NHWC, BatchNorm statistics and the output in fp32.  The input is
+ * tensors as endo_net_fwd (fp32), activations stored as bf16 in 32-channel blocks, BatchNorm statistics and the output in fp32.  The input is
  * rounded to bf16 on the way in.  training != 0: batch statistics + running-statistics update; 0: running statistics (the
  * evaluate.py path).  tape: endo_net16_tape_bytes() bytes of device memory, 256-byte aligned.  H and W multiples of 32.
  * There is no backward pass over this layout yet: gradients come from the fp32 family. */

@@ -23,32 +23,33 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
 
-def run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=False):
-    """x: [n][C][in_h][in_w] fp32 planar (all in_t channels); returns (out planar fp32 of the cout channels, sums or None)."""
+def run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=False, blk=0):
+    """x: [n][C][in_h][in_w] fp32 planar (all in_t channels); returns (out planar fp32 of the cout channels, sums or None).
+    blk: channels per block of both buffers ([n][t / blk][h][w][blk]; 0 = plain channels-last)."""
     lib = ea._lib.load()
     n = x.shape[0]
     in_h, in_w = x.shape[2], x.shape[3]
     cout = weight.shape[0]
-    xin = torch.zeros((n, in_h, in_w, in_t), dtype=torch.bfloat16, device=dev())
-    assert lib.endo_bf16_pack_nhwc(x.to(dev()).contiguous().data_ptr(), xin.data_ptr(), n, in_t, in_h, in_w, in_t, 0, None) == 0
+    xin = torch.zeros(n * in_h * in_w * in_t, dtype=torch.bfloat16, device=dev())
+    assert lib.endo_bf16_pack_nhwc(x.to(dev()).contiguous().data_ptr(), xin.data_ptr(), n, in_t, in_h, in_w, in_t, blk, 0, None) == 0
     wl = torch.empty(int(lib.endo_bf16_conv_weight_elems(cout, cin, ks)), dtype=torch.bfloat16, device=dev())
     assert lib.endo_bf16_conv_weights(weight.to(dev()).contiguous().data_ptr(), cout, cin, ks, wl.data_ptr(), None) == 0
-    out = torch.full((n, h, w, out_t), float("nan"), dtype=torch.bfloat16, device=dev())
+    out = torch.full((n * h * w * out_t,), float("nan"), dtype=torch.bfloat16, device=dev())
     s = torch.zeros((cout, 2), dtype=torch.float64, device=dev()) if sums else None
     b = bias.to(dev()) if bias is not None else None
     bnd = bn.to(dev()).contiguous() if bn is not None else None
-    rc = lib.endo_bf16_conv(xin.data_ptr(), in_t, ic0, cin, bnd.data_ptr() if bnd is not None else None, wl.data_ptr(),
-                            b.data_ptr() if b is not None else None, out.data_ptr(), out_t, oc0, cout,
+    rc = lib.endo_bf16_conv(xin.data_ptr(), in_t, blk, ic0, cin, bnd.data_ptr() if bnd is not None else None, wl.data_ptr(),
+                            b.data_ptr() if b is not None else None, out.data_ptr(), out_t, blk, oc0, cout,
                             s.data_ptr() if s is not None else None, n, h, w, ks, ups, None)
     assert rc == 0, rc
-    y = torch.empty((n, cout, h, w), dtype=torch.float32, device=dev())
-    assert lib.endo_bf16_unpack_nhwc(out.data_ptr(), y.data_ptr(), n, cout, h, w, out_t, oc0, None) == 0
+    y_all = torch.empty((n, out_t, h, w), dtype=torch.float32, device=dev())
+    assert lib.endo_bf16_unpack_nhwc(out.data_ptr(), y_all.data_ptr(), n, out_t, h, w, out_t, blk, 0, None) == 0
     torch.cuda.synchronize()
     # nothing outside the slice was written
     untouched = torch.ones(out_t, dtype=torch.bool)
     untouched[oc0:oc0 + cout] = False
-    assert torch.isnan(out.float()[..., untouched.to(dev())]).all()
-    return y.cpu(), (s.cpu() if s is not None else None)
+    assert torch.isnan(y_all[:, untouched.to(dev())]).all()
+    return y_all[:, oc0:oc0 + cout].cpu(), (s.cpu() if s is not None else None)
 
 
 def reference(x, ic0, cin, weight, bias, bn, ks, ups):
@@ -68,12 +69,13 @@ CASES = [
     (1, 37, 53, 96, 0, 48, 12, 96, 48, 3, 0, True),              # sizes that are not multiples of the tile
     (2, 16, 20, 384, 48, 288, 12, 384, 336, 3, 0, True),         # a coarse level, 9 K-chunks
     (2, 32, 64, 96, 48, 48, 48, 192, 0, 3, 1, False),            # transition up: nearest x2 + conv 48 -> 48, raw input
-    (1, 24, 40, 144, 48, 96, 96, 96, 0, 1, 0, True),             # 1 x 1, 96 -> 96 (two cout groups of 48)
+    (1, 24, 40, 160, 48, 96, 96, 96, 0, 1, 0, True),             # 1 x 1, 96 -> 96 (two cout groups of 48)
 ]
 
 
+@pytest.mark.parametrize("blk", [0, 32], ids=["nhwc", "blk32"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_cin%d_cout%d_ks%d%s" % (c[0], c[1], c[2], c[5], c[6], c[9], "_ups" if c[10] else ""))
-def test_bf16_conv_against_fp64(case):
+def test_bf16_conv_against_fp64(case, blk):
     n, h, w, in_t, ic0, cin, cout, out_t, oc0, ks, ups, use_bn = case
     rng = np.random.default_rng(7)
     in_h, in_w = (h // 2, w // 2) if ups else (h, w)
@@ -81,7 +83,7 @@ def test_bf16_conv_against_fp64(case):
     weight = torch.from_numpy((rng.standard_normal((cout, cin, ks, ks)) * (2.0 / (cin * ks * ks)) ** 0.5).astype(np.float32))
     bias = torch.from_numpy(rng.uniform(-0.1, 0.1, cout).astype(np.float32))
     bn = torch.from_numpy(np.stack([rng.uniform(0.5, 1.5, cin) * rng.choice([-1, 1], cin), rng.uniform(-0.3, 0.3, cin)], axis=1).astype(np.float32)) if use_bn else None
-    y, s = run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=True)
+    y, s = run_conv(x, ic0, cin, in_t, weight, bias, bn, oc0, out_t, ks, ups, h, w, sums=True, blk=blk)
     ref = reference(x, ic0, cin, weight, bias, bn, ks, ups)
     err = float((y.double() - ref).abs().max() / ref.abs().max())
     print("bf16 conv %s: max err / max |ref| = %.2e" % (case, err))
@@ -98,7 +100,8 @@ def test_bf16_conv_dense_layer_timing():
     lib = ea._lib.load()
     n, h, w, t, ic0, cin, cout, oc0 = 16, 256, 320, 192, 0, 180, 12, 180
     g = torch.Generator(device=dev()).manual_seed(3)
-    xin = (torch.rand((n, h, w, t), device=dev(), generator=g) * 2 - 1).to(torch.bfloat16)
+    blk = 32                                       # the level buffers' layout: [n][t / 32][h][w][32]
+    xin = (torch.rand(n * h * w * t, device=dev(), generator=g) * 2 - 1).to(torch.bfloat16)
     weight = torch.randn((cout, cin, 3, 3), device=dev(), generator=g) * (2.0 / (cin * 9)) ** 0.5
     bn = torch.stack([torch.rand(cin, device=dev(), generator=g) + 0.5, torch.rand(cin, device=dev(), generator=g) * 0.2 - 0.1], dim=1).contiguous()
     bias = torch.zeros(cout, device=dev())
@@ -107,7 +110,7 @@ def test_bf16_conv_dense_layer_timing():
     sums = torch.zeros((cout, 2), dtype=torch.float64, device=dev())
 
     def run():
-        return lib.endo_bf16_conv(xin.data_ptr(), t, ic0, cin, bn.data_ptr(), wl.data_ptr(), bias.data_ptr(), xin.data_ptr(), t, oc0, cout,
+        return lib.endo_bf16_conv(xin.data_ptr(), t, blk, ic0, cin, bn.data_ptr(), wl.data_ptr(), bias.data_ptr(), xin.data_ptr(), t, blk, oc0, cout,
                                   sums.data_ptr(), n, h, w, 3, 0, None)
     for _ in range(3):
         assert run() == 0
@@ -121,11 +124,13 @@ def test_bf16_conv_dense_layer_timing():
     us = e0.elapsed_time(e1) / 20 * 1e3
     gb = n * h * w * (cin + cout) * 2 / 1e9
     print("bf16-storage dense layer, level 0, Cin 180 -> 12, 16 x 256 x 320: %.1f us = %.2f TB/s of algorithmic bytes, %.1f TFLOP/s" % (
-        us, gb / us * 1e3 / 1e3 * 1e3 / 1e3, 2.0 * n * h * w * cin * cout * 9 / us / 1e6))
+        us, gb / us * 1e3, 2.0 * n * h * w * cin * cout * 9 / us / 1e6))
     # correctness on the first sample's top-left block
     y = torch.empty((1, cout, h, w), dtype=torch.float32, device=dev())
-    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), y.data_ptr(), 1, cout, h, w, t, oc0, None) == 0
-    x0 = xin[0, :40, :40, :cin].float().permute(2, 0, 1).unsqueeze(0).cpu()
+    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), y.data_ptr(), 1, cout, h, w, t, blk, oc0, None) == 0
+    xa = torch.empty((1, cin, h, w), dtype=torch.float32, device=dev())
+    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), xa.data_ptr(), 1, cin, h, w, t, blk, ic0, None) == 0
+    x0 = xa[:, :, :40, :40].cpu()
     ref = reference(x0, 0, cin, weight.cpu(), bias.cpu(), bn.cpu(), 3, 0)[0, :, :32, :32]
     err = float((y[0, :, :32, :32].cpu().double() - ref).abs().max() / ref.abs().max())
     assert err <= 6e-3, err
@@ -134,7 +139,7 @@ def test_bf16_conv_dense_layer_timing():
 # ---------------------------------------------------------------------------------------------
 # the whole forward pass over bf16 level buffers
 # ---------------------------------------------------------------------------------------------
-BF16_STORAGE_FWD_TOL = 5e-2          # depth against the fp64 oracle, max error / max depth; measured values are printed by the test
+BF16_STORAGE_FWD_TOL = 2e-2          # depth against the fp64 oracle, max error / max depth; measured 6e-3 .. 1e-2 (printed by the test)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (1, 128, 160), (2, 256, 320)])
