@@ -50,6 +50,9 @@ SIGNATURES = {
     "endo_net16_destroy": (None, [_P]),
     "endo_net16_tape_bytes": (_L, [_P]),
     "endo_net16_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "endo_net16_bwd_workspace_bytes": (_L, [_P]),
+    "endo_net16_offset": (_L, [_P, _I, _I]),
+    "endo_net16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "endo_net_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
     "endo_net_create_grouped": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),

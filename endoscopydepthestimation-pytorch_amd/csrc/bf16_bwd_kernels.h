@@ -1,0 +1,395 @@
+// bf16-STORAGE kernel family, backward pass (round 3): what is not a convolution over the gradient buffer (those run through
+// bf16_conv_kernel with its kEpiDgradBn / kEpiSumPool epilogues): the final 1 x 1 + |.| backward, the deferred BatchNorm terms
+// (prep_dy + finalize, the scheme of the fp32 family, net.hip prep_dy_kernel / bn_bwd_finalize_kernel), and the weight gradients.
+//
+// Weight gradient of a convolution over 32-channel-blocked bf16 buffers.  dW[co][ci][ky][kx] = sum over pixels of
+// G[co][y][x] * a[ci][y + ky - 1][x + kx - 1], a = relu(bn(x)) recomputed from the stored bf16 x (reference models.py:22-25).  On
+// v_mfma_f32_16x16x32_bf16 the contraction index k is the PIXEL (8 consecutive pixels of one channel per lane), which the blocked
+// layout keeps 64 bytes apart: both operands are transposed through LDS on the way in ([channel][row][32 pixels], channel pitch
+// 16 bytes off a multiple of 256 so that the 16 channels of a fragment read land in 16 different bank groups).  A = G (i = cout), B = a
+// (j = ci): the SMALL operand is the one shifted per tap -- G is staged three times, pre-shifted by kx - 1 pixels, so that every
+// fragment read is 16-byte aligned; the ky shift is a row offset.  One B fragment feeds 9 MFMAs (3 x 3: the 9 taps of one 16-cout
+// group; 1 x 1: 9 cout groups).  A block owns up to 192 input channels, 3 ci tiles per wave, 27 accumulator tiles per wave, and walks
+// 4 x 32 pixel tiles; its sums leave as one fp32 partial per block, reduced by a second small kernel (deterministic, no atomics).
+#pragma once
+
+#include "bf16_conv_kernels.h"
+
+namespace endo {
+
+__device__ __forceinline__ int rot_index(int c, int rot, int rot_n) { return c < rot_n ? (c + rot < rot_n ? c + rot : c + rot - rot_n) : c; }
+// element offset of channel ca of pixel pix in a [t / blk][plane][blk] sample
+__device__ __forceinline__ int64_t blk_off(int ca, int64_t pix, int64_t plane, int blk) {
+    const int cb = ca / blk;
+    return (cb * plane + pix) * blk + (ca - cb * blk);
+}
+
+// ---- final 1 x 1 + |.| backward (reference models.py:167, 186): du[c] = g * sign(pre) * w[c] for all 192 channels (first writer of the
+// level-0 gradient buffer); grad_w[c] += sum g * sign(pre) * u[c]; grad_b += sum g * sign(pre).  8 lanes per pixel, 24 channels each.
+__global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
+                                                             const uint16_t* __restrict__ u, uint16_t* __restrict__ du, int64_t ns, int plane,
+                                                             const float* __restrict__ w, int rot, int rot_n, float* __restrict__ grad_w,
+                                                             float* __restrict__ grad_b, double* __restrict__ gsum) {
+    __shared__ float s_part[4][8][25];
+    const int n = blockIdx.y;
+    const int sub = threadIdx.x & 7;
+    float wv[24], gw[24];
+    float gb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) { wv[k] = w[rot_index(sub * 24 + k, rot, rot_n)]; gw[k] = 0.f; }
+    for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; px < plane; px += (gridDim.x * blockDim.x) >> 3) {
+        const float z = pre[static_cast<int64_t>(n) * plane + px];
+        const float gs = gout[static_cast<int64_t>(n) * plane + px] * (z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f));
+        gb += gs;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int c0 = sub * 24 + 8 * j;
+            const int64_t off = n * ns + (static_cast<int64_t>(c0 >> 5) * plane + px) * 32 + (c0 & 31);
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(u + off);
+            u32x4_t o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gw[8 * j + 2 * k] = fmaf(gs, bf16_lo(v[k]), gw[8 * j + 2 * k]);
+                gw[8 * j + 2 * k + 1] = fmaf(gs, bf16_hi(v[k]), gw[8 * j + 2 * k + 1]);
+                o[k] = pack_bf16x2(gs * wv[8 * j + 2 * k], gs * wv[8 * j + 2 * k + 1]);
+            }
+            *reinterpret_cast<u32x4_t*>(du + off) = o;
+        }
+    }
+    // lanes with the same sub: 8 per wave (lane bits 3..5), then the 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+        gw[k] += __shfl_xor(gw[k], 8, 64); gw[k] += __shfl_xor(gw[k], 16, 64); gw[k] += __shfl_xor(gw[k], 32, 64);
+    }
+    gb += __shfl_xor(gb, 8, 64); gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+    if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) s_part[wave][sub][k] = gw[k];
+        s_part[wave][sub][24] = gb;
+    }
+    __syncthreads();
+    const float gb_block = s_part[0][0][24] + s_part[1][0][24] + s_part[2][0][24] + s_part[3][0][24];
+    if (threadIdx.x < 192) {
+        const int s = threadIdx.x / 24, k = threadIdx.x - 24 * s;
+        atomicAdd(grad_w + rot_index(threadIdx.x, rot, rot_n), s_part[0][s][k] + s_part[1][s][k] + s_part[2][s][k] + s_part[3][s][k]);
+        // sum over pixels of what this kernel writes into channel c of the gradient buffer (see bf16_prep_dy_kernel)
+        atomicAdd(gsum + 2 * threadIdx.x, static_cast<double>(w[rot_index(threadIdx.x, rot, rot_n)]) * static_cast<double>(gb_block));
+    }
+    if (threadIdx.x == 192) atomicAdd(grad_b, gb_block);
+}
+
+// ---- prep_dy: a channel range [c0, c0 + count) of a level's gradient buffer becomes the full gradient of the stored values once
+// all its consumers have been differentiated: d += P[c] * x + Q[c] (the deferred BatchNorm terms, zero in inference mode).  count % 4 == 0.
+//
+// The bias gradient of the convolution that produced the range (reference: conv bias, models.py:24) is the sum of that full gradient
+// over the pixels -- and is NOT taken from the bf16 buffer: d holds sums of scale * da that the deferred terms then largely cancel
+// (BatchNorm removes the mean of the gradient), so its 8-bit roundings are relative to the uncancelled magnitude and their sum over
+// 1e4..1e6 pixels was measured at 2-3x the true bias gradient.  Every contribution's pixel sum is known exactly where it is made:
+// a training-mode BatchNorm consumer contributes 0 (scale * S1 - scale * S1 - k * sum(x - mean)), an inference-mode one scale * S1
+// (bf16_bn_finalize_kernel), the final convolution w[c] * sum g (bf16_final_bwd_kernel), a transition up the fp32 sum of what its
+// kEpiSumPool epilogue adds.  They meet in gsum ([t][2] fp64 per level, first of each pair), read here by one block.
+__global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict__ d, const uint16_t* __restrict__ x, int64_t ns, int plane, int blk,
+                                                           int c0, int count, const float* __restrict__ pq_p, const float* __restrict__ pq_q,
+                                                           float* __restrict__ bias_grad, const double* __restrict__ gsum, int apply) {
+    if (bias_grad && blockIdx.x == 0 && blockIdx.y == 0)
+        for (int c = threadIdx.x; c < count; c += 256) bias_grad[c] += static_cast<float>(gsum[2 * (c0 + c)]);
+    if (!apply) return;          // inference mode: P = Q = 0
+    const int n = blockIdx.y;
+    const int quads = count >> 2;
+    const int ppi = 256 / quads;                                   // pixels per iteration of the block
+    const int q = threadIdx.x % quads, p0 = threadIdx.x / quads;
+    if (p0 >= ppi) return;
+    float pc[4], qc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { pc[i] = pq_p[c0 + 4 * q + i]; qc[i] = pq_q[c0 + 4 * q + i]; }
+    for (int px = blockIdx.x * ppi + p0; px < plane; px += gridDim.x * ppi) {
+        const int64_t off = n * ns + blk_off(c0 + 4 * q, px, plane, blk);
+        const u32x2_t dv = *reinterpret_cast<const u32x2_t*>(d + off);
+        const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(x + off);
+        const float g0 = bf16_lo(dv[0]) + fmaf(pc[0], bf16_lo(xv[0]), qc[0]), g1 = bf16_hi(dv[0]) + fmaf(pc[1], bf16_hi(xv[0]), qc[1]);
+        const float g2 = bf16_lo(dv[1]) + fmaf(pc[2], bf16_lo(xv[1]), qc[2]), g3 = bf16_hi(dv[1]) + fmaf(pc[3], bf16_hi(xv[1]), qc[3]);
+        *reinterpret_cast<u32x2_t*>(d + off) = u32x2_t{pack_bf16x2(g0, g1), pack_bf16x2(g2, g3)};
+    }
+}
+
+// ---- BatchNorm backward, the per-channel part (reference: nn.BatchNorm2d in front of every dense / transition-down convolution).
+// sums: [cin][2] fp64 from the kEpiDgradBn epilogue (S1 = sum da, S2raw = sum da * x); xhat = (x - mean) * rstd, so
+// S2 = sum da * xhat = rstd * (S2raw - mean * S1).  ggamma += S2, gbeta += S1; training mode also defers
+//   dx = scale * da - scale * S1 / M - scale * rstd * (S2 / M) * (x - mean)   =>   P += -scale * rstd * S2 / M,
+//   Q += -scale * S1 / M + scale * rstd * S2 / M * mean        (the fp32 family's bn_bwd_finalize_kernel, net.hip)
+// to the prep_dy of the channels (buffer channel ic0 + ci; parameters at (ci + rot) % rot_n).
+__global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ saved,
+                                                               const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
+                                                               float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum, int cin, int rot,
+                                                               int rot_n, double count, int training) {
+    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < cin; ci += gridDim.x * blockDim.x) {
+        const int pc = rot_index(ci, rot, rot_n);
+        const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
+        const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
+        atomicAdd(ggamma + pc, static_cast<float>(s2));
+        atomicAdd(gbeta + pc, static_cast<float>(s1));
+        const double scale = gamma[pc] * rstd;
+        if (training) {
+            const double k = scale * rstd * s2 / count;
+            pq_p[ci] += static_cast<float>(-k);
+            pq_q[ci] += static_cast<float>(-scale * s1 / count + k * mean);
+        } else {
+            gsum[2 * ci] += scale * s1;          // the pixel sum of what the layer added to channel ci (training mode: exactly 0)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradient
+// ---------------------------------------------------------------------------------------------
+constexpr int kWgRows = 4, kWgCols = 32;                 // pixels of a tile
+constexpr int kWgCi = 192;                               // input channels per block (grid.y covers the rest)
+constexpr int kWgPitchA = kWgRows * 64 + 16;             // bytes between channels of the staged a tile
+constexpr int kWgPitchG3 = (kWgRows + 2) * 3 * 64 + 16;  // 3 x 3: [16 cout][6 rows][3 shifted copies][32 px]
+constexpr int kWgCo1 = 144;                              // 1 x 1: couts per block (9 fragments of 16)
+
+struct Wgrad16Params {
+    int n, h, w;                       // grid of G (the forward convolution's output)
+    const uint16_t* a;                 // forward input of the convolution (bf16, blocked)
+    int64_t a_ns;
+    int a_blk, a_h, a_w;               // a_h, a_w = h, w unless ups
+    int ac0, cin;                      // the convolution read channels [ac0, ac0 + cin)
+    int cin_w;                         // input channels of the weight tensor (0 = cin; the first convolution's 3 travel as 4)
+    int ups;                           // nearest x2 upsampling of a (transition up)
+    const float* saved;                // BatchNorm of the input: (mean, rstd) at parameter index (ci + rot) % rot_n, or null = raw input
+    const float* gamma;
+    const float* beta;
+    int rot, rot_n;
+    const uint16_t* g;                 // prepared gradient of the convolution's output
+    int64_t g_ns;
+    int g_blk;
+    int gc0, cout;
+    const uint8_t* g_idx;              // 1 x 1 only: g is the POOLED gradient ([h / 2][w / 2]) and g_idx the forward max-pool codes
+    float* partial;                    // [gridDim.x][co groups][9][16][ci_pad] fp32
+    int ci_pad;                        // cin rounded up to 16
+};
+
+// KS = 3: grid (blocks, ci groups of 192, cout groups of 16); KS = 1: grid (blocks, ci groups of 192, cout groups of 144)
+template <int KS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) bf16_wgrad_kernel(const Wgrad16Params p) {
+    constexpr int kGBytes = KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
+    unsigned char* s_a = smem_wg;                                       // [192][4 rows][32 px] bf16, pitch kWgPitchA
+    unsigned char* s_g = s_a + kWgCi * kWgPitchA;
+    float* s_bn = reinterpret_cast<float*>(s_g + kGBytes);              // [192][2] (scale, shift)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int ci0 = blockIdx.y * kWgCi;
+    const int cin_g = p.cin - ci0 < kWgCi ? p.cin - ci0 : kWgCi;       // this block's input channels
+    const int units_c = (cin_g + 7) >> 3;                               // 8-channel units per pixel
+    const int ntiles_ci = (cin_g + 15) >> 4;
+    const int co0 = blockIdx.z * (KS == 3 ? 16 : kWgCo1);
+    const int cout_g = p.cout - co0 < (KS == 3 ? 16 : kWgCo1) ? p.cout - co0 : (KS == 3 ? 16 : kWgCo1);
+    const int a_plane = p.a_h * p.a_w;
+    const int g_h = p.g_idx ? p.h >> 1 : p.h, g_w = p.g_idx ? p.w >> 1 : p.w;
+    const int g_plane = g_h * g_w;
+
+    for (int c = tid; c < kWgCi; c += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (p.saved && c < cin_g) {
+            const int pc = rot_index(ci0 + c, p.rot, p.rot_n);
+            sc = p.gamma[pc] * p.saved[2 * pc + 1];
+            sh = fmaf(-p.saved[2 * pc], sc, p.beta[pc]);
+        }
+        s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
+    }
+
+    f32x4_t acc[9][3];
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[f][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int tiles_x = (p.w + kWgCols - 1) / kWgCols, tiles_y = (p.h + kWgRows - 1) / kWgRows;
+    const int total = tiles_x * tiles_y * p.n;
+    for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+        const int n = tile / (tiles_x * tiles_y);
+        const int rem = tile - n * tiles_x * tiles_y;
+        const int y0 = (rem / tiles_x) * kWgRows, x0 = (rem % tiles_x) * kWgCols;
+        __syncthreads();          // the previous tile's fragment reads (and, the first time, s_bn)
+        // ---- G ----
+        if constexpr (KS == 3) {
+            const int quads = (cout_g + 3) >> 2;
+            for (int it = tid; it < (kWgRows + 2) * (kWgCols + 2) * quads; it += 256) {
+                const int q = it % quads, px = it / quads;
+                const int ry = px / (kWgCols + 2), rx = px - ry * (kWgCols + 2);          // tile pixel (ry - 1, rx - 1)
+                const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+                u32x2_t v = u32x2_t{0u, 0u};
+                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
+                    v = *reinterpret_cast<const u32x2_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 4 * q, static_cast<int64_t>(gy) * p.w + gx, g_plane, p.g_blk));
+                const uint16_t e[4] = {static_cast<uint16_t>(v[0] & 0xffffu), static_cast<uint16_t>(v[0] >> 16), static_cast<uint16_t>(v[1] & 0xffffu),
+                                       static_cast<uint16_t>(v[1] >> 16)};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int x = rx - 1 + kx - 1;          // copy kx holds G[x - kx + 1] at x
+                    if (x < 0 || x >= kWgCols) continue;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<uint16_t*>(s_g + (4 * q + i) * kWgPitchG3 + (ry * 3 + kx) * 64 + x * 2) = e[i];
+                }
+            }
+        } else {
+            const int units_g = (cout_g + 7) >> 3;
+            for (int it = tid; it < kWgRows * kWgCols * units_g; it += 256) {
+                const int k = it % units_g, px = it / units_g;
+                const int ry = px >> 5, rx = px & 31;
+                const int gy = y0 + ry, gx = x0 + rx;
+                u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+                if (gx < p.w && gy < p.h) {
+                    if (p.g_idx) {
+                        const int64_t pp = static_cast<int64_t>(gy >> 1) * g_w + (gx >> 1);
+                        v = *reinterpret_cast<const u32x4_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 8 * k, pp, g_plane, p.g_blk));
+                        const u32x2_t cw = *reinterpret_cast<const u32x2_t*>(p.g_idx + (static_cast<int64_t>(n) * g_plane + pp) * p.cout + co0 + 8 * k);
+                        const unsigned pos = ((gy & 1) << 1) | (gx & 1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const unsigned c2 = cw[j >> 1] >> (16 * (j & 1));
+                            v[j] &= (((c2 & 0xffu) == pos) ? 0x0000ffffu : 0u) | ((((c2 >> 8) & 0xffu) == pos) ? 0xffff0000u : 0u);
+                        }
+                    } else {
+                        v = *reinterpret_cast<const u32x4_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 8 * k, static_cast<int64_t>(gy) * p.w + gx, g_plane, p.g_blk));
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    *reinterpret_cast<uint16_t*>(s_g + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(v[j] & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(s_g + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(v[j] >> 16);
+                }
+            }
+        }
+        // ---- a: relu(bn(x)) of the tile's own pixels, transposed to [channel][row][px]; u = ((k_hi * 128 + px) * 4 + k_lo), unit k_hi * 4 + k_lo ----
+        const int units_hi = (units_c + 3) >> 2;
+        for (int it = tid; it < units_hi * 512; it += 256) {
+            const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
+            if (k >= units_c) continue;
+            const int ry = px >> 5, rx = px & 31;
+            const int gy = y0 + ry, gx = x0 + rx;
+            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
+            const bool ok = gx < p.w && gy < p.h;
+            if (ok) {
+                const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+                v = *reinterpret_cast<const u32x4_t*>(p.a + n * p.a_ns + blk_off(p.ac0 + ci0 + 8 * k, static_cast<int64_t>(sy) * p.a_w + sx, a_plane, p.a_blk));
+            }
+            float z[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { z[2 * j] = bf16_lo(v[j]); z[2 * j + 1] = bf16_hi(v[j]); }
+            if (p.saved) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(s_bn + 2 * (8 * k + 2 * j));
+                    z[2 * j] = ok ? fmaxf(fmaf(z[2 * j], q[0], q[1]), 0.f) : 0.f;
+                    z[2 * j + 1] = ok ? fmaxf(fmaf(z[2 * j + 1], q[2], q[3]), 0.f) : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned pk = pack_bf16x2(z[2 * j], z[2 * j + 1]);
+                *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk & 0xffffu);
+                *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk >> 16);
+            }
+        }
+        __syncthreads();
+        // ---- this wave's ci tiles 3 wave .. 3 wave + 2, one k-step per tile row ----
+        if (3 * wave < ntiles_ci) {
+#pragma unroll
+            for (int row = 0; row < kWgRows; ++row) {
+                bf16x8_t b[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const bf16x8_t*>(s_a + (16 * (3 * wave + t) + li) * kWgPitchA + row * 64 + lk * 16);
+#pragma unroll
+                for (int f = 0; f < 9; ++f) {
+                    bf16x8_t a;
+                    if constexpr (KS == 3) a = *reinterpret_cast<const bf16x8_t*>(s_g + li * kWgPitchG3 + ((row - f / 3 + 2) * 3 + f % 3) * 64 + lk * 16);
+                    else a = *reinterpret_cast<const bf16x8_t*>(s_g + (16 * f + li) * kWgPitchA + row * 64 + lk * 16);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[t], acc[f][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- partial sums of the block: [block][cout group][f][16][ci_pad], lane = (ci = li of its tile, 4 couts 4 lk ..) ----
+    float* dst = p.partial + ((static_cast<int64_t>(blockIdx.x) * gridDim.z + blockIdx.z) * 9) * 16 * p.ci_pad;
+#pragma unroll
+    for (int f = 0; f < 9; ++f)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int ci = ci0 + 16 * (3 * wave + t) + li;
+            if (3 * wave + t >= ntiles_ci || ci >= p.ci_pad) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[(static_cast<int64_t>(f) * 16 + 4 * lk + i) * p.ci_pad + ci] = acc[f][t][i];
+        }
+}
+
+// dW[co][(ci + rot) % rot_n][tap] += sum over blocks of partial; KS = 3: co = 16 z + r, tap = f; KS = 1: co = 144 z + 16 f + r.
+// grid.y splits the blocks into slices of 64 (one fp32 atomic per element and slice): a single thread walking 512 partials is a chain
+// of 512 dependent loads
+__global__ void __launch_bounds__(256) bf16_wgrad_reduce_kernel(const float* __restrict__ partial, int blocks, int co_groups, int ci_pad, int cin, int cout,
+                                                                int ks, int rot, int rot_n, float* __restrict__ dw, int cin_w) {
+    const int64_t per_block = static_cast<int64_t>(co_groups) * 9 * 16 * ci_pad;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < per_block; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int ci = e % ci_pad;
+        int64_t rest = e / ci_pad;
+        const int r = rest & 15; rest >>= 4;
+        const int f = rest % 9, z = rest / 9;
+        const int co = ks == 3 ? 16 * z + r : kWgCo1 * z + 16 * f + r;
+        if (ci >= cin_w || co >= cout) continue;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = blockIdx.y * 64;
+        const int b_end = b + 64 < blocks ? b + 64 : blocks;
+        for (; b + 3 < b_end; b += 4) {
+            s0 += partial[b * per_block + e]; s1 += partial[(b + 1) * per_block + e];
+            s2 += partial[(b + 2) * per_block + e]; s3 += partial[(b + 3) * per_block + e];
+        }
+        for (; b < b_end; ++b) s0 += partial[b * per_block + e];
+        const int pci = rot_index(ci, rot, rot_n);
+        atomicAdd(ks == 3 ? dw + (static_cast<int64_t>(co) * cin_w + pci) * 9 + f : dw + static_cast<int64_t>(co) * cin_w + pci, (s0 + s1) + (s2 + s3));
+    }
+}
+
+template <int KS>
+inline size_t bf16_wgrad_smem() {
+    return static_cast<size_t>(kWgCi) * kWgPitchA + (KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA) + sizeof(float) * 2 * kWgCi;
+}
+
+// blocks of the walk over tiles, the partial buffer a launch needs (floats) and the launch itself
+inline int bf16_wgrad_blocks(const Wgrad16Params& p, int ks) {
+    const int tiles = ((p.w + kWgCols - 1) / kWgCols) * ((p.h + kWgRows - 1) / kWgRows) * p.n;
+    const int ci_groups = (p.cin + kWgCi - 1) / kWgCi, co_groups = ks == 3 ? (p.cout + 15) / 16 : (p.cout + kWgCo1 - 1) / kWgCo1;
+    int blocks = (ks == 3 ? 512 : 256) / (ci_groups * co_groups);
+    // (fewer, longer-running blocks at the coarse levels -- at least 8 tiles each -- halve the reduction but leave most CUs idle:
+    // measured 11.7 vs 8.3 ms per step for the two kernels together, profiles/r03_r)
+    blocks = blocks < 1 ? 1 : blocks;
+    return blocks < tiles ? blocks : tiles;
+}
+inline int64_t bf16_wgrad_partial_floats(int cin, int cout, int ks, int blocks) {
+    const int64_t ci_pad = (cin + 15) / 16 * 16, co_groups = ks == 3 ? (cout + 15) / 16 : (cout + kWgCo1 - 1) / kWgCo1;
+    return blocks * co_groups * 9 * 16 * ci_pad;
+}
+
+template <int KS>
+inline int launch_bf16_wgrad(Wgrad16Params p, float* dw, hipStream_t stream) {
+    if ((p.cin & 3) || (p.cout & 3) || (p.ac0 & 7) || (p.gc0 & 3) || (p.a_blk & 7) || (p.g_blk & 3)) return ENDO_E_BADARG;
+    if (KS == 1 && ((p.cout & 7) || (p.gc0 & 7))) return ENDO_E_BADARG;
+    p.ci_pad = (p.cin + 15) / 16 * 16;
+    const int blocks = bf16_wgrad_blocks(p, KS);
+    const int ci_groups = (p.cin + kWgCi - 1) / kWgCi, co_groups = KS == 3 ? (p.cout + 15) / 16 : (p.cout + kWgCo1 - 1) / kWgCo1;
+    const size_t smem = bf16_wgrad_smem<KS>();
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_wgrad_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+    bf16_wgrad_kernel<KS><<<dim3(blocks, ci_groups, co_groups), 256, smem, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    const int64_t per_block = static_cast<int64_t>(co_groups) * 9 * 16 * p.ci_pad;
+    bf16_wgrad_reduce_kernel<<<dim3(static_cast<int>((per_block + 255) / 256), (blocks + 63) / 64), 256, 0, stream>>>(p.partial, blocks, co_groups, p.ci_pad, p.cin, p.cout, KS, p.rot,
+                                                                                            p.rot_n, dw, p.cin_w > 0 ? p.cin_w : p.cin);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace endo

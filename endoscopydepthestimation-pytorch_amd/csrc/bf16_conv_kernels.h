@@ -76,7 +76,19 @@ struct Conv16Params {
     // POOL epilogue (transition down, models.py:64: MaxPool2d(2)): out is the (h / 2) x (w / 2) grid; out_idx: one byte per pooled
     // value, [n][h / 2][w / 2][cout], the position 2 dy + dx of the maximum inside its window (first maximum in row-major order)
     uint8_t* out_idx;
+    // ---- backward use (EPI 2 / 3, UNPOOL): the convolution runs over a GRADIENT buffer with the transposed, flipped weights ----
+    // EPI_DGRAD_BN (dense layer / transition down, reference models.py:22-25 differentiated): out is the gradient buffer of the layer's
+    // INPUT channels, x their forward values (same geometry and channel positions as out); da = [x * scale + shift > 0] * dz;
+    // out += scale * da (read-modify-write); out_sums[ci] += (sum da, sum da * x).  scale / shift of output channel ci come from
+    // x_saved / gamma / beta at parameter index (ci + rot) % rot_n (as in the forward pass, bit for bit).
+    const uint16_t* x;
+    const float* x_saved;            // [cin of the layer][2] (mean, rstd)
+    // UNPOOL input (transition down backward): `in` is the pooled-resolution gradient (ups = 1 addressing) and a full-resolution pixel
+    // takes a channel's value only where in_idx ([n][h / 2][w / 2][cin] bytes, the forward pass's out_idx) names its position
+    const uint8_t* in_idx;
 };
+
+constexpr int kEpiFwd = 0, kEpiPool = 1, kEpiDgradBn = 2, kEpiSumPool = 3;
 
 __device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
@@ -91,7 +103,9 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
 template <int COLS>
 __device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row * COLS + x) * 4 + (part ^ ((x >> 1) & 3))) * 16; }
 
-// KS = 3 (pad 1) or 1; NT = 16-cout tiles per block (grid.y covers ceil(cout / (16 NT)) of them); POOL = 1: 2 x 2 max-pool epilogue
+// KS = 3 (pad 1) or 1; NT = 16-cout tiles per block (grid.y covers ceil(cout / (16 NT)) of them); EPI: kEpiFwd store, kEpiPool 2 x 2
+// max-pool + codes, kEpiDgradBn ReLU / BatchNorm backward into the gradient buffer, kEpiSumPool 2 x 2 sum added into the coarser
+// gradient buffer (transition up backward); UNPOOL = 1: max-unpooling of the input on the way in
 // WAVES = waves per block (4 or 8): the 16 tile rows are dealt R = 16 / WAVES to a wave; 8 waves halve the registers a thread needs
 // for its share of the staged loads.  WPE = waves per SIMD the register allocation must leave room for.
 //
@@ -99,7 +113,7 @@ __device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row 
 // tile order, statistics flushed once per block) was built and measured: no faster at equal occupancy and 60 registers over the
 // 128-register budget of two 8-wave blocks per CU (profiles/r03_o_bf16_conv_variants.txt); not kept.
 // EXP: diagnostic masks of tools/bf16_conv_variants (1 = no matrix phase, 2 = no activation loads, 4 = no BatchNorm arithmetic and LDS stage writes); 0 in the product
-template <int KS, int NT, int POOL = 0, int WAVES = 8, int WPE = 4, int EXP = 0>
+template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE))) bf16_conv_kernel(const Conv16Params p) {
     constexpr int kThreads = 64 * WAVES;
     constexpr int R = kBfTileY / WAVES;
@@ -111,11 +125,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     constexpr int kTaps = KS * KS;
     constexpr int kWUnits = kTaps * NT * 16 * 4;                       // 16-byte units of a chunk's weight slice
     constexpr int kWIter = (kWUnits + kThreads - 1) / kThreads;
+    constexpr bool QUADS = EPI == kEpiDgradBn && UNPOOL == 0;          // the input run starts at a multiple of 4 channels, not of 8
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     unsigned char* s_act = smem16;                                     // [kRows][kCols][4 slots][16 B]
     unsigned char* s_w = s_act + kPix * 64;                            // [tap][nt][16 cout][4 slots][16 B]
-    float* s_bn = reinterpret_cast<float*>(s_w + kWUnits * 16);        // [cin padded to 32][2]
-    float* s_red = s_bn;                                               // reused after the K loop: [WAVES][NT * 16][2]
+    float* s_bn = reinterpret_cast<float*>(s_w + kWUnits * 16);        // [max(cin padded to 32, NT * 16)][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -125,10 +139,24 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const int tiles_img = tiles_x * tiles_y;
     const int co_base = blockIdx.y * NT * 16;
     const int nchunks = (p.cin + kBfKC - 1) / kBfKC;
+    float* s_red = s_bn + 2 * (nchunks * kBfKC > NT * 16 ? nchunks * kBfKC : NT * 16);          // [WAVES][NT * 16][2]
     const int in_plane = p.in_h * p.in_w;
 
-    const bool has_bn = p.bn != nullptr || p.use_stats != 0;
     const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const bool has_bn = EPI != kEpiDgradBn && (p.bn != nullptr || p.use_stats != 0);
+    if constexpr (EPI == kEpiDgradBn) {
+        // (scale, shift) of this block's NT * 16 output channels = input channels of the differentiated layer
+        for (int c = tid; c < NT * 16; c += kThreads) {
+            const int ci = co_base + c;
+            float sc = 0.f, sh = 0.f;
+            if (ci < p.cout) {
+                const int pc = ci < p.rot_n ? (ci + p.rot < p.rot_n ? ci + p.rot : ci + p.rot - p.rot_n) : ci;
+                sc = p.gamma[pc] * p.x_saved[2 * pc + 1];
+                sh = fmaf(-p.x_saved[2 * pc], sc, p.beta[pc]);
+            }
+            s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
+        }
+    } else
     for (int c = tid; c < nchunks * kBfKC; c += kThreads) {
         float sc = 0.f, sh = 0.f;
         if (c < p.cin) {
@@ -191,18 +219,38 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     };
 
     u32x4_t raw[kIter];
+    u32x2_t craw[UNPOOL ? kIter : 1];
     u32x4_t wraw[kWIter];
     auto issue_loads = [&](int chunk, int n, const int (&off)[kIter]) {
         // the thread's 8 channels of this chunk: block and position inside the block
         const int cpart = chunk * kBfKC + (tid & 3) * 8;
         const int cb = (p.ic0 + cpart) / p.in_blk;
         const uint16_t* base = p.in + n * p.in_ns + static_cast<int64_t>(cb) * in_plane * p.in_blk + (p.ic0 + cpart - cb * p.in_blk);
+        if constexpr (QUADS) {
+            // ic0 is a multiple of 4 only (a dense layer's 12 maps start at multiples of 12): the unit is read as two 4-channel halves,
+            // each inside one channel block
+            const int cb1 = (p.ic0 + cpart + 4) / p.in_blk;
+            const uint16_t* base1 = p.in + n * p.in_ns + static_cast<int64_t>(cb1) * in_plane * p.in_blk + (p.ic0 + cpart + 4 - cb1 * p.in_blk);
+#pragma unroll
+            for (int i = 0; i < kIter; ++i) {
+                raw[i] = u32x4_t{0u, 0u, 0u, 0u};
+                if (off[i] >= 0) {
+                    if (cpart < p.cin) { const u32x2_t h0 = *reinterpret_cast<const u32x2_t*>(base + off[i]); raw[i][0] = h0[0]; raw[i][1] = h0[1]; }
+                    if (cpart + 4 < p.cin) { const u32x2_t h1 = *reinterpret_cast<const u32x2_t*>(base1 + off[i]); raw[i][2] = h1[0]; raw[i][3] = h1[1]; }
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < kIter; ++i) {
             raw[i] = u32x4_t{0u, 0u, 0u, 0u};
             if ((EXP & 2) == 0 && off[i] >= 0) {
                 // the last unit of the last chunk may straddle cin: it is read as far as the layer goes and the rest stays zero
                 const uint16_t* src = base + off[i];
+                if constexpr (UNPOOL != 0) {          // cin is a multiple of 8 here; off / in_blk = the pooled pixel
+                    craw[i] = u32x2_t{0xffffffffu, 0xffffffffu};
+                    if (cpart + 8 <= p.cin)
+                        craw[i] = *reinterpret_cast<const u32x2_t*>(p.in_idx + (static_cast<int64_t>(n) * in_plane + off[i] / p.in_blk) * p.cin + cpart);
+                }
                 if (cpart + 8 <= p.cin) raw[i] = *reinterpret_cast<const u32x4_t*>(src);
                 else if (cpart < p.cin) {          // cin is a multiple of 4: the unit holds 4 valid channels
                     const u32x2_t half = *reinterpret_cast<const u32x2_t*>(src);
@@ -231,6 +279,17 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         for (int i = 0; i < kIter; ++i) {
             if (u_dst[i] < 0 || (EXP & 4) != 0) continue;
             u32x4_t v = raw[i];
+            if constexpr (UNPOOL != 0) {
+                static_assert(UNPOOL == 0 || KS == 1, "max-unpooling is staged for 1 x 1 convolutions");
+                const int px = (tid + i * kThreads) >> 2;
+                const unsigned pos = (((px >> 5) & 1) << 1) | (px & 1);          // tile origins are even: the pixel's place in its window
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned cw = craw[i][k >> 1] >> (16 * (k & 1));
+                    const unsigned keep = (((cw & 0xffu) == pos) ? 0x0000ffffu : 0u) | ((((cw >> 8) & 0xffu) == pos) ? 0xffff0000u : 0u);
+                    v[k] &= keep;
+                }
+            }
             if (has_bn) {
                 if (u_off[i] >= 0) {
 #pragma unroll
@@ -262,7 +321,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { s1[t][i] = 0.f; s2[t][i] = 0.f; }
-    const int64_t out_plane = POOL != 0 ? static_cast<int64_t>(p.h >> 1) * (p.w >> 1) : static_cast<int64_t>(p.h) * p.w;
+    constexpr bool POOLED = EPI == kEpiPool || EPI == kEpiSumPool;
+    const int64_t out_plane = POOLED ? static_cast<int64_t>(p.h >> 1) * (p.w >> 1) : static_cast<int64_t>(p.h) * p.w;
 
     __syncthreads();          // s_bn
     const int n = blockIdx.z;
@@ -314,7 +374,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             const int ca = p.oc0 + co, cb = ca / p.out_blk;
             return out_n + (cb * out_plane + pix) * p.out_blk + (ca - cb * p.out_blk);
         };
-        if constexpr (POOL != 0) {
+        if constexpr (EPI == kEpiPool) {
             // 2 x 2 max pool of the accumulators: rows 2 rp, 2 rp + 1 of the lane, columns li (even) and li + 1 (the neighbouring lane)
             const int hp = p.h >> 1, wp = p.w >> 1;
 #pragma unroll
@@ -350,6 +410,86 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
                     }
                 }
+        } else if constexpr (EPI == kEpiSumPool) {
+            // 2 x 2 sums of the accumulators added into the coarser gradient buffer (nearest x2 upsampling differentiated)
+            const int hp = p.h >> 1, wp = p.w >> 1;
+#pragma unroll
+            for (int rp = 0; rp < R / 2; ++rp)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int yp = (y0 >> 1) + (R / 2) * wave + rp, xp = (x0 + 16 * hh + li) >> 1;
+                    const bool pix_ok = yp < hp && xp < wp && (li & 1) == 0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const int co = co_base + 16 * t + 4 * lk;
+                        float sum[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float v = acc[2 * rp][hh][t][i] + acc[2 * rp + 1][hh][t][i];
+                            sum[i] = v + __shfl_xor(v, 1, 64);
+                        }
+                        if (co >= p.cout || !pix_ok) continue;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s1[t][i] += sum[i];          // out_sums: the pixel sum of what is added (fp32, unrounded)
+                        uint16_t* dst = out_ptr(static_cast<int64_t>(yp) * wp + xp, co);
+                        const u32x2_t old = *reinterpret_cast<const u32x2_t*>(dst);
+                        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_bf16x2(bf16_lo(old[0]) + sum[0], bf16_hi(old[0]) + sum[1]),
+                                                                    pack_bf16x2(bf16_lo(old[1]) + sum[2], bf16_hi(old[1]) + sum[3])};
+                    }
+                }
+        } else if constexpr (EPI == kEpiDgradBn) {
+            // all of the lane's reads first (forward values and old gradients of its R x 2 x NT quads), then the arithmetic and the
+            // stores: with one block of 8 waves per CU the memory-level parallelism has to come from inside the wave
+            const uint16_t* x_n = p.x + n * p.out_ns;
+            int64_t offs[R][2];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int y = y0 + R * wave + r, x = x0 + 16 * hh + li;
+                    offs[r][hh] = (y < p.h && x < p.w) ? static_cast<int64_t>(y) * p.w + x : -1;
+                }
+            u32x2_t xv[NT][R][2], old[NT][R][2];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co_base + 16 * t + 4 * lk;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        xv[t][r][hh] = u32x2_t{0u, 0u}; old[t][r][hh] = u32x2_t{0u, 0u};
+                        if (co < p.cout && offs[r][hh] >= 0) {
+                            const int64_t o = out_ptr(offs[r][hh], co) - out_n;
+                            xv[t][r][hh] = *reinterpret_cast<const u32x2_t*>(x_n + o);
+                            old[t][r][hh] = *reinterpret_cast<const u32x2_t*>(out_n + o);
+                        }
+                    }
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int co = co_base + 16 * t + 4 * lk;
+                if (co >= p.cout) continue;
+                const f32x4_t q0 = *reinterpret_cast<const f32x4_t*>(s_bn + 2 * (16 * t + 4 * lk));
+                const f32x4_t q1 = *reinterpret_cast<const f32x4_t*>(s_bn + 2 * (16 * t + 4 * lk) + 4);
+                const float sc[4] = {q0[0], q0[2], q1[0], q1[2]}, sh[4] = {q0[1], q0[3], q1[1], q1[3]};
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        if (offs[r][hh] < 0) continue;
+                        const u32x2_t xq = xv[t][r][hh], oq = old[t][r][hh];
+                        const float xf[4] = {bf16_lo(xq[0]), bf16_hi(xq[0]), bf16_lo(xq[1]), bf16_hi(xq[1])};
+                        const float of[4] = {bf16_lo(oq[0]), bf16_hi(oq[0]), bf16_lo(oq[1]), bf16_hi(oq[1])};
+                        float nw[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float da = fmaf(xf[i], sc[i], sh[i]) > 0.f ? acc[r][hh][t][i] : 0.f;
+                            s1[t][i] += da; s2[t][i] = fmaf(da, xf[i], s2[t][i]);
+                            nw[i] = fmaf(sc[i], da, of[i]);
+                        }
+                        *reinterpret_cast<u32x2_t*>(out_ptr(offs[r][hh], co)) = u32x2_t{pack_bf16x2(nw[0], nw[1]), pack_bf16x2(nw[2], nw[3])};
+                    }
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -414,22 +554,23 @@ inline size_t bf16_conv_smem(int cin) {
     constexpr int kHalo = KS / 2;
     constexpr int kPix = (kBfTileY + 2 * kHalo) * (kBfTileX + 2 * kHalo);
     const int cpad = (cin + kBfKC - 1) / kBfKC * kBfKC;
-    const size_t bn = sizeof(float) * 2 * cpad, red = sizeof(float) * WAVES * NT * 16 * 2;
-    return static_cast<size_t>(kPix) * 64 + static_cast<size_t>(KS * KS * NT) * 16 * 64 + (bn > red ? bn : red);
+    const size_t bn = sizeof(float) * 2 * (cpad > NT * 16 ? cpad : NT * 16), red = sizeof(float) * WAVES * NT * 16 * 2;
+    return static_cast<size_t>(kPix) * 64 + static_cast<size_t>(KS * KS * NT) * 16 * 64 + bn + red;
 }
 
-template <int KS, int NT, int POOL = 0, int WAVES = 8, int WPE = 4, int EXP = 0>
+template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0>
 inline int launch_bf16_conv(const Conv16Params& p_, hipStream_t stream) {
     Conv16Params p = p_;
     if (p.in_blk <= 0) p.in_blk = p.in_t;
     if (p.out_blk <= 0) p.out_blk = p.out_t;
-    if ((p.in_blk & 7) || (p.out_blk & 3) || (p.ic0 & 7) || (p.oc0 & 3) || p.in_t % p.in_blk || p.out_t % p.out_blk) return ENDO_E_BADARG;
+    constexpr bool QUADS = EPI == kEpiDgradBn && UNPOOL == 0;
+    if ((p.in_blk & 7) || (p.out_blk & 3) || (p.ic0 & (QUADS ? 3 : 7)) || (p.oc0 & 3) || p.in_t % p.in_blk || p.out_t % p.out_blk) return ENDO_E_BADARG;
     const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kBfTileY - 1) / kBfTileY);
     const int ngroups = (p.cout + NT * 16 - 1) / (NT * 16);
     const size_t smem = bf16_conv_smem<KS, NT, WAVES>(p.cin);
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, POOL, WAVES, WPE, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(smem)));
-    bf16_conv_kernel<KS, NT, POOL, WAVES, WPE, EXP><<<dim3(tiles, ngroups, p.n), 64 * WAVES, smem, stream>>>(p);
+    bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL><<<dim3(tiles, ngroups, p.n), 64 * WAVES, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "bf16_conv_kernels.h"
+#include "bf16_bwd_kernels.h"
 
 extern "C" int64_t endo_net_param_offset(int index);
 extern "C" int64_t endo_net_bn_offset(int bn_index, int which);
@@ -25,7 +26,8 @@ inline int c16_level_channels(int level) {
     return (c + k16Blk - 1) / k16Blk * k16Blk;
 }
 
-struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; int rot, rot_n; };      // w16: element offset of the converted weights
+// w16 / w16d: element offsets of the forward / data-gradient (transposed, flipped; -1 = none) bf16 weights
+struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; int rot, rot_n; int64_t w16d; };      // w16: element offset of the converted weights
 struct Bn16 { int64_t g, b; int c; int64_t run_mean, run_var; int64_t saved; };
 
 // the reference's module order (models.py:100-170, the order of .parameters()): offsets come from the fp32 family's own table
@@ -34,7 +36,9 @@ struct Table16 {
     Conv16 down_conv[k16Levels][k16Layers], td_conv[k16Levels], bott_conv[k16Layers], tu_conv[k16Levels], up_conv[k16Levels][k16Layers];
     Bn16 down_bn[k16Levels][k16Layers], td_bn[k16Levels], bott_bn[k16Layers], up_bn[k16Levels][k16Layers];
     std::vector<Conv16*> convs;
-    int64_t w16_elems = 0, saved_floats = 0;
+    int64_t w16_elems = 0, w16d_elems = 0, saved_floats = 0;
+    std::vector<Conv16*> dconvs;          // the convolutions with a data gradient (all but the first)
+    std::vector<Bn16*> bns;               // module order
 };
 
 static const Table16& table16() {
@@ -45,7 +49,13 @@ static const Table16& table16() {
         auto conv = [&](Conv16& c, int cout, int cin, int ks, bool mfma) {
             c.cout = cout; c.cin = cin; c.ks = ks; c.nt = cout <= 16 ? 1 : 3;
             c.w = endo_net_param_offset(pi++); c.b = endo_net_param_offset(pi++);
-            c.w16 = -1; c.rot = 0; c.rot_n = 0;
+            c.w16 = -1; c.rot = 0; c.rot_n = 0; c.w16d = -1;
+            if (mfma && cin >= 4) {          // as a convolution over the gradient: cout' = cin (48-wide groups), K = cout
+                c.w16d = tb->w16d_elems;
+                const int64_t groups = (cin + 47) / 48, chunks = (cout + kBfKC - 1) / kBfKC;
+                tb->w16d_elems += chunks * groups * ks * ks * 3 * 16 * 32;
+                tb->dconvs.push_back(&c);
+            }
             if (mfma) {
                 const int cin_k = cin < 4 ? 4 : cin;          // the first convolution's 3 input channels travel as 4 (+ 4 zero) of an 8-channel record
                 c.w16 = tb->w16_elems;
@@ -59,6 +69,7 @@ static const Table16& table16() {
             b.g = endo_net_param_offset(pi++); b.b = endo_net_param_offset(pi++);
             b.run_mean = endo_net_bn_offset(bi, 0); b.run_var = endo_net_bn_offset(bi, 1); ++bi;
             b.saved = saved; saved += 2 * c;
+            tb->bns.push_back(&b);
         };
         conv(tb->first, k16First, 3, 3, true);
         for (int l = 0; l < k16Levels; ++l)
@@ -88,6 +99,7 @@ struct W16Table {
     int64_t start[64];          // prefix sum of output elements
     int64_t w[63], out[63];
     int cout[63], cin[63], cin_k[63], ks[63], nt[63], rot[63], rot_n[63];
+    int dgrad;          // 1: data-gradient form: row = input channel of the layer, k = its cout, taps flipped
 };
 
 __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t, const float* __restrict__ params, uint16_t* __restrict__ w16) {
@@ -106,8 +118,13 @@ __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t,
         const int chunk = rest / ngroups;
         const int co = (grp * nt + tt) * 16 + co16, ci = chunk * kBfKC + k;
         float v = 0.f;
-        const int pci = ci < t.rot_n[l] ? (ci + t.rot[l] < t.rot_n[l] ? ci + t.rot[l] : ci + t.rot[l] - t.rot_n[l]) : ci;
-        if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + pci) * taps + tap];
+        if (t.dgrad) {          // here cout[l] / cin[l] are the CONVOLUTION's: rows = the layer's input channels, k = the layer's couts
+            const int pco = co < t.rot_n[l] ? (co + t.rot[l] < t.rot_n[l] ? co + t.rot[l] : co + t.rot[l] - t.rot_n[l]) : co;
+            if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(ci) * t.cout[l] + pco) * taps + (taps - 1 - tap)];
+        } else {
+            const int pci = ci < t.rot_n[l] ? (ci + t.rot[l] < t.rot_n[l] ? ci + t.rot[l] : ci + t.rot[l] - t.rot_n[l]) : ci;
+            if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + pci) * taps + tap];
+        }
         w16[t.out[l] + e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
     }
 }
@@ -251,6 +268,21 @@ struct endo_net16 {
     int64_t sums_off, sums_bytes;
     int64_t w16_off;           // bytes
     int64_t tape_bytes;
+    // backward workspace (endo_net16_bwd): gradient buffers with the geometry of the level buffers, the deferred BatchNorm terms P, Q
+    // per level channel, the BatchNorm backward sums per layer, the data-gradient weights, the weight-gradient partials
+    int64_t ws_d[k16Levels + 1];          // bytes
+    int64_t ws_pq[k16Levels + 1];         // bytes: floats [2][t]
+    int64_t ws_bnsums;                    // bytes: doubles, layer at its `saved` offset
+    int64_t ws_gsum[k16Levels + 1];       // bytes: doubles [t][2], pixel sums of the total gradient per level channel (bf16_prep_dy_kernel)
+    int64_t ws_zero_begin, ws_zero_end;   // everything but the level-0 gradient buffer starts at zero
+    int64_t ws_w16d;                      // bytes
+    int64_t ws_partial;                   // bytes
+    int64_t ws_bytes;
+    // the weight gradients read only finished tensors (forward activations, a prepared gradient range) and nothing waits for them but
+    // the optimizer: they run on a side stream, forked after every prep_dy and joined once at the end (as in the fp32 family)
+    hipStream_t wstream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int use_wstream = 0;
 };
 
 extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
@@ -274,11 +306,62 @@ extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
     net->sums_off = off; net->sums_bytes = sums * 8; off += align(net->sums_bytes);
     net->w16_off = off; off += align(tb.w16_elems * 2);
     net->tape_bytes = off;
+    {
+        int64_t o = 0;
+        net->ws_d[0] = o; o += align(static_cast<int64_t>(n) * net->lv[0].plane * net->lv[0].t * 2);
+        net->ws_zero_begin = o;
+        for (int l = 1; l <= k16Levels; ++l) { net->ws_d[l] = o; o += align(static_cast<int64_t>(n) * net->lv[l].plane * net->lv[l].t * 2); }
+        for (int l = 0; l <= k16Levels; ++l) { net->ws_pq[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 4); }
+        net->ws_bnsums = o; o += align(tb.saved_floats * 8);
+        for (int l = 0; l <= k16Levels; ++l) { net->ws_gsum[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 8); }
+        net->ws_zero_end = o;
+        net->ws_w16d = o; o += align(tb.w16d_elems * 2);
+        int64_t need = 0;
+        auto wg = [&](int level, int cin, int cout, int ks) {
+            Wgrad16Params q{};
+            q.n = n; q.h = net->lv[level].h; q.w = net->lv[level].w; q.cin = cin; q.cout = cout;
+            const int64_t f = bf16_wgrad_partial_floats(cin, cout, ks, bf16_wgrad_blocks(q, ks));
+            need = f > need ? f : need;
+        };
+        wg(0, 4, k16First, 3);
+        for (int l = 0; l < k16Levels; ++l) {
+            wg(l, c16_skip(l) + k16New + k16Growth * 3, k16Growth, 3);       // widest dense layer of the level
+            wg(l, c16_skip(l), c16_skip(l), 1);                              // transition down
+            wg(l, k16New, k16New, 3);                                        // transition up
+        }
+        wg(k16Levels, 288 + k16Growth * 3, k16Growth, 3);
+        net->ws_partial = o; o += align(need * 4);
+        net->ws_bytes = o;
+    }
     *out = net;
     return 0;
 }
-extern "C" void endo_net16_destroy(endo_net16* net) { delete net; }
+extern "C" void endo_net16_destroy(endo_net16* net) {
+    if (!net) return;
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->wstream) (void)hipStreamDestroy(net->wstream);
+    delete net;
+}
 extern "C" int64_t endo_net16_tape_bytes(const endo_net16* net) { return net ? net->tape_bytes : 0; }
+extern "C" int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net) { return net ? net->ws_bytes : 0; }
+// Where things are (tests read the forward pass's decisions and the gradient buffers): byte offsets into the tape -- what 0: final
+// pre-activation (fp32), 1: (mean, rstd) of BatchNorm layer `index` in module order (fp32), 2: max-pool codes of transition down
+// `index`, 3: level buffer `index` -- or into the backward workspace -- 4: gradient buffer of level `index`; 5: channels of level
+// buffer `index` (not an offset).  -1 for anything else.
+extern "C" int64_t endo_net16_offset(const endo_net16* net, int what, int index) {
+    if (!net || index < 0) return -1;
+    const Table16& tb = table16();
+    switch (what) {
+        case 0: return net->pre_off;
+        case 1: return index < static_cast<int>(tb.bns.size()) ? net->saved_off + tb.bns[index]->saved * 4 : -1;
+        case 2: return index < k16Levels ? net->idx_off[index] : -1;
+        case 3: return index <= k16Levels ? net->lv[index].act : -1;
+        case 4: return index <= k16Levels ? net->ws_d[index] : -1;
+        case 5: return index <= k16Levels ? net->lv[index].t : -1;
+        default: return -1;
+    }
+}
 
 namespace {
 
@@ -289,6 +372,24 @@ struct Ctx16 {
     char* tape;
     int training;
     hipStream_t stream;
+    float* grads = nullptr;          // backward: parameter gradients (accumulated), workspace
+    char* ws = nullptr;
+    uint16_t* dbuf(int level) const { return reinterpret_cast<uint16_t*>(ws + net->ws_d[level]); }
+    float* pq_p(int level) const { return reinterpret_cast<float*>(ws + net->ws_pq[level]); }
+    float* pq_q(int level) const { return pq_p(level) + net->lv[level].t; }
+    double* gsum(int level) const { return reinterpret_cast<double*>(ws + net->ws_gsum[level]); }
+    double* bnsums(const Bn16& b) const { return reinterpret_cast<double*>(ws + net->ws_bnsums) + b.saved; }
+    const uint16_t* w16d(const Conv16& c) const { return reinterpret_cast<const uint16_t*>(ws + net->ws_w16d) + c.w16d; }
+    float* partial() const { return reinterpret_cast<float*>(ws + net->ws_partial); }
+    // the side stream, after everything issued on `stream` so far
+    int fork_wgrad(hipStream_t& side) const {
+        side = net->wstream ? net->wstream : stream;
+        if (net->wstream) {
+            ENDO_CHECK(hipEventRecord(net->ev_fork, stream));
+            ENDO_CHECK(hipStreamWaitEvent(net->wstream, net->ev_fork, 0));
+        }
+        return 0;
+    }
     uint16_t* act(int level) const { return reinterpret_cast<uint16_t*>(tape + net->lv[level].act); }
     double* sums(int level) const { return reinterpret_cast<double*>(tape + net->sums_off) + net->lv[level].sums; }
     const uint16_t* w16(const Conv16& c) const { return reinterpret_cast<const uint16_t*>(tape + net->w16_off) + c.w16; }
@@ -416,6 +517,225 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
         bf16_final_fwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(c.act(0), lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w,
                                                                      params + tb.final_.b, tb.final_.rot, tb.final_.rot_n, reinterpret_cast<float*>(c.tape + net->pre_off), out);
         ENDO_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// FCDenseNet57 backward over bf16 level buffers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+int prep_dy16(const Ctx16& c, int level, int c0, int count, float* bias_grad) {
+    const auto& lv = c.net->lv[level];
+    const int ppi = 256 / (count / 4);
+    int bx = static_cast<int>((lv.plane + ppi - 1) / ppi);
+    bx = bx > 1024 ? 1024 : bx;
+    const dim3 grid = c.training ? dim3(bx, c.net->n) : dim3(1, 1);          // inference mode: only the bias gradient
+    bf16_prep_dy_kernel<<<grid, 256, 0, c.stream>>>(c.dbuf(level), c.act(level), lv.plane * lv.t, static_cast<int>(lv.plane), k16Blk, c0, count,
+                                                                  c.pq_p(level), c.pq_q(level), bias_grad, c.gsum(level), c.training);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+int bn_finalize16(const Ctx16& c, const Bn16& b, const Conv16& cv, int level) {
+    const auto& lv = c.net->lv[level];
+    bf16_bn_finalize_kernel<<<(b.c + 127) / 128, 128, 0, c.stream>>>(c.bnsums(b), c.saved(b), c.params + b.g, c.grads + b.g, c.grads + b.b, c.pq_p(level),
+                                                                     c.pq_q(level), c.gsum(level), b.c, cv.rot, cv.rot_n, static_cast<double>(c.net->n) * lv.plane, c.training);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+void fill_wgrad_a(const Ctx16& c, Wgrad16Params& p, int level, int ac0, int cin, const Bn16* b, const Conv16& cv) {
+    const auto& lv = c.net->lv[level];
+    p.a = c.act(level); p.a_ns = lv.plane * lv.t; p.a_blk = k16Blk; p.a_h = lv.h; p.a_w = lv.w; p.ac0 = ac0; p.cin = cin;
+    if (b) { p.saved = c.saved(*b); p.gamma = c.params + b->g; p.beta = c.params + b->b; }
+    p.rot = cv.rot; p.rot_n = cv.rot_n;
+    p.partial = c.partial();
+}
+
+// the data gradient of a BN -> ReLU -> conv layer: a convolution over the gradient of its outputs with the kEpiDgradBn epilogue
+void fill_dgrad(const Ctx16& c, Conv16Params& p, int g_level, int gc0, int level, const Bn16& b, const Conv16& cv) {
+    const auto& lg = c.net->lv[g_level];
+    const auto& lv = c.net->lv[level];
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.in = c.dbuf(g_level); p.in_t = lg.t; p.in_blk = k16Blk; p.in_h = lg.h; p.in_w = lg.w; p.in_ns = lg.plane * lg.t; p.ic0 = gc0; p.cin = cv.cout;
+    p.wgt = c.w16d(cv);
+    p.out = c.dbuf(level); p.out_t = lv.t; p.out_blk = k16Blk; p.out_ns = lv.plane * lv.t; p.oc0 = 0; p.cout = cv.cin;
+    p.x = c.act(level); p.x_saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
+    p.out_sums = c.bnsums(b);
+}
+
+// dense layer (reads [0, cin), wrote [oc0, oc0 + 12)): bias gradient + deferred terms, weight gradient, data gradient, BN parameters
+int dense_bwd16(const Ctx16& c, int level, int oc0, const Bn16& b, const Conv16& cv) {
+    const auto& lv = c.net->lv[level];
+    int rc = prep_dy16(c, level, oc0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    {
+        Wgrad16Params p{};
+        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+        fill_wgrad_a(c, p, level, 0, cv.cin, &b, cv);
+        p.g = c.dbuf(level); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = oc0; p.cout = cv.cout;
+        hipStream_t side;
+        rc = c.fork_wgrad(side);
+        if (rc) return rc;
+        rc = launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
+        if (rc) return rc;
+    }
+    Conv16Params p{};
+    fill_dgrad(c, p, level, oc0, level, b, cv);
+    rc = launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2>(p, c.stream);
+    if (rc) return rc;
+    return bn_finalize16(c, b, cv, level);
+}
+
+int dense_block_bwd16(const Ctx16& c, int level, int new0, const Bn16* bn, const Conv16* cv) {
+    for (int j = k16Layers - 1; j >= 0; --j) {
+        const int rc = dense_bwd16(c, level, new0 + k16Growth * j, bn[j], cv[j]);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+// transition down (level -> level + 1): reads [0, S), its pooled outputs are channels [0, S) of the next level
+int td_bwd16(const Ctx16& c, int level, const Bn16& b, const Conv16& cv) {
+    const int next = level + 1;
+    const auto& lv = c.net->lv[level];
+    const auto& nx = c.net->lv[next];
+    int rc = prep_dy16(c, next, 0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    const uint8_t* idx = reinterpret_cast<const uint8_t*>(c.tape + c.net->idx_off[level]);
+    {
+        Wgrad16Params p{};
+        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+        fill_wgrad_a(c, p, level, 0, cv.cin, &b, cv);
+        p.g = c.dbuf(next); p.g_ns = nx.plane * nx.t; p.g_blk = k16Blk; p.gc0 = 0; p.cout = cv.cout; p.g_idx = idx;
+        hipStream_t side;
+        rc = c.fork_wgrad(side);
+        if (rc) return rc;
+        rc = launch_bf16_wgrad<1>(p, c.grads + cv.w, side);
+        if (rc) return rc;
+    }
+    Conv16Params p{};
+    fill_dgrad(c, p, next, 0, level, b, cv);
+    p.ups = 1; p.in_idx = idx;
+    rc = launch_bf16_conv<1, 3, kEpiDgradBn, 8, 2, 0, 1>(p, c.stream);
+    if (rc) return rc;
+    return bn_finalize16(c, b, cv, level);
+}
+
+// transition up (src level, channels [src_c0, +48) -> level, channels [S, S + 48)): no BatchNorm, no ReLU
+int tu_bwd16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16& cv) {
+    const auto& lv = c.net->lv[level];
+    const auto& sv = c.net->lv[src_level];
+    const int oc0 = c16_skip(level);
+    int rc = prep_dy16(c, level, oc0, cv.cout, c.grads + cv.b);
+    if (rc) return rc;
+    {
+        Wgrad16Params p{};
+        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+        fill_wgrad_a(c, p, src_level, src_c0, cv.cin, nullptr, cv);
+        p.ups = 1;
+        p.g = c.dbuf(level); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = oc0; p.cout = cv.cout;
+        hipStream_t side;
+        rc = c.fork_wgrad(side);
+        if (rc) return rc;
+        rc = launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
+        if (rc) return rc;
+    }
+    Conv16Params p{};
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.in = c.dbuf(level); p.in_t = lv.t; p.in_blk = k16Blk; p.in_h = lv.h; p.in_w = lv.w; p.in_ns = lv.plane * lv.t; p.ic0 = oc0; p.cin = cv.cout;
+    p.wgt = c.w16d(cv);
+    p.out = c.dbuf(src_level); p.out_t = sv.t; p.out_blk = k16Blk; p.out_ns = sv.plane * sv.t; p.oc0 = src_c0; p.cout = cv.cin;
+    p.out_sums = c.gsum(src_level) + 2 * src_c0;
+    return launch_bf16_conv<3, 3, kEpiSumPool, 8, 2>(p, c.stream);
+}
+
+}  // namespace
+
+// Backward of endo_net16_fwd.  tape: the forward pass's tape, untouched since; grad_out: fp32 [n][1][H][W]; grads: the flat fp32
+// parameter-gradient buffer of the fp32 family (same offsets), ACCUMULATED into; ws: endo_net16_bwd_workspace_bytes() bytes, 256-byte
+// aligned.  `training` as in the forward call (0: BatchNorm as a fixed affine map, the reference's .eval() backward).  Gradients
+// between layers are stored as bf16 (fp32 accumulation inside every kernel); BatchNorm sums, parameter gradients and the deferred
+// BatchNorm terms are fp32 / fp64.
+extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* tape_, const float* grad_out, float* grads, void* ws_, int training,
+                              void* stream_) {
+    if (!net || !params || !tape_ || !grad_out || !grads || !ws_) return ENDO_E_BADARG;
+    const Table16& tb = table16();
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    Ctx16 c{net, params, nullptr, const_cast<char*>(static_cast<const char*>(tape_)), training, stream};
+    c.grads = grads; c.ws = static_cast<char*>(ws_);
+    // (measured, profiles/r03_r: with the weight gradients on the side stream both they and the data-gradient kernels slow down by as
+    // much as the overlap buys -- 22.4 vs 21.6 ms per forward + backward of the two batches; the stream is created only on request)
+    if (!net->wstream && net->use_wstream) {
+        ENDO_CHECK(hipStreamCreateWithFlags(&net->wstream, hipStreamNonBlocking));
+        ENDO_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
+        ENDO_CHECK(hipEventCreateWithFlags(&net->ev_join, hipEventDisableTiming));
+    }
+    ENDO_CHECK(hipMemsetAsync(c.ws + net->ws_zero_begin, 0, static_cast<size_t>(net->ws_zero_end - net->ws_zero_begin), stream));
+    {   // data-gradient weights of the 54 convolutions that have one
+        W16Table t{};
+        t.layers = static_cast<int>(tb.dconvs.size());
+        t.dgrad = 1;
+        if (t.layers > 63) return ENDO_E_BADARG;
+        int64_t start = 0;
+        for (int l = 0; l < t.layers; ++l) {
+            const Conv16& cv = *tb.dconvs[l];
+            const int64_t groups = (cv.cin + 47) / 48, chunks = (cv.cout + kBfKC - 1) / kBfKC;
+            t.start[l] = start; t.w[l] = cv.w; t.out[l] = cv.w16d; t.cout[l] = cv.cin; t.cin[l] = cv.cout; t.cin_k[l] = cv.cout; t.ks[l] = cv.ks; t.nt[l] = 3;
+            t.rot[l] = cv.rot; t.rot_n[l] = cv.rot_n;
+            start += chunks * groups * cv.ks * cv.ks * 3 * 16 * 32;
+        }
+        t.start[t.layers] = start;
+        bf16_all_weights_kernel<<<1024, 256, 0, stream>>>(t, params, reinterpret_cast<uint16_t*>(c.ws + net->ws_w16d));
+        ENDO_LAUNCH_CHECK();
+    }
+    int rc;
+    {
+        const auto& lv = net->lv[0];
+        int bx = static_cast<int>((lv.plane * 8 + 255) / 256);
+        bx = bx > 512 ? 512 : bx;
+        bf16_final_bwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(grad_out, reinterpret_cast<const float*>(c.tape + net->pre_off), c.act(0), c.dbuf(0),
+                                                                    lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w, tb.final_.rot,
+                                                                    tb.final_.rot_n, grads + tb.final_.w, grads + tb.final_.b, c.gsum(0));
+        ENDO_LAUNCH_CHECK();
+    }
+    for (int i = k16Levels - 1; i >= 0; --i) {
+        const int l = k16Levels - 1 - i, src = l + 1;
+        rc = dense_block_bwd16(c, l, c16_skip(l) + k16New, tb.up_bn[i], tb.up_conv[i]);
+        if (rc) return rc;
+        rc = tu_bwd16(c, l, src, (i == 0) ? 288 : c16_skip(src) + k16New, tb.tu_conv[i]);
+        if (rc) return rc;
+    }
+    rc = dense_block_bwd16(c, k16Levels, 288, tb.bott_bn, tb.bott_conv);
+    if (rc) return rc;
+    for (int l = k16Levels - 1; l >= 0; --l) {
+        rc = td_bwd16(c, l, tb.td_bn[l], tb.td_conv[l]);
+        if (rc) return rc;
+        rc = dense_block_bwd16(c, l, c16_down_in(l), tb.down_bn[l], tb.down_conv[l]);
+        if (rc) return rc;
+    }
+    {   // first convolution: bias and weight gradient (the image needs none)
+        rc = prep_dy16(c, 0, 0, k16First, grads + tb.first.b);
+        if (rc) return rc;
+        const auto& lv = net->lv[0];
+        Wgrad16Params p{};
+        p.n = net->n; p.h = lv.h; p.w = lv.w;
+        p.a = reinterpret_cast<const uint16_t*>(c.tape + net->in_off); p.a_ns = lv.plane * 8; p.a_blk = 8; p.a_h = lv.h; p.a_w = lv.w; p.ac0 = 0; p.cin = 4;
+        p.cin_w = 3;
+        p.g = c.dbuf(0); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = 0; p.cout = k16First;
+        p.partial = c.partial();
+        hipStream_t side;
+        rc = c.fork_wgrad(side);
+        if (rc) return rc;
+        rc = launch_bf16_wgrad<3>(p, grads + tb.first.w, side);
+        if (rc) return rc;
+    }
+    if (net->wstream) {          // join: the caller's stream continues only after every weight gradient has landed
+        ENDO_CHECK(hipEventRecord(net->ev_join, net->wstream));
+        ENDO_CHECK(hipStreamWaitEvent(stream, net->ev_join, 0));
     }
     return 0;
 }

@@ -119,6 +119,30 @@ class _NetFunction(torch.autograd.Function):
         return None, None, None, None
 
 
+class _Net16Function(torch.autograd.Function):
+    """The bf16-storage network (endo_net16_fwd / endo_net16_bwd) as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        x = _lib.dev_f32(x, "FCDenseNet57 input")
+        out, tape = net._run_forward16(x)
+        ctx.net = net
+        ctx.training = net.training
+        ctx.tape = tape
+        ctx.shape = tuple(x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("FCDenseNet57 on the MI355X path does not produce a gradient for its input image; detach the input")
+        if ctx.tape is None:
+            raise RuntimeError("FCDenseNet57: the forward tape of this call was released by its first backward pass")
+        ctx.net._run_backward16(ctx.shape, ctx.tape, grad_out, ctx.training)
+        ctx.tape = None
+        return None, None, None
+
+
 class FCDenseNet(nn.Module):
     """FC-DenseNet57 (the only configuration the drivers use, reference models.py:190-194)."""
 
@@ -358,14 +382,28 @@ class FCDenseNet(nn.Module):
         return out
 
     def forward_bf16_storage(self, x):
-        """The forward pass over bf16 level buffers (``endo_net16_fwd``: channels-last bf16 activations, bf16 matrix cores with
-        fp32 accumulation, fp32 BatchNorm statistics and output; the first bricks of the bf16-storage family of BASELINE configs[2],
-        DESIGN.md 7).  Same parameters, same running-statistics semantics (``.train()``: batch statistics and an update; ``.eval()``:
-        running statistics, the evaluate.py path) -- a different function numerically (every activation is rounded to 8 significant
-        bits), with its own tolerance (tests/test_gpu_bf16.py).  No gradient: the backward pass over this layout is not built yet, so
-        this is an inference / no-grad forward; H and W must be multiples of 32."""
+        """The network over bf16 level buffers (``endo_net16_fwd`` / ``endo_net16_bwd``: activations and inter-layer gradients stored
+        as bf16 in 32-channel blocks, bf16 matrix cores with fp32 accumulation; BatchNorm statistics, parameter gradients and the
+        output in fp32 -- the bf16-storage family of BASELINE configs[2]).  Same parameters, same running-statistics
+        semantics (``.train()``: batch statistics and an update; ``.eval()``: running statistics) -- a different function numerically
+        (every stored activation is rounded to 8 significant bits), with its own tolerances (tests/test_gpu_bf16.py).  Differentiable
+        with respect to the parameters; H and W must be multiples of 32."""
+        if torch.is_grad_enabled():
+            return _Net16Function.apply(x, self._anchor, self)
+        out, _ = self._run_forward16(_lib.dev_f32(x, "FCDenseNet57 input"))
+        return out
+
+    def _handle16(self, n, h, w):
         lib = _lib.load()
-        x = _lib.dev_f32(x, "FCDenseNet57 input")
+        key = ("bf16", n, h, w)
+        if key not in self._handles:
+            hnd = ctypes.c_void_p()
+            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w), "endo_net16_create(%d,%d,%d)" % (n, h, w))
+            self._handles[key] = (hnd, int(lib.endo_net16_tape_bytes(hnd)), int(lib.endo_net16_bwd_workspace_bytes(hnd)))
+        return self._handles[key]
+
+    def _run_forward16(self, x):
+        lib = _lib.load()
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected N x 3 x H x W input")
         if x.device != self._flat.device:
@@ -373,12 +411,7 @@ class FCDenseNet(nn.Module):
         if not self._views_intact():
             self._flatten()
         n, _, h, w = x.shape
-        key = ("bf16", n, h, w)
-        if key not in self._handles:
-            hnd = ctypes.c_void_p()
-            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w), "endo_net16_create(%d,%d,%d)" % (n, h, w))
-            self._handles[key] = (hnd, int(lib.endo_net16_tape_bytes(hnd)), 0)
-        hnd, tape_bytes, _ = self._handles[key]
+        hnd, tape_bytes, _ = self._handle16(n, h, w)
         tape = torch.empty(tape_bytes, dtype=torch.uint8, device=x.device)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         with torch.no_grad():
@@ -386,7 +419,19 @@ class FCDenseNet(nn.Module):
                                           1 if self.training else 0, _lib.stream()), "endo_net16_fwd")
         if self.training:
             self._nbt.add_(1)
-        return out
+        return out, tape
+
+    def _run_backward16(self, shape, tape, grad_out, training):
+        lib = _lib.load()
+        n, _, h, w = shape
+        hnd, _, ws_bytes = self._handle16(n, h, w)
+        key = ("bf16", n, h, w)
+        if key not in self._gradws:
+            self._gradws[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=tape.device)
+        self._attach_grads()
+        grad_out = _lib.dev_f32(grad_out, "grad_output")
+        _lib.check(lib.endo_net16_bwd(hnd, _lib.ptr(self._flat), _lib.ptr(tape), _lib.ptr(grad_out), _lib.ptr(self._flat_grad),
+                                      _lib.ptr(self._gradws[key]), 1 if training else 0, _lib.stream()), "endo_net16_bwd")
 
     def forward_pair(self, x1, x2):
         """``(self(x1), self(x2))`` -- the two forward passes of a training step (reference train.py:276-277) -- as ONE

@@ -378,12 +378,23 @@ int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int cin, const
  * tensors as endo_net_fwd (fp32), activations stored as bf16 in 32-channel blocks, BatchNorm statistics and the output in fp32.  The input is
  * rounded to bf16 on the way in.  training != 0: batch statistics + running-statistics update; 0: running statistics (the
  * evaluate.py path).  tape: endo_net16_tape_bytes() bytes of device memory, 256-byte aligned.  H and W multiples of 32.
- * There is no backward pass over this layout yet: gradients come from the fp32 family. */
+ * endo_net16_bwd: its backward pass.  tape: the forward call's tape, untouched since; grad_out: fp32 [n][1][H][W]; grads: the flat
+ * fp32 parameter-gradient buffer (offsets of endo_net_param_offset), ACCUMULATED into; ws: endo_net16_bwd_workspace_bytes() bytes,
+ * 256-byte aligned; training as in the forward call (0: BatchNorm as a fixed affine map).  Gradients between layers are stored as
+ * bf16; BatchNorm sums (fp64), parameter gradients and the deferred BatchNorm terms (fp32) are not. */
 typedef struct endo_net16 endo_net16;
 int endo_net16_create(endo_net16** out, int n, int h, int w);
 void endo_net16_destroy(endo_net16* net);
 int64_t endo_net16_tape_bytes(const endo_net16* net);
 int endo_net16_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape, int training,
+                   void* stream);
+int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net);
+/* byte offsets into the tape (what 0: final pre-activation fp32; 1: (mean, rstd) of BatchNorm `index` in module order; 2: max-pool
+ * codes of transition down `index` ([n][h / 2][w / 2][cout] bytes); 3: level buffer `index`) or the backward workspace (4: gradient
+ * buffer of level `index`); 5: channels of level buffer `index`.  Level buffers: [n][t / 32][h][w][32] bf16, channels [0, S) the
+ * down path, [S, S + 48) the transition-up output, [S + 48, S + 96) the up block's maps (S = 96 + 48 level; bottleneck: 288 + 48). */
+int64_t endo_net16_offset(const endo_net16* net, int what, int index);
+int endo_net16_bwd(endo_net16* net, const float* params, const void* tape, const float* grad_out, float* grads, void* ws, int training,
                    void* stream);
 
 #ifdef __cplusplus

@@ -121,15 +121,27 @@ def trainable_names():
     return [n for n, _, k in parameter_spec() if k in ("conv_w", "conv_b", "bn_w", "bn_b")]
 
 
-def _bn_relu(state, prefix, x, training, pattern=None):
+def bf16_ste(t):
+    """Round to bfloat16 (nearest even) in the forward direction, identity in the backward direction: the ``quant`` argument of
+    ``forward`` that restates where the bf16-storage kernel family (endo_net16_fwd) rounds -- the input image, every stored
+    convolution output, every staged relu(bn(x)) and every matrix-core weight -- so that autograd yields the exact gradient of THAT
+    function, against which endo_net16_bwd differs only by its bf16 storage of the gradients between layers."""
+    return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
+
+
+def _q(quant, t):
+    return t if quant is None else quant(t)
+
+
+def _bn_relu(state, prefix, x, training, pattern=None, quant=None):
     y = F.batch_norm(x, state[prefix + ".running_mean"], state[prefix + ".running_var"],
                      state[prefix + ".weight"], state[prefix + ".bias"],
                      training, BN_MOMENTUM, BN_EPS)
     if training:
         state[prefix + ".num_batches_tracked"] += 1
     if pattern is not None:
-        return y * pattern["relu::" + prefix].to(y.dtype)
-    return F.relu(y)
+        return _q(quant, y * pattern["relu::" + prefix].to(y.dtype))
+    return _q(quant, F.relu(y))
 
 
 def _max_pool(x, prefix, pattern=None):
@@ -140,12 +152,12 @@ def _max_pool(x, prefix, pattern=None):
     return torch.gather(windows, 4, pattern["pool::" + prefix].long().unsqueeze(-1)).squeeze(-1)
 
 
-def _dense_block(state, prefix, x, training, keep_input, trace=None, pattern=None):
+def _dense_block(state, prefix, x, training, keep_input, trace=None, pattern=None, quant=None):
     new = []
     for j in range(LAYERS_PER_BLOCK):
         p = "%s.layers.%d" % (prefix, j)
-        a = _bn_relu(state, p + ".norm", x, training, pattern)
-        out = F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"], padding=1)
+        a = _bn_relu(state, p + ".norm", x, training, pattern, quant)
+        out = _q(quant, F.conv2d(a, _q(quant, state[p + ".conv.weight"]), state[p + ".conv.bias"], padding=1))
         if trace is not None:
             trace["conv::" + p] = out
         x = torch.cat([x, out], dim=1)
@@ -153,7 +165,7 @@ def _dense_block(state, prefix, x, training, keep_input, trace=None, pattern=Non
     return x if keep_input else torch.cat(new, dim=1)
 
 
-def forward(state, x, training=True, trace=None, pattern=None):
+def forward(state, x, training=True, trace=None, pattern=None, quant=None):
     """FCDenseNet.forward (models.py:171-187).  ``state`` running buffers are updated in place in
     training mode, exactly as nn.BatchNorm2d does.
 
@@ -168,30 +180,32 @@ def forward(state, x, training=True, trace=None, pattern=None):
     intermediate maps: skip_L (down block L output), bott_in, bott_new, tu_L, upnew_L, and "conv::<module>" = the
     output of every convolution (after the max-pool for a transition down), whose autograd gradient is the TOTAL
     gradient of those maps -- what the HIP gradient workspace holds for the same channel planes."""
-    out = F.conv2d(x, state["firstconv.weight"], state["firstconv.bias"], padding=1)
+    # quant (optional, e.g. bf16_ste): applied to the input, to every stored convolution output, to every relu(bn(x)) fed to a
+    # convolution and to the weights of every convolution but the final 1 x 1 (which the bf16-storage family evaluates in fp32)
+    out = _q(quant, F.conv2d(_q(quant, x), _q(quant, state["firstconv.weight"]), state["firstconv.bias"], padding=1))
     if trace is not None:
         trace["conv::firstconv"] = out
     skips = []
     for i in range(LEVELS):
-        out = _dense_block(state, "denseBlocksDown.%d" % i, out, training, keep_input=True, trace=trace, pattern=pattern)
+        out = _dense_block(state, "denseBlocksDown.%d" % i, out, training, keep_input=True, trace=trace, pattern=pattern, quant=quant)
         skips.append(out)
         if trace is not None:
             trace["skip_%d" % i] = out
         p = "transDownBlocks.%d" % i
-        a = _bn_relu(state, p + ".norm", out, training, pattern)
-        out = _max_pool(F.conv2d(a, state[p + ".conv.weight"], state[p + ".conv.bias"]), p, pattern)
+        a = _bn_relu(state, p + ".norm", out, training, pattern, quant)
+        out = _q(quant, _max_pool(F.conv2d(a, _q(quant, state[p + ".conv.weight"]), state[p + ".conv.bias"]), p, pattern))
         if trace is not None:
             trace["conv::" + p] = out
     if trace is not None:
         trace["bott_in"] = out
-    out = _dense_block(state, "bottleneck.bottleneck", out, training, keep_input=False, trace=trace, pattern=pattern)
+    out = _dense_block(state, "bottleneck.bottleneck", out, training, keep_input=False, trace=trace, pattern=pattern, quant=quant)
     if trace is not None:
         trace["bott_new"] = out
     for i in range(LEVELS):
         skip = skips.pop()
         p = "transUpBlocks.%d.convTrans.1" % i
         up = F.interpolate(out, scale_factor=2, mode="nearest")
-        up = F.conv2d(up, state[p + ".weight"], state[p + ".bias"], padding=1)
+        up = _q(quant, F.conv2d(up, _q(quant, state[p + ".weight"]), state[p + ".bias"], padding=1))
         dy = (up.shape[2] - skip.shape[2]) // 2
         dx = (up.shape[3] - skip.shape[3]) // 2
         up = up[:, :, dy:dy + skip.shape[2], dx:dx + skip.shape[3]]
@@ -200,7 +214,7 @@ def forward(state, x, training=True, trace=None, pattern=None):
             trace["conv::transUpBlocks.%d" % i] = up
         out = torch.cat([up, skip], dim=1)
         out = _dense_block(state, "denseBlocksUp.%d" % i, out, training, keep_input=(i == LEVELS - 1), trace=trace,
-                           pattern=pattern)
+                           pattern=pattern, quant=quant)
         if trace is not None:
             trace["upnew_%d" % (LEVELS - 1 - i)] = out[:, -GROWTH * LAYERS_PER_BLOCK:]
     pre = F.conv2d(out, state["finalConv.weight"], state["finalConv.bias"])

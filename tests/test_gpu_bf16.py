@@ -214,3 +214,114 @@ def test_bf16_storage_forward_timing():
             torch.cuda.synchronize()
         res[name] = e0.elapsed_time(e1) / 10
     print("forward of 16 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (res["bf16 storage"], res["fp32"]))
+
+
+# ---------------------------------------------------------------------------------------------
+# the backward pass over bf16 level buffers
+# ---------------------------------------------------------------------------------------------
+# per parameter tensor, max |g16 - g| / max(max |g|, floor), on the pass's own pattern; measured (printed by the test): weights and
+# BatchNorm parameters <= 2.1e-2 in inference mode, <= 5e-2 in training mode.  Conv BIASES in training mode are a sum over all pixels
+# of a gradient map whose mean BatchNorm has removed: what is left is border terms, and the bf16 roundings of the gradient buffers
+# (relative to the un-cancelled magnitude) do not average out against it -- up to 4e-1 of the tensor's largest entry on up-path layers
+# whose maps reach a transition up; every bias whose gradient is mathematically zero is exactly zero.
+BF16_STORAGE_GRAD_TOL = 4e-2                 # inference mode (measured <= 2.1e-2)
+BF16_STORAGE_GRAD_TOL_TRAIN = 1e-1           # training mode (measured <= 6.4e-2: 2 x 64 x 96, level 4, where a BatchNorm sees 48 values per channel)
+BF16_STORAGE_BIAS_GRAD_TOL_TRAIN = 5e-1
+
+
+def _grads_by_name(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 128, 160)])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_bf16_storage_backward(shape, mode):
+    """Parameter gradients of FCDenseNet57.forward_bf16_storage (endo_net16_bwd) against the fp64 oracle evaluated (a) with the SAME
+    roundings in its forward direction (oracle.network.forward(quant=bf16_ste): input, stored convolution outputs, staged
+    relu(bn(x)) and matrix-core weights rounded to bf16, identity backward) and (b) on the ReLU / max-pool / sign pattern the HIP
+    forward pass itself took (device_pattern16.py) -- without (b) the comparison measures how many ReLU bits 8-bit activations flip
+    (1e-1 on a gradient tensor), not the backward kernels.  What is left is the bf16 storage of the gradients between layers."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w = shape
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(29)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    from device_pattern16 import pattern_of
+    m = ea.FCDenseNet57(1)
+    m.load_state_dict(state)
+    m = m.to(dev())
+    getattr(m, mode)()
+    y = m.forward_bf16_storage(x.to(dev()))
+    pattern = pattern_of(y, m, n, h, w)
+    y.backward(g.to(dev()))
+    torch.cuda.synchronize()
+    # the oracle, on that pattern
+    st64 = {k: (v.double().requires_grad_(k in onet.trainable_names()) if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    y64 = onet.forward(st64, x.double(), training=(mode == "train"), quant=onet.bf16_ste, pattern=pattern)
+    y64.backward(g.double())
+    want = {k: st64[k].grad for k in onet.trainable_names()}
+    got = {k: v.double().cpu() for k, v in _grads_by_name(m).items()}
+    e_fwd = float((y.detach().double().cpu() - y64.detach()).abs().max() / y64.detach().abs().max())
+    # conv biases in front of a training-mode BatchNorm have a mathematically zero gradient: a tensor's error is measured against
+    # max(its own largest gradient, 1e-3 of the largest gradient of any tensor)
+    floor = 1e-3 * max(float(v.abs().max()) for v in want.values())
+    rows = []
+    l2_num, l2_den = 0.0, 0.0
+    for k, gw in want.items():
+        gg = got[k]
+        assert torch.isfinite(gg).all(), k
+        scale = max(float(gw.abs().max()), floor)
+        rows.append((float((gg - gw).abs().max()) / scale, k, float(gw.abs().max()), float(gg.abs().max())))
+        l2_num += float(((gg - gw) ** 2).sum()); l2_den += float((gw ** 2).sum())
+    rows.sort(reverse=True)
+    for err, k, mw, mg in rows[:6]:
+        print("      %-48s err %.2e   max |g oracle| %.3e   max |g16| %.3e" % (k, err, mw, mg))
+    for kind in ("conv.weight", "conv.bias", "norm.weight", "norm.bias", "Conv.weight", "convTrans.1.weight"):
+        num = sum(float(((got[k] - want[k]) ** 2).sum()) for k in want if k.endswith(kind))
+        den = sum(float((want[k] ** 2).sum()) for k in want if k.endswith(kind))
+        print("      kind %-20s relative L2 %.2e" % (kind, (num / max(den, 1e-300)) ** 0.5))
+    worst, worst_name = rows[0][0], rows[0][1]
+    print("bf16-storage backward %s %s: forward vs the bf16-rounding oracle %.2e; worst tensor %s max err / max |g| = %.2e; all parameters relative L2 %.2e" % (
+        shape, mode, e_fwd, worst_name, worst, (l2_num / l2_den) ** 0.5))
+    assert e_fwd <= 8e-3, e_fwd
+    for err, k, _, _ in rows:
+        loose = mode == "train" and (k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias")
+        assert err <= (BF16_STORAGE_BIAS_GRAD_TOL_TRAIN if loose else (BF16_STORAGE_GRAD_TOL_TRAIN if mode == "train" else BF16_STORAGE_GRAD_TOL)), (k, err)
+    assert (l2_num / l2_den) ** 0.5 <= 3e-2
+
+
+def test_bf16_storage_step_timing():
+    """Prints (no gate) forward + backward of the benchmark batch (two calls of 8 frames of 256 x 320, as a training step makes them)
+    over bf16 level buffers next to the fp32 path's grouped pair."""
+    n, h, w = 8, 256, 320
+    m = ea.FCDenseNet57(1)
+    ea.utils.kaiming_weight_zero_bias(m, mode="fan_in", activation_mode="relu", distribution="normal")
+    m = m.to(dev()).train()
+    x1 = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
+    x2 = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
+    g = torch.randn((n, 1, h, w), device=dev())
+
+    def step16():
+        y1 = m.forward_bf16_storage(x1); y2 = m.forward_bf16_storage(x2)
+        torch.autograd.backward([y1, y2], [g, g])
+
+    def step32():
+        y1, y2 = m.forward_pair(x1, x2)
+        torch.autograd.backward([y1, y2], [g, g])
+    res = {}
+    for name, fn in (("bf16 storage", step16), ("fp32", step32)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / 5
+    print("network forward + backward, two batches of 8 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (
+        res["bf16 storage"], res["fp32"]))

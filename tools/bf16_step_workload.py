@@ -1,0 +1,25 @@
+"""Profiling workload (development tool): the bf16-storage network forward + backward of a training step's two batches
+(8 x 256 x 320 each), 5 iterations after 2 of warm-up.  usage: rocprofv3 --kernel-trace --stats -- python3 tools/bf16_step_workload.py"""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+
+n, h, w = 8, 256, 320
+dev = torch.device("cuda:0")
+m = ea.FCDenseNet57(1)
+ea.utils.kaiming_weight_zero_bias(m, mode="fan_in", activation_mode="relu", distribution="normal")
+m = m.to(dev).train()
+x1 = torch.rand((n, 3, h, w), device=dev) * 2 - 1
+x2 = torch.rand((n, 3, h, w), device=dev) * 2 - 1
+g = torch.randn((n, 1, h, w), device=dev)
+for it in range(7):
+    y1 = m.forward_bf16_storage(x1)
+    y2 = m.forward_bf16_storage(x2)
+    torch.autograd.backward([y1, y2], [g, g])
+torch.cuda.synchronize()
+print("done")
