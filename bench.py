@@ -2,7 +2,7 @@
 """Headline benchmark: training frame-pairs/s of the full hot-path step (BASELINE.json metric) on
 synthetic frame pairs -- by default config 2 of BASELINE.json (configs[1]): 256 x 320, batch 8 per GPU, fp32.
 
-    python bench.py --gpus N --steps K --warmup W [--config 1|3|4]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5]
 
 With N > 1 and no WORLD_SIZE in the environment the script starts N fresh rank processes itself
 (``python -m torch.distributed.run --nproc-per-node N ... bench.py``, before this process touches the GPU) and relays
@@ -18,6 +18,9 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
     3   512 x 640, batch 4 per GPU, fp32
     4   256 x 320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10 ("adjacent range 5-30");
         fp32 storage (the fp16-storage half of configs[4] does not exist in this library)
+    2   256 x 320, batch 8 per GPU, bf16 MFMA operands over fp32 tensors (a mixed-precision mode of the fp32 family)
+    5   256 x 320, batch 8 per GPU, BF16 STORAGE: the network over bf16 level buffers (endo_net16_fwd / endo_net16_bwd) -- the
+        per-GPU half of BASELINE.json configs[2] (bs 64 bf16 over 8 GPUs); its own line, never compared with configs[1]
 
 Extra objects on that line:
   roofline             the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad: whichever took the most
@@ -69,6 +72,13 @@ CONFIGS = {
             metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30",
             workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, "
                      "fp32 storage (BASELINE.json configs[4] without its fp16-storage half)"),
+    5: dict(height=256, width=320, batch=8, gap=None, bf16_storage=True,
+            metric="train frame-pairs/sec at 256x320 bs=8, bf16 storage",
+            workload="full training step, 256x320, batch 8 per GPU, BF16 STORAGE: the network's activations and inter-layer gradients "
+                     "are stored as bf16 in 32-channel blocks and multiplied on the bf16 matrix cores (fp32 accumulation; BatchNorm "
+                     "statistics, parameter gradients, geometry, losses, clipping and SGD fp32) -- the per-GPU half of BASELINE.json "
+                     "configs[2] (bs 64 bf16 over 8 GPUs); a different function from the fp32 line of configs[1], with its own parity "
+                     "bounds (tests/test_gpu_bf16.py)"),
 }
 
 
@@ -294,6 +304,7 @@ def main():
     dev = torch.device("cuda", local)
     lib = pkg._lib.load()
     bf16 = bool(cfg.get("bf16_operands"))
+    bf16_storage = bool(cfg.get("bf16_storage"))
 
     torch.manual_seed(10085)                                            # reference train.py:80
     model = pkg.models.FCDenseNet57(n_classes=1)
@@ -307,7 +318,7 @@ def main():
         model.set_kernel_option(option_id, value)
     optimizer = pkg.optim.FusedClipSGD(model, lr=1.0e-3, momentum=0.9, max_norm=10.0)
     scheduler = pkg.scheduler.CyclicLR(optimizer, base_lr=1.0e-4, max_lr=1.0e-3, step_size=2000)
-    step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1)
+    step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, bf16_storage=bf16_storage)
     batch = {k: v.to(dev) for k, v in pkg.synthetic.make_batch(batch_size, height, width, seed=rank, gap_scale=cfg["gap"]).items()}
 
     def barrier():
@@ -460,7 +471,8 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 MFMA operands, f32 accumulate, f32 storage" if bf16 else "f32",
+        "dtype": "bf16 storage and MFMA operands, f32 accumulate" if bf16_storage else (
+            "bf16 MFMA operands, f32 accumulate, f32 storage" if bf16 else "f32"),
         "data": "synthetic",
         "config": {"workload": cfg["workload"], "baseline_config_index": args.config,
                    "global_batch": batch_size * world, "height": height, "width": width, "parallelism": "dp%d" % world},
@@ -494,7 +506,7 @@ def main():
             "host_inclusive_ms_per_pair_through_the_modules_and_autograd": warp_ms_per_pair_modules,
             "note": "latency/launch bound at this size: %.0f KB per launch" % (warp_bytes / max(geo[1] + los[1], 1) * reps / 1e3)},
     }
-    if bf16:
+    if bf16 or bf16_storage:
         # with bf16 operands the matrix work is ~1/8 of the fp32 kernels' and the dense-layer families are bound by HBM / LDS / VALU:
         # the roofline that applies is HBM (~90 FLOP/B against a bf16 ridge of ~310)
         r = result["roofline"]
@@ -502,7 +514,15 @@ def main():
         r.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                   "mfma_tflops_for_reference": achieved})
         result["conv_roofline_frac_whole_step"] = None
-        result["roofline_serial"] = None
+        if bf16_storage:
+            r["concurrent"] = False          # one stream: kernels run one at a time
+            r["algorithmic_bytes_note"] = ("bf16 tensors: dense forward 2 B x (Cin + 12) per pixel; data gradient 2 B x 12 + per input "
+                                           "channel the forward value (2 B) and the gradient read and written (4 B); weight gradient "
+                                           "2 B x (Cin + 12) per pixel")
+            result["roofline_serial"]["unit"] = "TFLOP/s (bf16 matrix cores; these kernels are HBM-bound, see roofline)"
+            result["roofline_serial"]["frac"] = None
+        else:
+            result["roofline_serial"] = None
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
         result["cpu_baseline"] = cpu_baseline(cfg)
     print(json.dumps(result))

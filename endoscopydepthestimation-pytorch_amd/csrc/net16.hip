@@ -423,6 +423,8 @@ int dense16(const Ctx16& c, int level, int ic0, int oc0, const Bn16& b, const Co
     fill_io(c, p, level, ic0, cv.cin, level, oc0, cv);
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
     fill_bn(c, p, b, level, ic0);
+    const double px = static_cast<double>(c.net->n) * c.net->lv[level].plane;
+    ProfScope prof(kProfConv3x3Dense, c.stream, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin + cv.cout));
     return launch_bf16_conv<3, 1, 0, 8, 4>(p, c.stream);
 }
 
@@ -434,6 +436,8 @@ int td16(const Ctx16& c, int level, const Bn16& b, const Conv16& cv) {
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
     fill_bn(c, p, b, level, 0);
     p.out_idx = reinterpret_cast<uint8_t*>(c.tape + c.net->idx_off[level]);
+    const double px = static_cast<double>(c.net->n) * c.net->lv[level].plane;
+    ProfScope prof(kProfConv1x1Pool, c.stream, 2.0 * px * cv.cin * cv.cout, 2.0 * px * cv.cin + 0.75 * px * cv.cout);
     return launch_bf16_conv<1, 3, 1, 8, 4>(p, c.stream);
 }
 
@@ -443,6 +447,8 @@ int tu16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16& cv)
     fill_io(c, p, src_level, src_c0, cv.cin, level, c16_skip(level), cv);
     p.h = c.net->lv[level].h; p.w = c.net->lv[level].w;
     p.ups = 1;
+    const double px = static_cast<double>(c.net->n) * c.net->lv[level].plane;
+    ProfScope prof(kProfConv3x3Up, c.stream, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin / 4.0 + cv.cout));
     return launch_bf16_conv<3, 3, 0, 8, 2>(p, c.stream);
 }
 
@@ -580,12 +586,19 @@ int dense_bwd16(const Ctx16& c, int level, int oc0, const Bn16& b, const Conv16&
         hipStream_t side;
         rc = c.fork_wgrad(side);
         if (rc) return rc;
+        const double px = static_cast<double>(c.net->n) * lv.plane;
+        ProfScope prof(kProfWgradDense, side, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin + cv.cout));
         rc = launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
         if (rc) return rc;
     }
     Conv16Params p{};
     fill_dgrad(c, p, level, oc0, level, b, cv);
-    rc = launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2>(p, c.stream);
+    {
+        // per input channel and pixel: the forward value (2 B) and the gradient read and written (2 + 2 B); per output channel 2 B
+        const double px = static_cast<double>(c.net->n) * lv.plane;
+        ProfScope prof(kProfDgradDense, c.stream, 2.0 * px * cv.cin * cv.cout * 9, px * (6.0 * cv.cin + 2.0 * cv.cout));
+        rc = launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2>(p, c.stream);
+    }
     if (rc) return rc;
     return bn_finalize16(c, b, cv, level);
 }

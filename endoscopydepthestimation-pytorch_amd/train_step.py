@@ -45,8 +45,14 @@ def mask_mul(a, mask):
 
 class TrainingStep(object):
     def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8, pair_forward=True,
-                 fused_head=True):
+                 fused_head=True, bf16_storage=False):
         self.model = model
+        # the network over bf16 level buffers (FCDenseNet.forward_bf16_storage: activations and inter-layer gradients stored as
+        # bf16, bf16 matrix cores, fp32 accumulation / statistics / parameter gradients; BASELINE configs[2]); the two frames are two
+        # calls of the network, as in the reference (train.py:276-277); losses, clipping and SGD stay fp32
+        self.bf16_storage = bool(bf16_storage)
+        if self.bf16_storage and not (fused_head and pair_forward):
+            raise ValueError("bf16_storage runs through the fused loss head")
         self.epsilon = float(epsilon)
         # everything between the network outputs and d loss / d prediction as one library call (endo_loss_head: the modules'
         # kernels, composed in C) instead of ~60 autograd nodes; needs the grouped pair forward
@@ -119,7 +125,12 @@ class TrainingStep(object):
             x = torch.empty((2 * n, ch, h, w), dtype=torch.float32, device=c1.device)          # both frames, masked (train.py:272-273)
             _lib.check(lib.endo_mask_mul(_lib.ptr(c1), _lib.ptr(b), _lib.ptr(x[:n]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
             _lib.check(lib.endo_mask_mul(_lib.ptr(c2), _lib.ptr(b), _lib.ptr(x[n:]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
-            pred, tape = self.model._run_forward(x, 2)          # (2N, 1, H, W): frame 1's predictions first
+            if self.bf16_storage:
+                p1, t1 = self.model._run_forward16(x[:n])
+                p2, t2 = self.model._run_forward16(x[n:])
+                pred, tape = torch.cat([p1, p2], dim=0), (t1, t2)
+            else:
+                pred, tape = self.model._run_forward(x, 2)          # (2N, 1, H, W): frame 1's predictions first
             need = int(lib.endo_loss_head_workspace_floats(n, h, w))
             if self._head_ws is None or self._head_ws.numel() < need or self._head_ws.device != pred.device:
                 self._head_ws = torch.empty(need, dtype=torch.float32, device=pred.device)
@@ -138,7 +149,13 @@ class TrainingStep(object):
 
     def _fused_backward(self, x, tape, grad_pred):
         with torch.no_grad():
-            self.model._run_backward(x, tape, grad_pred, self.model.training, 2)
+            if self.bf16_storage:
+                n = x.shape[0] // 2
+                shape = (n,) + tuple(x.shape[1:])
+                self.model._run_backward16(shape, tape[1], grad_pred[n:], self.model.training)
+                self.model._run_backward16(shape, tape[0], grad_pred[:n], self.model.training)
+            else:
+                self.model._run_backward(x, tape, grad_pred, self.model.training, 2)
 
     def __call__(self, batch, lr=None):
         if lr is not None:
