@@ -46,7 +46,7 @@ SIGNATURES = {
     "endo_bf16_conv_weight_elems": (_L, [_I, _I, _I]),
     "endo_bf16_conv_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "endo_bf16_conv": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
-    "endo_net16_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
+    "endo_net16_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "endo_net16_destroy": (None, [_P]),
     "endo_net16_tape_bytes": (_L, [_P]),
     "endo_net16_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),

@@ -91,7 +91,8 @@ __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __rest
 // kEpiSumPool epilogue adds.  They meet in gsum ([t][2] fp64 per level, first of each pair), read here by one block.
 __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict__ d, const uint16_t* __restrict__ x, int64_t ns, int plane, int blk,
                                                            int c0, int count, const float* __restrict__ pq_p, const float* __restrict__ pq_q,
-                                                           float* __restrict__ bias_grad, const double* __restrict__ gsum, int apply) {
+                                                           float* __restrict__ bias_grad, const double* __restrict__ gsum, int apply, int group_n,
+                                                           int64_t gs_pq) {
     if (bias_grad && blockIdx.x == 0 && blockIdx.y == 0)
         for (int c = threadIdx.x; c < count; c += 256) bias_grad[c] += static_cast<float>(gsum[2 * (c0 + c)]);
     if (!apply) return;          // inference mode: P = Q = 0
@@ -101,8 +102,9 @@ __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict_
     const int q = threadIdx.x % quads, p0 = threadIdx.x / quads;
     if (p0 >= ppi) return;
     float pc[4], qc[4];
+    const int64_t go = (group_n > 0 ? n / group_n : 0) * gs_pq;          // the sample's group has its own deferred terms
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { pc[i] = pq_p[c0 + 4 * q + i]; qc[i] = pq_q[c0 + 4 * q + i]; }
+    for (int i = 0; i < 4; ++i) { pc[i] = pq_p[go + c0 + 4 * q + i]; qc[i] = pq_q[go + c0 + 4 * q + i]; }
     for (int px = blockIdx.x * ppi + p0; px < plane; px += gridDim.x * ppi) {
         const int64_t off = n * ns + blk_off(c0 + 4 * q, px, plane, blk);
         const u32x2_t dv = *reinterpret_cast<const u32x2_t*>(d + off);
@@ -121,9 +123,12 @@ __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict_
 // to the prep_dy of the channels (buffer channel ic0 + ci; parameters at (ci + rot) % rot_n).
 __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ saved,
                                                                const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
-                                                               float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum, int cin, int rot,
-                                                               int rot_n, double count, int training) {
-    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < cin; ci += gridDim.x * blockDim.x) {
+                                                               float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum, int first,
+                                                               int cnt, int rot, int rot_n, double count, int training, int64_t gs_sums, int64_t gs_saved,
+                                                               int64_t gs_pq) {
+    // blockIdx.y = sample group: its own sums, statistics and deferred terms; the parameter gradients add up over the groups
+    sums += blockIdx.y * gs_sums; saved += blockIdx.y * gs_saved; pq_p += blockIdx.y * gs_pq; pq_q += blockIdx.y * gs_pq;
+    for (int ci = first + blockIdx.x * blockDim.x + threadIdx.x; ci < first + cnt; ci += gridDim.x * blockDim.x) {
         const int pc = rot_index(ci, rot, rot_n);
         const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
         const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
@@ -135,7 +140,7 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __r
             pq_p[ci] += static_cast<float>(-k);
             pq_q[ci] += static_cast<float>(-scale * s1 / count + k * mean);
         } else {
-            gsum[2 * ci] += scale * s1;          // the pixel sum of what the layer added to channel ci (training mode: exactly 0)
+            atomicAdd(gsum + 2 * ci, scale * s1);          // the pixel sum of what the layer added to channel ci (training mode: exactly 0)
         }
     }
 }
@@ -161,6 +166,8 @@ struct Wgrad16Params {
     const float* gamma;
     const float* beta;
     int rot, rot_n;
+    int group_n;                       // sample groups (at most 2): group g's saved starts gs_saved floats later
+    int64_t gs_saved;
     const uint16_t* g;                 // prepared gradient of the convolution's output
     int64_t g_ns;
     int g_blk;
@@ -177,7 +184,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
     unsigned char* s_a = smem_wg;                                       // [192][4 rows][32 px] bf16, pitch kWgPitchA
     unsigned char* s_g = s_a + kWgCi * kWgPitchA;
-    float* s_bn = reinterpret_cast<float*>(s_g + kGBytes);              // [192][2] (scale, shift)
+    float* s_bn = reinterpret_cast<float*>(s_g + kGBytes);              // [2 groups][192][2] (scale, shift)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -192,14 +199,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
     const int g_h = p.g_idx ? p.h >> 1 : p.h, g_w = p.g_idx ? p.w >> 1 : p.w;
     const int g_plane = g_h * g_w;
 
-    for (int c = tid; c < kWgCi; c += 256) {
+    for (int e = tid; e < 2 * kWgCi; e += 256) {
+        const int g = e / kWgCi, c = e - g * kWgCi;
         float sc = 1.f, sh = 0.f;
-        if (p.saved && c < cin_g) {
+        if (p.saved && c < cin_g && (g == 0 || p.group_n > 0)) {
             const int pc = rot_index(ci0 + c, p.rot, p.rot_n);
-            sc = p.gamma[pc] * p.saved[2 * pc + 1];
-            sh = fmaf(-p.saved[2 * pc], sc, p.beta[pc]);
+            const float* sv = p.saved + g * p.gs_saved;
+            sc = p.gamma[pc] * sv[2 * pc + 1];
+            sh = fmaf(-sv[2 * pc], sc, p.beta[pc]);
         }
-        s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
+        s_bn[2 * e] = sc; s_bn[2 * e + 1] = sh;
     }
 
     f32x4_t acc[9][3];
@@ -214,6 +223,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         const int n = tile / (tiles_x * tiles_y);
         const int rem = tile - n * tiles_x * tiles_y;
         const int y0 = (rem / tiles_x) * kWgRows, x0 = (rem % tiles_x) * kWgCols;
+        const float* bn_g = s_bn + (p.group_n > 0 ? n / p.group_n : 0) * 2 * kWgCi;
         __syncthreads();          // the previous tile's fragment reads (and, the first time, s_bn)
         // ---- G ----
         if constexpr (KS == 3) {
@@ -284,7 +294,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
             if (p.saved) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(s_bn + 2 * (8 * k + 2 * j));
+                    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(bn_g + 2 * (8 * k + 2 * j));
                     z[2 * j] = ok ? fmaxf(fmaf(z[2 * j], q[0], q[1]), 0.f) : 0.f;
                     z[2 * j + 1] = ok ? fmaxf(fmaf(z[2 * j + 1], q[2], q[3]), 0.f) : 0.f;
                 }
@@ -356,7 +366,7 @@ __global__ void __launch_bounds__(256) bf16_wgrad_reduce_kernel(const float* __r
 
 template <int KS>
 inline size_t bf16_wgrad_smem() {
-    return static_cast<size_t>(kWgCi) * kWgPitchA + (KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA) + sizeof(float) * 2 * kWgCi;
+    return static_cast<size_t>(kWgCi) * kWgPitchA + (KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA) + sizeof(float) * 2 * 2 * kWgCi;
 }
 
 // blocks of the walk over tiles, the partial buffer a launch needs (floats) and the launch itself
@@ -378,6 +388,7 @@ template <int KS>
 inline int launch_bf16_wgrad(Wgrad16Params p, float* dw, hipStream_t stream) {
     if ((p.cin & 3) || (p.cout & 3) || (p.ac0 & 7) || (p.gc0 & 3) || (p.a_blk & 7) || (p.g_blk & 3)) return ENDO_E_BADARG;
     if (KS == 1 && ((p.cout & 7) || (p.gc0 & 7))) return ENDO_E_BADARG;
+    if (p.group_n > 0 && p.n > 2 * p.group_n) return ENDO_E_BADARG;          // two BatchNorm tables in LDS
     p.ci_pad = (p.cin + 15) / 16 * 16;
     const int blocks = bf16_wgrad_blocks(p, KS);
     const int ci_groups = (p.cin + kWgCi - 1) / kWgCi, co_groups = KS == 3 ? (p.cout + 15) / 16 : (p.cout + kWgCo1 - 1) / kWgCo1;

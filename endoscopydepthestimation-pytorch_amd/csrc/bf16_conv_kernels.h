@@ -83,6 +83,16 @@ struct Conv16Params {
     // x_saved / gamma / beta at parameter index (ci + rot) % rot_n (as in the forward pass, bit for bit).
     const uint16_t* x;
     const float* x_saved;            // [cin of the layer][2] (mean, rstd)
+    // a SUB-RANGE of the layer's input channels (the dense block's new maps; its base channels go through bf16_dgrad_block_kernel):
+    // output channel co of this launch is input channel co_off + co of the layer (weights row, BatchNorm parameters, out_sums index),
+    // its weights start at 48-row group grp0 of wgroups (0 = gridDim.y)
+    int co_off, grp0, wgroups;
+    // SAMPLE GROUPS (the two frames of a training pair in one launch, each with its own BatchNorm batch statistics -- reference
+    // train.py:276-277 calls the network twice): sample n belongs to group n / group_n (0 = one group); in_sums, saved / x_saved and
+    // out_sums of group g start gs_in_sums, gs_saved, gs_out_sums elements after group 0's.  Running statistics are updated by the
+    // launch's first block with group 0's statistics first, then group 1's, as two consecutive calls would.
+    int group_n;
+    int64_t gs_in_sums, gs_saved, gs_out_sums;
     // UNPOOL input (transition down backward): `in` is the pooled-resolution gradient (ups = 1 addressing) and a full-resolution pixel
     // takes a channel's value only where in_idx ([n][h / 2][w / 2][cin] bytes, the forward pass's out_idx) names its position
     const uint8_t* in_idx;
@@ -142,17 +152,21 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     float* s_red = s_bn + 2 * (nchunks * kBfKC > NT * 16 ? nchunks * kBfKC : NT * 16);          // [WAVES][NT * 16][2]
     const int in_plane = p.in_h * p.in_w;
 
-    const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;
+    const int grp = p.group_n > 0 ? static_cast<int>(blockIdx.z) / p.group_n : 0;
+    const int ngrp = p.group_n > 0 ? static_cast<int>(gridDim.z) / p.group_n : 1;
+    const bool first_block = blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0;                       // of the launch
+    const bool first_of_group = blockIdx.x == 0 && blockIdx.y == 0 && static_cast<int>(blockIdx.z) == grp * p.group_n;
     const bool has_bn = EPI != kEpiDgradBn && (p.bn != nullptr || p.use_stats != 0);
     if constexpr (EPI == kEpiDgradBn) {
         // (scale, shift) of this block's NT * 16 output channels = input channels of the differentiated layer
         for (int c = tid; c < NT * 16; c += kThreads) {
-            const int ci = co_base + c;
+            const int ci = p.co_off + co_base + c;
             float sc = 0.f, sh = 0.f;
-            if (ci < p.cout) {
+            if (co_base + c < p.cout) {
                 const int pc = ci < p.rot_n ? (ci + p.rot < p.rot_n ? ci + p.rot : ci + p.rot - p.rot_n) : ci;
-                sc = p.gamma[pc] * p.x_saved[2 * pc + 1];
-                sh = fmaf(-p.x_saved[2 * pc], sc, p.beta[pc]);
+                const float* sv = p.x_saved + grp * p.gs_saved;
+                sc = p.gamma[pc] * sv[2 * pc + 1];
+                sh = fmaf(-sv[2 * pc], sc, p.beta[pc]);
             }
             s_bn[2 * c] = sc; s_bn[2 * c + 1] = sh;
         }
@@ -162,11 +176,15 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
         if (c < p.cin) {
             const int pc = c < p.rot_n ? (c + p.rot < p.rot_n ? c + p.rot : c + p.rot - p.rot_n) : c;
             if (p.use_stats) {
+                auto stats_of = [&](int g, double& mean, double& var) {
+                    const double* sums = p.in_sums + g * p.gs_in_sums;
+                    mean = sums[2 * c] / p.count;
+                    var = sums[2 * c + 1] / p.count - mean * mean;
+                    if (var < 0.0) var = 0.0;
+                };
                 double mean, var;
                 if (p.training) {
-                    mean = p.in_sums[2 * c] / p.count;
-                    var = p.in_sums[2 * c + 1] / p.count - mean * mean;
-                    if (var < 0.0) var = 0.0;
+                    stats_of(grp, mean, var);
                 } else {
                     mean = p.running_mean[pc];
                     var = p.running_var[pc];
@@ -175,13 +193,17 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 const float mean_f = static_cast<float>(mean);
                 sc = p.gamma[pc] * rstd;
                 sh = fmaf(-mean_f, sc, p.beta[pc]);
-                if (first_block) {
-                    if (p.saved) { p.saved[2 * pc] = mean_f; p.saved[2 * pc + 1] = rstd; }
-                    if (p.training) {
-                        const double unbiased = p.count > 1.0 ? var * p.count / (p.count - 1.0) : var;
-                        p.running_mean[pc] = (1.0f - p.momentum) * p.running_mean[pc] + p.momentum * mean_f;
-                        p.running_var[pc] = (1.0f - p.momentum) * p.running_var[pc] + p.momentum * static_cast<float>(unbiased);
+                if (first_of_group && p.saved) { float* sv = p.saved + grp * p.gs_saved; sv[2 * pc] = mean_f; sv[2 * pc + 1] = rstd; }
+                if (first_block && p.training) {
+                    float rm = p.running_mean[pc], rv = p.running_var[pc];
+                    for (int g = 0; g < ngrp; ++g) {
+                        double gm, gv;
+                        stats_of(g, gm, gv);
+                        const double unbiased = p.count > 1.0 ? gv * p.count / (p.count - 1.0) : gv;
+                        rm = (1.0f - p.momentum) * rm + p.momentum * static_cast<float>(gm);
+                        rv = (1.0f - p.momentum) * rv + p.momentum * static_cast<float>(unbiased);
                     }
+                    p.running_mean[pc] = rm; p.running_var[pc] = rv;
                 }
             } else {
                 sc = p.bn ? p.bn[2 * pc] : 1.f; sh = p.bn ? p.bn[2 * pc + 1] : 0.f;
@@ -258,7 +280,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 }
             }
         }
-        const uint16_t* wsrc = p.wgt + (static_cast<int64_t>(chunk) * gridDim.y + blockIdx.y) * (kWUnits * 8);
+        const uint16_t* wsrc = p.wgt + (static_cast<int64_t>(chunk) * (p.wgroups > 0 ? p.wgroups : gridDim.y) + blockIdx.y + p.grp0) * (kWUnits * 8);
 #pragma unroll
         for (int i = 0; i < kWIter; ++i) {
             const int u = tid + i * kThreads;
@@ -543,7 +565,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             if (co_base + ch < p.cout) {
                 double tsum = 0.0;
                 for (int wv = 0; wv < WAVES; ++wv) tsum += static_cast<double>(s_red[(wv * NT * 16 + ch) * 2 + (e & 1)]);
-                atomicAdd(p.out_sums + 2 * (co_base + ch) + (e & 1), tsum);
+                atomicAdd(p.out_sums + grp * p.gs_out_sums + 2 * (p.co_off + co_base + ch) + (e & 1), tsum);
             }
         }
     }

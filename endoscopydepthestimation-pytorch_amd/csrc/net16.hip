@@ -7,6 +7,7 @@
 
 #include "bf16_conv_kernels.h"
 #include "bf16_bwd_kernels.h"
+#include "bf16_dgrad_block_kernels.h"
 
 extern "C" int64_t endo_net_param_offset(int index);
 extern "C" int64_t endo_net_bn_offset(int bn_index, int which);
@@ -27,7 +28,9 @@ inline int c16_level_channels(int level) {
 }
 
 // w16 / w16d: element offsets of the forward / data-gradient (transposed, flipped; -1 = none) bf16 weights
-struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; int rot, rot_n; int64_t w16d; };      // w16: element offset of the converted weights
+// base / koff: a dense layer's data-gradient weights below row `base` (the block's base channels) sit at k = koff + co -- the K window
+// of bf16_dgrad_block_kernel -- and at k = co from there on
+struct Conv16 { int64_t w, b; int cout, cin, ks, nt; int64_t w16; int rot, rot_n; int64_t w16d; int base, koff; };      // w16: element offset of the converted weights
 struct Bn16 { int64_t g, b; int c; int64_t run_mean, run_var; int64_t saved; };
 
 // the reference's module order (models.py:100-170, the order of .parameters()): offsets come from the fp32 family's own table
@@ -49,7 +52,7 @@ static const Table16& table16() {
         auto conv = [&](Conv16& c, int cout, int cin, int ks, bool mfma) {
             c.cout = cout; c.cin = cin; c.ks = ks; c.nt = cout <= 16 ? 1 : 3;
             c.w = endo_net_param_offset(pi++); c.b = endo_net_param_offset(pi++);
-            c.w16 = -1; c.rot = 0; c.rot_n = 0; c.w16d = -1;
+            c.w16 = -1; c.rot = 0; c.rot_n = 0; c.w16d = -1; c.base = 0; c.koff = 0;
             if (mfma && cin >= 4) {          // as a convolution over the gradient: cout' = cin (48-wide groups), K = cout
                 c.w16d = tb->w16d_elems;
                 const int64_t groups = (cin + 47) / 48, chunks = (cout + kBfKC - 1) / kBfKC;
@@ -71,11 +74,18 @@ static const Table16& table16() {
             b.saved = saved; saved += 2 * c;
             tb->bns.push_back(&b);
         };
+        const int koffs[k16Layers] = {0, 12, 8, 20};          // 12 j - 8 u0_j, u0 = {0, 0, 2, 2} (bf16_dgrad_block_kernels.h)
         conv(tb->first, k16First, 3, 3, true);
         for (int l = 0; l < k16Levels; ++l)
-            for (int j = 0; j < k16Layers; ++j) { bn(tb->down_bn[l][j], c16_down_in(l) + k16Growth * j); conv(tb->down_conv[l][j], k16Growth, c16_down_in(l) + k16Growth * j, 3, true); }
+            for (int j = 0; j < k16Layers; ++j) {
+                bn(tb->down_bn[l][j], c16_down_in(l) + k16Growth * j); conv(tb->down_conv[l][j], k16Growth, c16_down_in(l) + k16Growth * j, 3, true);
+                tb->down_conv[l][j].base = c16_down_in(l); tb->down_conv[l][j].koff = koffs[j];
+            }
         for (int l = 0; l < k16Levels; ++l) { bn(tb->td_bn[l], c16_down_in(l) + k16New); conv(tb->td_conv[l], c16_down_in(l) + k16New, c16_down_in(l) + k16New, 1, true); }
-        for (int j = 0; j < k16Layers; ++j) { bn(tb->bott_bn[j], 288 + k16Growth * j); conv(tb->bott_conv[j], k16Growth, 288 + k16Growth * j, 3, true); }
+        for (int j = 0; j < k16Layers; ++j) {
+            bn(tb->bott_bn[j], 288 + k16Growth * j); conv(tb->bott_conv[j], k16Growth, 288 + k16Growth * j, 3, true);
+            tb->bott_conv[j].base = 288; tb->bott_conv[j].koff = koffs[j];
+        }
         for (int i = 0; i < k16Levels; ++i) conv(tb->tu_conv[i], k16New, k16New, 3, true);
         for (int i = 0; i < k16Levels; ++i) {
             const int l = k16Levels - 1 - i;
@@ -83,6 +93,7 @@ static const Table16& table16() {
                 const int cin = 96 + c16_down_in(l) + k16Growth * j;
                 bn(tb->up_bn[i][j], cin); conv(tb->up_conv[i][j], k16Growth, cin, 3, true);
                 tb->up_conv[i][j].rot = k16New; tb->up_conv[i][j].rot_n = c16_skip(l) + k16New;
+                tb->up_conv[i][j].base = c16_skip(l) + k16New; tb->up_conv[i][j].koff = koffs[j];
             }
         }
         conv(tb->final_, 1, 192, 1, false);
@@ -98,7 +109,7 @@ struct W16Table {
     int layers;
     int64_t start[64];          // prefix sum of output elements
     int64_t w[63], out[63];
-    int cout[63], cin[63], cin_k[63], ks[63], nt[63], rot[63], rot_n[63];
+    int cout[63], cin[63], cin_k[63], ks[63], nt[63], rot[63], rot_n[63], base[63], koff[63];
     int dgrad;          // 1: data-gradient form: row = input channel of the layer, k = its cout, taps flipped
 };
 
@@ -116,11 +127,16 @@ __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t,
         const int tap = rest % taps; rest /= taps;
         const int grp = rest % ngroups;
         const int chunk = rest / ngroups;
-        const int co = (grp * nt + tt) * 16 + co16, ci = chunk * kBfKC + k;
+        const int co = (grp * nt + tt) * 16 + co16;
+        int ci = chunk * kBfKC + k;
+        // rows of a dense block's base channels are copied into LDS as they lie (bf16_dgrad_block_kernel): position k holds slot k / 8
+        // of the row, which is channel part (k / 8) XOR (row >> 1) & 3
+        if (t.dgrad && co < t.base[l]) ci = (((k >> 3) ^ ((co16 >> 1) & 3)) << 3) | (k & 7);
         float v = 0.f;
         if (t.dgrad) {          // here cout[l] / cin[l] are the CONVOLUTION's: rows = the layer's input channels, k = the layer's couts
             const int pco = co < t.rot_n[l] ? (co + t.rot[l] < t.rot_n[l] ? co + t.rot[l] : co + t.rot[l] - t.rot_n[l]) : co;
-            if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(ci) * t.cout[l] + pco) * taps + (taps - 1 - tap)];
+            const int kk = ci - (co < t.base[l] ? t.koff[l] : 0);          // the layer's cout at this k
+            if (co < t.cout[l] && kk >= 0 && kk < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(kk) * t.cout[l] + pco) * taps + (taps - 1 - tap)];
         } else {
             const int pci = ci < t.rot_n[l] ? (ci + t.rot[l] < t.rot_n[l] ? ci + t.rot[l] : ci + t.rot[l] - t.rot_n[l]) : ci;
             if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + pci) * taps + tap];
@@ -259,7 +275,9 @@ extern "C" int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int
 // FCDenseNet57 forward over bf16 level buffers (reference models.py:171-187)
 // ---------------------------------------------------------------------------------------------
 struct endo_net16 {
-    int n, h, w;
+    int n, h, w;               // n: all samples of a call = groups x gn
+    int gn, groups;            // sample groups: each has its own BatchNorm batch statistics (bf16_conv_kernels.h)
+    int64_t gs_saved, gs_sums; // floats / doubles between the groups' (mean, rstd) tables and forward sums (the backward sums: gs_saved doubles)
     struct Level { int h, w, t; int64_t plane; int64_t act; int64_t sums; } lv[k16Levels + 1];      // act: bytes, sums: doubles (from sums_off)
     int64_t in_off;            // bytes: the packed input [n][h][w][8] bf16
     int64_t idx_off[k16Levels];
@@ -285,12 +303,13 @@ struct endo_net16 {
     int use_wstream = 0;
 };
 
-extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
-    if (!out || n <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32)) return ENDO_E_BADARG;
+extern "C" int endo_net16_create(endo_net16** out, int n_per_group, int h, int w, int groups) {
+    if (!out || n_per_group <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32) || groups < 1 || groups > 2) return ENDO_E_BADARG;
+    const int n = n_per_group * groups;
     const Table16& tb = table16();
     endo_net16* net = new (std::nothrow) endo_net16();
     if (!net) return ENDO_E_BADARG;
-    net->n = n; net->h = h; net->w = w;
+    net->n = n; net->h = h; net->w = w; net->gn = n_per_group; net->groups = groups;
     auto align = [](int64_t v) { return (v + 255) / 256 * 256; };
     int64_t off = 0, sums = 0;
     for (int l = 0; l <= k16Levels; ++l) {
@@ -302,8 +321,9 @@ extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
     net->in_off = off; off += align(static_cast<int64_t>(n) * net->lv[0].plane * 16);
     for (int l = 0; l < k16Levels; ++l) { net->idx_off[l] = off; off += align(static_cast<int64_t>(n) * net->lv[l + 1].plane * (c16_down_in(l) + k16New)); }
     net->pre_off = off; off += align(static_cast<int64_t>(n) * net->lv[0].plane * 4);
-    net->saved_off = off; off += align(tb.saved_floats * 4);
-    net->sums_off = off; net->sums_bytes = sums * 8; off += align(net->sums_bytes);
+    net->gs_saved = tb.saved_floats; net->gs_sums = sums;
+    net->saved_off = off; off += align(tb.saved_floats * 4 * groups);
+    net->sums_off = off; net->sums_bytes = sums * 8 * groups; off += align(net->sums_bytes);
     net->w16_off = off; off += align(tb.w16_elems * 2);
     net->tape_bytes = off;
     {
@@ -311,8 +331,8 @@ extern "C" int endo_net16_create(endo_net16** out, int n, int h, int w) {
         net->ws_d[0] = o; o += align(static_cast<int64_t>(n) * net->lv[0].plane * net->lv[0].t * 2);
         net->ws_zero_begin = o;
         for (int l = 1; l <= k16Levels; ++l) { net->ws_d[l] = o; o += align(static_cast<int64_t>(n) * net->lv[l].plane * net->lv[l].t * 2); }
-        for (int l = 0; l <= k16Levels; ++l) { net->ws_pq[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 4); }
-        net->ws_bnsums = o; o += align(tb.saved_floats * 8);
+        for (int l = 0; l <= k16Levels; ++l) { net->ws_pq[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 4 * groups); }
+        net->ws_bnsums = o; o += align(tb.saved_floats * 8 * groups);
         for (int l = 0; l <= k16Levels; ++l) { net->ws_gsum[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 8); }
         net->ws_zero_end = o;
         net->ws_w16d = o; o += align(tb.w16d_elems * 2);
@@ -404,6 +424,7 @@ void fill_io(const Ctx16& c, Conv16Params& p, int in_level, int ic0, int cin, in
     p.wgt = c.w16(cv); p.bias = c.params + cv.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
     p.out = c.act(out_level); p.out_t = lo.t; p.out_blk = k16Blk; p.out_ns = lo.plane * lo.t; p.oc0 = oc0; p.cout = cv.cout;
     p.out_sums = c.training ? c.sums(out_level) + 2 * oc0 : nullptr;
+    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_in_sums = c.net->gs_sums; p.gs_out_sums = c.net->gs_sums; p.gs_saved = c.net->gs_saved;
 }
 
 void fill_bn(const Ctx16& c, Conv16Params& p, const Bn16& b, int level, int ic0) {
@@ -413,7 +434,7 @@ void fill_bn(const Ctx16& c, Conv16Params& p, const Bn16& b, int level, int ic0)
     p.gamma = c.params + b.g; p.beta = c.params + b.b;
     p.running_mean = c.bn_running + b.run_mean; p.running_var = c.bn_running + b.run_var;
     p.saved = c.saved(b);
-    p.count = static_cast<double>(c.net->n) * lv.plane;
+    p.count = static_cast<double>(c.net->gn) * lv.plane;
     p.eps = 1.0e-5f; p.momentum = 0.1f; p.training = c.training;
 }
 
@@ -491,6 +512,7 @@ extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_ru
         p.wgt = c.w16(tb.first); p.bias = params + tb.first.b;
         p.out = c.act(0); p.out_t = net->lv[0].t; p.out_blk = k16Blk; p.out_ns = net->lv[0].plane * net->lv[0].t; p.oc0 = 0; p.cout = k16First;
         p.out_sums = training ? c.sums(0) : nullptr;
+        p.group_n = net->groups > 1 ? net->gn : 0; p.gs_out_sums = net->gs_sums;
         rc = launch_bf16_conv<3, 3, 0, 8, 2>(p, stream);
         if (rc) return rc;
     }
@@ -540,15 +562,20 @@ int prep_dy16(const Ctx16& c, int level, int c0, int count, float* bias_grad) {
     bx = bx > 1024 ? 1024 : bx;
     const dim3 grid = c.training ? dim3(bx, c.net->n) : dim3(1, 1);          // inference mode: only the bias gradient
     bf16_prep_dy_kernel<<<grid, 256, 0, c.stream>>>(c.dbuf(level), c.act(level), lv.plane * lv.t, static_cast<int>(lv.plane), k16Blk, c0, count,
-                                                                  c.pq_p(level), c.pq_q(level), bias_grad, c.gsum(level), c.training);
+                                                                  c.pq_p(level), c.pq_q(level), bias_grad, c.gsum(level), c.training,
+                                                                  c.net->groups > 1 ? c.net->gn : 0, 2 * lv.t);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
-int bn_finalize16(const Ctx16& c, const Bn16& b, const Conv16& cv, int level) {
+// channels [first, first + count) of the layer's input (count < 0: all of them)
+int bn_finalize16(const Ctx16& c, const Bn16& b, const Conv16& cv, int level, int first = 0, int count = -1) {
     const auto& lv = c.net->lv[level];
-    bf16_bn_finalize_kernel<<<(b.c + 127) / 128, 128, 0, c.stream>>>(c.bnsums(b), c.saved(b), c.params + b.g, c.grads + b.g, c.grads + b.b, c.pq_p(level),
-                                                                     c.pq_q(level), c.gsum(level), b.c, cv.rot, cv.rot_n, static_cast<double>(c.net->n) * lv.plane, c.training);
+    if (count < 0) count = b.c - first;
+    if (count == 0) return 0;
+    bf16_bn_finalize_kernel<<<dim3((count + 127) / 128, c.net->groups), 128, 0, c.stream>>>(
+        c.bnsums(b), c.saved(b), c.params + b.g, c.grads + b.g, c.grads + b.b, c.pq_p(level), c.pq_q(level), c.gsum(level), first, count, cv.rot, cv.rot_n,
+        static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved, 2 * lv.t);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -558,6 +585,7 @@ void fill_wgrad_a(const Ctx16& c, Wgrad16Params& p, int level, int ac0, int cin,
     p.a = c.act(level); p.a_ns = lv.plane * lv.t; p.a_blk = k16Blk; p.a_h = lv.h; p.a_w = lv.w; p.ac0 = ac0; p.cin = cin;
     if (b) { p.saved = c.saved(*b); p.gamma = c.params + b->g; p.beta = c.params + b->b; }
     p.rot = cv.rot; p.rot_n = cv.rot_n;
+    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved;
     p.partial = c.partial();
 }
 
@@ -571,13 +599,18 @@ void fill_dgrad(const Ctx16& c, Conv16Params& p, int g_level, int gc0, int level
     p.out = c.dbuf(level); p.out_t = lv.t; p.out_blk = k16Blk; p.out_ns = lv.plane * lv.t; p.oc0 = 0; p.cout = cv.cin;
     p.x = c.act(level); p.x_saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
     p.out_sums = c.bnsums(b);
+    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_out_sums = c.net->gs_saved;
 }
 
-// dense layer (reads [0, cin), wrote [oc0, oc0 + 12)): bias gradient + deferred terms, weight gradient, data gradient, BN parameters
-int dense_bwd16(const Ctx16& c, int level, int oc0, const Bn16& b, const Conv16& cv) {
+// dense layer j of a block with `c0` base channels (reads [0, c0 + 12 j), wrote [c0 + 12 j, + 12)): bias gradient + deferred terms,
+// weight gradient, and the data gradient with respect to the NEW maps it reads ([c0, c0 + 12 j): they carry the layer-to-layer
+// dependency); the base channels of all four layers follow in one pass (dense_block_bwd16)
+int dense_bwd16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const Conv16& cv) {
     const auto& lv = c.net->lv[level];
+    const int oc0 = c0 + k16Growth * j;
     int rc = prep_dy16(c, level, oc0, cv.cout, c.grads + cv.b);
     if (rc) return rc;
+    const double px = static_cast<double>(c.net->n) * lv.plane;
     {
         Wgrad16Params p{};
         p.n = c.net->n; p.h = lv.h; p.w = lv.w;
@@ -586,26 +619,47 @@ int dense_bwd16(const Ctx16& c, int level, int oc0, const Bn16& b, const Conv16&
         hipStream_t side;
         rc = c.fork_wgrad(side);
         if (rc) return rc;
-        const double px = static_cast<double>(c.net->n) * lv.plane;
         ProfScope prof(kProfWgradDense, side, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin + cv.cout));
         rc = launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
         if (rc) return rc;
     }
+    if (j == 0) return 0;
     Conv16Params p{};
     fill_dgrad(c, p, level, oc0, level, b, cv);
+    p.oc0 = c0; p.cout = k16Growth * j; p.co_off = c0; p.grp0 = c0 / 48; p.wgroups = (cv.cin + 47) / 48;
     {
-        // per input channel and pixel: the forward value (2 B) and the gradient read and written (2 + 2 B); per output channel 2 B
-        const double px = static_cast<double>(c.net->n) * lv.plane;
-        ProfScope prof(kProfDgradDense, c.stream, 2.0 * px * cv.cin * cv.cout * 9, px * (6.0 * cv.cin + 2.0 * cv.cout));
+        ProfScope prof(kProfDgradDense, c.stream, 2.0 * px * p.cout * cv.cout * 9, px * (6.0 * p.cout + 2.0 * cv.cout));
         rc = launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2>(p, c.stream);
     }
     if (rc) return rc;
-    return bn_finalize16(c, b, cv, level);
+    return bn_finalize16(c, b, cv, level, c0, k16Growth * j);
 }
 
-int dense_block_bwd16(const Ctx16& c, int level, int new0, const Bn16* bn, const Conv16* cv) {
+// a dense block with c0 base channels [0, c0) and its four layers' maps at [c0, c0 + 48)
+int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const Conv16* cv) {
     for (int j = k16Layers - 1; j >= 0; --j) {
-        const int rc = dense_bwd16(c, level, new0 + k16Growth * j, bn[j], cv[j]);
+        const int rc = dense_bwd16(c, level, c0, j, bn[j], cv[j]);
+        if (rc) return rc;
+    }
+    const auto& lv = c.net->lv[level];
+    DgradBlock16Params p{};
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    p.g = c.dbuf(level); p.out = c.dbuf(level); p.x = c.act(level); p.ns = lv.plane * lv.t; p.blk = k16Blk; p.gc0 = c0; p.c0 = c0;
+    for (int j = 0; j < k16Layers; ++j) {
+        p.wgt[j] = c.w16d(cv[j]); p.saved[j] = c.saved(bn[j]); p.gamma[j] = c.params + bn[j].g; p.beta[j] = c.params + bn[j].b;
+        p.sums[j] = c.bnsums(bn[j]);
+    }
+    p.rot = cv[0].rot; p.rot_n = cv[0].rot_n;
+    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_sums = c.net->gs_saved;
+    {
+        // per base channel and pixel: forward value 2 B, gradient read + written 4 B; the 48 gradient maps 2 B each
+        const double px = static_cast<double>(c.net->n) * lv.plane;
+        ProfScope prof(kProfDgradDense, c.stream, 2.0 * px * c0 * k16New * 9, px * (6.0 * c0 + 2.0 * k16New));
+        const int rc = launch_bf16_dgrad_block(p, c.stream);
+        if (rc) return rc;
+    }
+    for (int j = 0; j < k16Layers; ++j) {
+        const int rc = bn_finalize16(c, bn[j], cv[j], level, 0, c0);
         if (rc) return rc;
     }
     return 0;
@@ -698,7 +752,7 @@ extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* 
             const Conv16& cv = *tb.dconvs[l];
             const int64_t groups = (cv.cin + 47) / 48, chunks = (cv.cout + kBfKC - 1) / kBfKC;
             t.start[l] = start; t.w[l] = cv.w; t.out[l] = cv.w16d; t.cout[l] = cv.cin; t.cin[l] = cv.cout; t.cin_k[l] = cv.cout; t.ks[l] = cv.ks; t.nt[l] = 3;
-            t.rot[l] = cv.rot; t.rot_n[l] = cv.rot_n;
+            t.rot[l] = cv.rot; t.rot_n[l] = cv.rot_n; t.base[l] = cv.base; t.koff[l] = cv.koff;
             start += chunks * groups * cv.ks * cv.ks * 3 * 16 * 32;
         }
         t.start[t.layers] = start;

@@ -393,16 +393,26 @@ class FCDenseNet(nn.Module):
         out, _ = self._run_forward16(_lib.dev_f32(x, "FCDenseNet57 input"))
         return out
 
-    def _handle16(self, n, h, w):
+    def _handle16(self, n, h, w, groups=1):
+        """n: samples per group"""
         lib = _lib.load()
-        key = ("bf16", n, h, w)
+        key = ("bf16", n, h, w, groups)
         if key not in self._handles:
             hnd = ctypes.c_void_p()
-            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w), "endo_net16_create(%d,%d,%d)" % (n, h, w))
+            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w, groups), "endo_net16_create(%d,%d,%d,%d)" % (n, h, w, groups))
             self._handles[key] = (hnd, int(lib.endo_net16_tape_bytes(hnd)), int(lib.endo_net16_bwd_workspace_bytes(hnd)))
         return self._handles[key]
 
-    def _run_forward16(self, x):
+    def forward_pair_bf16_storage(self, x1, x2):
+        """(forward_bf16_storage(x1), forward_bf16_storage(x2)) as ONE pass over a grouped batch (endo_net16 with two sample groups: every
+        launch covers both frames, each frame keeps its own BatchNorm batch statistics, the running statistics are updated with x1's
+        first) -- what a training step runs.  No autograd node: TrainingStep differentiates it through ``_run_backward16``."""
+        x = torch.cat([_lib.dev_f32(x1, "FCDenseNet57 input"), _lib.dev_f32(x2, "FCDenseNet57 input")], dim=0)
+        out, _ = self._run_forward16(x, 2)
+        n = x1.shape[0]
+        return out[:n], out[n:]
+
+    def _run_forward16(self, x, groups=1):
         lib = _lib.load()
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected N x 3 x H x W input")
@@ -411,21 +421,21 @@ class FCDenseNet(nn.Module):
         if not self._views_intact():
             self._flatten()
         n, _, h, w = x.shape
-        hnd, tape_bytes, _ = self._handle16(n, h, w)
+        hnd, tape_bytes, _ = self._handle16(n // groups, h, w, groups)
         tape = torch.empty(tape_bytes, dtype=torch.uint8, device=x.device)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         with torch.no_grad():
             _lib.check(lib.endo_net16_fwd(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out), _lib.ptr(tape),
                                           1 if self.training else 0, _lib.stream()), "endo_net16_fwd")
         if self.training:
-            self._nbt.add_(1)
+            self._nbt.add_(groups)
         return out, tape
 
-    def _run_backward16(self, shape, tape, grad_out, training):
+    def _run_backward16(self, shape, tape, grad_out, training, groups=1):
         lib = _lib.load()
         n, _, h, w = shape
-        hnd, _, ws_bytes = self._handle16(n, h, w)
-        key = ("bf16", n, h, w)
+        hnd, _, ws_bytes = self._handle16(n // groups, h, w, groups)
+        key = ("bf16", n // groups, h, w, groups)
         if key not in self._gradws:
             self._gradws[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=tape.device)
         self._attach_grads()

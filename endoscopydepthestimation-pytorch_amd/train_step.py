@@ -49,7 +49,8 @@ class TrainingStep(object):
         self.model = model
         # the network over bf16 level buffers (FCDenseNet.forward_bf16_storage: activations and inter-layer gradients stored as
         # bf16, bf16 matrix cores, fp32 accumulation / statistics / parameter gradients; BASELINE configs[2]); the two frames are two
-        # calls of the network, as in the reference (train.py:276-277); losses, clipping and SGD stay fp32
+        # sample groups of one call (each with its own BatchNorm statistics, as the reference's two calls, train.py:276-277); losses,
+        # clipping and SGD stay fp32
         self.bf16_storage = bool(bf16_storage)
         if self.bf16_storage and not (fused_head and pair_forward):
             raise ValueError("bf16_storage runs through the fused loss head")
@@ -126,9 +127,7 @@ class TrainingStep(object):
             _lib.check(lib.endo_mask_mul(_lib.ptr(c1), _lib.ptr(b), _lib.ptr(x[:n]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
             _lib.check(lib.endo_mask_mul(_lib.ptr(c2), _lib.ptr(b), _lib.ptr(x[n:]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
             if self.bf16_storage:
-                p1, t1 = self.model._run_forward16(x[:n])
-                p2, t2 = self.model._run_forward16(x[n:])
-                pred, tape = torch.cat([p1, p2], dim=0), (t1, t2)
+                pred, tape = self.model._run_forward16(x, 2)       # both frames as two sample groups of one call
             else:
                 pred, tape = self.model._run_forward(x, 2)          # (2N, 1, H, W): frame 1's predictions first
             need = int(lib.endo_loss_head_workspace_floats(n, h, w))
@@ -150,10 +149,7 @@ class TrainingStep(object):
     def _fused_backward(self, x, tape, grad_pred):
         with torch.no_grad():
             if self.bf16_storage:
-                n = x.shape[0] // 2
-                shape = (n,) + tuple(x.shape[1:])
-                self.model._run_backward16(shape, tape[1], grad_pred[n:], self.model.training)
-                self.model._run_backward16(shape, tape[0], grad_pred[:n], self.model.training)
+                self.model._run_backward16(tuple(x.shape), tape, grad_pred, self.model.training, 2)
             else:
                 self.model._run_backward(x, tape, grad_pred, self.model.training, 2)
 

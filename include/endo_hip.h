@@ -383,7 +383,9 @@ int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int cin, const
  * 256-byte aligned; training as in the forward call (0: BatchNorm as a fixed affine map).  Gradients between layers are stored as
  * bf16; BatchNorm sums (fp64), parameter gradients and the deferred BatchNorm terms (fp32) are not. */
 typedef struct endo_net16 endo_net16;
-int endo_net16_create(endo_net16** out, int n, int h, int w);
+/* n_per_group x groups samples per call (groups 1 or 2): every group has its own BatchNorm batch statistics and the running statistics are
+ * updated with group 0's first -- one call with groups = 2 equals the reference's two network calls of a training step (train.py:276-277) */
+int endo_net16_create(endo_net16** out, int n_per_group, int h, int w, int groups);
 void endo_net16_destroy(endo_net16* net);
 int64_t endo_net16_tape_bytes(const endo_net16* net);
 int endo_net16_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape, int training,

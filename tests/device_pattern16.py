@@ -43,7 +43,7 @@ def level_buffer(lib, hnd, buf, what, level, n, h, w):
 
 def pattern_from_tape(model, tape, n, h, w):
     lib = ea._lib.load()
-    hnd, _, _ = model._handle16(n, h, w)
+    hnd, _, _ = model._handle16(n, h, w, 1)
     params = dict(model.named_parameters())
     raw = tape.detach().cpu().numpy()
     levels = [level_buffer(lib, hnd, tape, 3, lvl, n, h, w) for lvl in range(6)]

@@ -40,7 +40,7 @@ for v in trace.values():
     if v.requires_grad:
         v.retain_grad()
 y64.backward(g.double())
-ws = m._gradws[("bf16", n, h, w)]
+ws = m._gradws[("bf16", n, h, w, 1)]
 lib = ea._lib.load()
 
 T = [192, 256, 288, 352, 384, 352]

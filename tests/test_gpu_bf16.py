@@ -325,3 +325,46 @@ def test_bf16_storage_step_timing():
         res[name] = e0.elapsed_time(e1) / 5
     print("network forward + backward, two batches of 8 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (
         res["bf16 storage"], res["fp32"]))
+
+
+def test_bf16_storage_pair_as_two_groups():
+    """One call with two sample groups (what TrainingStep(bf16_storage=True) runs) against two calls: outputs, running statistics and
+    parameter gradients.  The kernels are the same and every sample sees the same arithmetic; what differs is the order of the fp64
+    atomics behind the BatchNorm sums and of the fp32 atomics behind the parameter gradients."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w = 2, 64, 96
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(31)
+    x1, x2 = (torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)).to(dev()) for _ in range(2))
+    g1, g2 = (torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)).to(dev()) for _ in range(2))
+    res = {}
+    for how in ("two calls", "two groups"):
+        m = ea.FCDenseNet57(1)
+        m.load_state_dict(state)
+        m = m.to(dev()).train()
+        if how == "two calls":
+            y1 = m.forward_bf16_storage(x1)
+            y2 = m.forward_bf16_storage(x2)
+            torch.autograd.backward([y2, y1], [g2, g1])
+            ys = torch.cat([y1.detach(), y2.detach()])
+        else:
+            x = torch.cat([x1, x2])
+            with torch.no_grad():
+                ys, tape = m._run_forward16(x, 2)
+                m._run_backward16(tuple(x.shape), tape, torch.cat([g1, g2]), True, 2)
+        torch.cuda.synchronize()
+        res[how] = (ys.clone(), _grads_by_name(m), {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    ya, ga, sa = res["two calls"]
+    yb, gb, sb = res["two groups"]
+    assert float((ya - yb).abs().max() / ya.abs().max()) <= 1e-6
+    for k in sa:
+        if "num_batches" in k:
+            assert int(sa[k]) == int(sb[k]) == 2
+        else:
+            assert float((sa[k] - sb[k]).abs().max() / (sa[k].abs().max() + 1e-6)) <= 1e-5, k
+    floor = 1e-3 * max(float(v.abs().max()) for v in ga.values())
+    worst = max((float((ga[k] - gb[k]).abs().max()) / max(float(ga[k].abs().max()), floor), k) for k in ga)
+    print("two groups vs two calls: worst gradient tensor %s, %.2e" % (worst[1], worst[0]))
+    assert worst[0] <= 2e-3, worst
