@@ -228,13 +228,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         // ---- G ----
         if constexpr (KS == 3) {
             const int quads = (cout_g + 3) >> 2;
-            for (int it = tid; it < (kWgRows + 2) * (kWgCols + 2) * quads; it += 256) {
+            // (loads of a batch first, then its LDS writes: a load -> store loop pays the memory latency once per item)
+            constexpr int kGItems = (kWgRows + 2) * (kWgCols + 2) * 4, kGIter = (kGItems + 255) / 256;
+            u32x2_t gv[kGIter];
+#pragma unroll
+            for (int i = 0; i < kGIter; ++i) {
+                const int it = tid + i * 256;
                 const int q = it % quads, px = it / quads;
                 const int ry = px / (kWgCols + 2), rx = px - ry * (kWgCols + 2);          // tile pixel (ry - 1, rx - 1)
                 const int gy = y0 + ry - 1, gx = x0 + rx - 1;
-                u32x2_t v = u32x2_t{0u, 0u};
-                if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
-                    v = *reinterpret_cast<const u32x2_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 4 * q, static_cast<int64_t>(gy) * p.w + gx, g_plane, p.g_blk));
+                gv[i] = u32x2_t{0u, 0u};
+                if (it < (kWgRows + 2) * (kWgCols + 2) * quads && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
+                    gv[i] = *reinterpret_cast<const u32x2_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 4 * q, static_cast<int64_t>(gy) * p.w + gx, g_plane, p.g_blk));
+            }
+#pragma unroll
+            for (int i = 0; i < kGIter; ++i) {
+                const int it = tid + i * 256;
+                if (it >= (kWgRows + 2) * (kWgCols + 2) * quads) continue;
+                const int q = it % quads, px = it / quads;
+                const int ry = px / (kWgCols + 2), rx = px - ry * (kWgCols + 2);
+                const u32x2_t v = gv[i];
                 const uint16_t e[4] = {static_cast<uint16_t>(v[0] & 0xffffu), static_cast<uint16_t>(v[0] >> 16), static_cast<uint16_t>(v[1] & 0xffffu),
                                        static_cast<uint16_t>(v[1] >> 16)};
 #pragma unroll
@@ -242,8 +255,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
                     const int x = rx - 1 + kx - 1;          // copy kx holds G[x - kx + 1] at x
                     if (x < 0 || x >= kWgCols) continue;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<uint16_t*>(s_g + (4 * q + i) * kWgPitchG3 + (ry * 3 + kx) * 64 + x * 2) = e[i];
+                    for (int i2 = 0; i2 < 4; ++i2)
+                        *reinterpret_cast<uint16_t*>(s_g + (4 * q + i2) * kWgPitchG3 + (ry * 3 + kx) * 64 + x * 2) = e[i2];
                 }
             }
         } else {
@@ -277,33 +290,46 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         }
         // ---- a: relu(bn(x)) of the tile's own pixels, transposed to [channel][row][px]; u = ((k_hi * 128 + px) * 4 + k_lo), unit k_hi * 4 + k_lo ----
         const int units_hi = (units_c + 3) >> 2;
-        for (int it = tid; it < units_hi * 512; it += 256) {
-            const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
-            if (k >= units_c) continue;
-            const int ry = px >> 5, rx = px & 31;
-            const int gy = y0 + ry, gx = x0 + rx;
-            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-            const bool ok = gx < p.w && gy < p.h;
-            if (ok) {
-                const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
-                v = *reinterpret_cast<const u32x4_t*>(p.a + n * p.a_ns + blk_off(p.ac0 + ci0 + 8 * k, static_cast<int64_t>(sy) * p.a_w + sx, a_plane, p.a_blk));
-            }
-            float z[8];
+        for (int it0 = tid; it0 < units_hi * 512; it0 += 4 * 256) {          // batches of 4 units per thread: loads, then the rest
+            u32x4_t av[4];
+            bool aok[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { z[2 * j] = bf16_lo(v[j]); z[2 * j + 1] = bf16_hi(v[j]); }
-            if (p.saved) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4_t q = *reinterpret_cast<const f32x4_t*>(bn_g + 2 * (8 * k + 2 * j));
-                    z[2 * j] = ok ? fmaxf(fmaf(z[2 * j], q[0], q[1]), 0.f) : 0.f;
-                    z[2 * j + 1] = ok ? fmaxf(fmaf(z[2 * j + 1], q[2], q[3]), 0.f) : 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const int it = it0 + i * 256;
+                const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
+                const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+                av[i] = u32x4_t{0u, 0u, 0u, 0u};
+                aok[i] = it < units_hi * 512 && k < units_c && gx < p.w && gy < p.h;
+                if (aok[i]) {
+                    const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+                    av[i] = *reinterpret_cast<const u32x4_t*>(p.a + n * p.a_ns + blk_off(p.ac0 + ci0 + 8 * k, static_cast<int64_t>(sy) * p.a_w + sx, a_plane, p.a_blk));
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned pk = pack_bf16x2(z[2 * j], z[2 * j + 1]);
-                *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk & 0xffffu);
-                *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk >> 16);
+            for (int i = 0; i < 4; ++i) {
+                const int it = it0 + i * 256;
+                const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
+                if (it >= units_hi * 512 || k >= units_c) continue;
+                const int ry = px >> 5, rx = px & 31;
+                const u32x4_t v = av[i];
+                const bool ok = aok[i];
+                float z[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { z[2 * j] = bf16_lo(v[j]); z[2 * j + 1] = bf16_hi(v[j]); }
+                if (p.saved) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(bn_g + 2 * (8 * k + 2 * j));
+                        z[2 * j] = ok ? fmaxf(fmaf(z[2 * j], q[0], q[1]), 0.f) : 0.f;
+                        z[2 * j + 1] = ok ? fmaxf(fmaf(z[2 * j + 1], q[2], q[3]), 0.f) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned pk = pack_bf16x2(z[2 * j], z[2 * j + 1]);
+                    *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk >> 16);
+                }
             }
         }
         __syncthreads();

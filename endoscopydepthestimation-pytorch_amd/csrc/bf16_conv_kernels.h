@@ -109,6 +109,17 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
 
+// sum over the 16 lanes of a DPP row (the 16 pixels li of one lane group): four v_add with row_shr 8 / 4 / 2 / 1, valid in lane 15 of the
+// row.  (__shfl_xor is a ds_bpermute -- an LDS-pipe instruction; the BatchNorm sums need 8 of them per value and a fused
+// data-gradient block 768 per wave: measured as the largest single cost of that kernel.)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xf, 0xf, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true));
+    return v;
+}
+
 // byte offset of the 16-byte slot (channel part 0..3 of the chunk) of tile pixel (row, x) in the staged tile
 template <int COLS>
 __device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row * COLS + x) * 4 + (part ^ ((x >> 1) & 3))) * 16; }
@@ -543,14 +554,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    s1[t][i] += __shfl_xor(s1[t][i], off, 64);
-                    s2[t][i] += __shfl_xor(s2[t][i], off, 64);
-                }
-            }
-        if (li == 0) {
+            for (int i = 0; i < 4; ++i) { s1[t][i] = row16_sum(s1[t][i]); s2[t][i] = row16_sum(s2[t][i]); }
+        if (li == 15) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
 #pragma unroll

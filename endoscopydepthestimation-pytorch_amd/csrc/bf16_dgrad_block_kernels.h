@@ -16,8 +16,8 @@
 // A block: 16 x 32 pixels x 48 base channels (grid.y = base channels / 48), 8 waves x 2 rows.  LDS: the staged tile, 18 x 34 pixels x 7
 // slots of 16 bytes (6 units + 1 pad: a 112-byte pixel pitch puts the 16 pixels of a fragment read in 16 different bank groups), and
 // two weight buffers (layer j + 1 arrives by LDS-DMA while layer j multiplies: the converted weights are stored in the LDS image's own
-// order, slot swizzle included).  The BatchNorm sums of a layer leave after its phase (wave
-// shuffles, LDS across the waves, one fp64 atomic per channel and sum).
+// order, slot swizzle included).  The BatchNorm sums of a layer leave after its phase (DPP row
+// sums over the 16 pixels of a lane group, LDS across the waves, one fp64 atomic per channel and sum).
 #pragma once
 
 #include "bf16_conv_kernels.h"
@@ -76,16 +76,26 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
     // ---- the 48 gradient channels of the haloed tile: 6 units of 8 channels per pixel ----
     {
         const uint16_t* g_n = p.g + n * p.ns;
-        for (int u = tid; u < kDbRows * kDbCols * 6; u += 512) {
+        // all of a thread's loads first, then its LDS writes (a load -> store loop would pay the memory latency once per unit)
+        constexpr int kGUnits = kDbRows * kDbCols * 6, kGIter = (kGUnits + 511) / 512;
+        u32x4_t gv[kGIter];
+#pragma unroll
+        for (int i = 0; i < kGIter; ++i) {
+            const int u = tid + i * 512;
             const int px = u / 6, unit = u - 6 * px;
             const int ry = px / kDbCols, rx = px - ry * kDbCols;
             const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
-            u32x4_t v = u32x4_t{0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
+            gv[i] = u32x4_t{0u, 0u, 0u, 0u};
+            if (u < kGUnits && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w) {
                 const int ca = p.gc0 + 8 * unit, cb = ca / p.blk;
-                v = *reinterpret_cast<const u32x4_t*>(g_n + (cb * plane + static_cast<int64_t>(gy) * p.w + gx) * p.blk + (ca - cb * p.blk));
+                gv[i] = *reinterpret_cast<const u32x4_t*>(g_n + (cb * plane + static_cast<int64_t>(gy) * p.w + gx) * p.blk + (ca - cb * p.blk));
             }
-            *reinterpret_cast<u32x4_t*>(s_g + px * kDbPitch + unit * 16) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < kGIter; ++i) {
+            const int u = tid + i * 512;
+            const int px = u / 6, unit = u - 6 * px;
+            if (u < kGUnits) *reinterpret_cast<u32x4_t*>(s_g + px * kDbPitch + unit * 16) = gv[i];
         }
     }
     // weights of a layer: the group's 27 KB are stored in global memory as the LDS image ([tap][nt][16 rows][4 slots], slot = k / 8
@@ -205,14 +215,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) {
-                    s1[t][i] += __shfl_xor(s1[t][i], off, 64);
-                    s2[t][i] += __shfl_xor(s2[t][i], off, 64);
-                }
-                if (li == 0) {
-                    red[wave * 96 + 2 * (16 * t + 4 * lk + i)] = s1[t][i];
-                    red[wave * 96 + 2 * (16 * t + 4 * lk + i) + 1] = s2[t][i];
+                const float r1 = row16_sum(s1[t][i]), r2 = row16_sum(s2[t][i]);
+                if (li == 15) {
+                    red[wave * 96 + 2 * (16 * t + 4 * lk + i)] = r1;
+                    red[wave * 96 + 2 * (16 * t + 4 * lk + i) + 1] = r2;
                 }
             }
     }
@@ -223,7 +229,15 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
         for (int wv = 0; wv < 8; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
         atomicAdd(p.sums[kDbLayers - 1] + grp * p.gs_sums + 2 * co_base + tid, tsum);
     }
-    // ---- one read-modify-write of the gradient buffer ----
+    // ---- one read-modify-write of the gradient buffer: all reads, then the sums and the writes ----
+    u32x2_t old[NT][R][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh)
+                old[t][r][hh] = pix[r][hh] >= 0 ? *reinterpret_cast<const u32x2_t*>(out_n + quad_off(t, pix[r][hh])) : u32x2_t{0u, 0u};
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -231,11 +245,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 if (pix[r][hh] < 0) continue;
-                uint16_t* dst = out_n + quad_off(t, pix[r][hh]);
-                const u32x2_t old = *reinterpret_cast<const u32x2_t*>(dst);
+                const u32x2_t o = old[t][r][hh];
                 const float* tt = total[t][r][hh];
-                *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_bf16x2(bf16_lo(old[0]) + tt[0], bf16_hi(old[0]) + tt[1]),
-                                                                                pack_bf16x2(bf16_lo(old[1]) + tt[2], bf16_hi(old[1]) + tt[3])};
+                *reinterpret_cast<u32x2_t*>(out_n + quad_off(t, pix[r][hh])) = u32x2_t{pack_bf16x2(bf16_lo(o[0]) + tt[0], bf16_hi(o[0]) + tt[1]),
+                                                                                      pack_bf16x2(bf16_lo(o[1]) + tt[2], bf16_hi(o[1]) + tt[3])};
             }
 }
 

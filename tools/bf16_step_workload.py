@@ -1,5 +1,5 @@
 """Profiling workload (development tool): the bf16-storage network forward + backward of a training step's two batches
-(8 x 256 x 320 each), 5 iterations after 2 of warm-up.  usage: rocprofv3 --kernel-trace --stats -- python3 tools/bf16_step_workload.py"""
+(8 x 256 x 320 each, two sample groups of one call), 7 iterations.  usage: rocprofv3 --kernel-trace --stats -- python3 tools/bf16_step_workload.py"""
 import importlib
 import os
 import sys
@@ -17,9 +17,11 @@ m = m.to(dev).train()
 x1 = torch.rand((n, 3, h, w), device=dev) * 2 - 1
 x2 = torch.rand((n, 3, h, w), device=dev) * 2 - 1
 g = torch.randn((n, 1, h, w), device=dev)
-for it in range(7):
-    y1 = m.forward_bf16_storage(x1)
-    y2 = m.forward_bf16_storage(x2)
-    torch.autograd.backward([y1, y2], [g, g])
+x = torch.cat([x1, x2])
+gg = torch.cat([g, g])
+for it in range(7):          # both frames as two sample groups of one call, as TrainingStep(bf16_storage=True) runs them
+    with torch.no_grad():
+        y, tape = m._run_forward16(x, 2)
+        m._run_backward16(tuple(x.shape), tape, gg, True, 2)
 torch.cuda.synchronize()
 print("done")
