@@ -1,8 +1,8 @@
-// bf16-storage kernel family: host side (round 3).  What exists: layout conversion, the channels-last convolution (dense layer,
-// transition up, transition down with its max-pool, first convolution), the final 1x1 + |.|, and on top of them the FORWARD pass of
-// FCDenseNet57 (reference models.py:171-187) over bf16 level buffers -- training-mode (batch statistics, running-statistics
-// update) and inference.  The backward pass over this layout is the next round's work; nothing here is on the fp32
-// product path.
+// bf16-storage kernel family: host side (round 3).  Layout conversion and the single-convolution bricks the tests
+// drive, and on top of them FCDenseNet57 (reference models.py:171-187) over bf16 level buffers in 32-channel blocks: endo_net16_fwd
+// (training mode: batch statistics + running-statistics update; inference) and endo_net16_bwd (parameter gradients into the fp32
+// family's flat gradient buffer).  One or two sample groups per call (a training pair's two frames, each with its own statistics).
+// A separate network implementation next to the fp32 one (net.hip): same parameters, same tensors at the boundary.
 #include <vector>
 
 #include "bf16_conv_kernels.h"

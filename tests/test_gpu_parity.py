@@ -595,11 +595,11 @@ def reference_pattern(state64, x64):
     own = {}
     plain = onet._bn_relu
 
-    def recording(state, prefix, xx, training, pattern=None):
+    def recording(state, prefix, xx, training, pattern=None, quant=None):
         yy = F.batch_norm(xx, state[prefix + ".running_mean"].clone(), state[prefix + ".running_var"].clone(),
                           state[prefix + ".weight"], state[prefix + ".bias"], training, onet.BN_MOMENTUM, onet.BN_EPS)
         own["relu::" + prefix] = yy > 0
-        return plain(state, prefix, xx, training, pattern)
+        return plain(state, prefix, xx, training, pattern, quant)
     onet._bn_relu = recording
     try:
         with torch.no_grad():
