@@ -455,7 +455,7 @@ def main():
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
     traffic, traffic_src = (None, None)
-    if args.config in (1, 2):
+    if args.config in (1, 2, 5):
         traffic, traffic_src = pmc_traffic(dom_name, args.config)      # bytes per step -> per launch with the launches counted here
     if traffic is not None and cnt:
         traffic = traffic / (cnt / args.steps)
