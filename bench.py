@@ -211,7 +211,7 @@ def cpu_baseline(cfg):
             "ms_per_step": full["ms_per_step"], "timed_iterations": full["iterations"], "batch": cfg["batch"], "batch1_by_threads": sweep}
 
 
-def dispatches_per_step():
+def dispatches_per_step(config=1):
     """Kernel dispatches per training step, from the newest rocprofv3 kernel-trace summary under profiles/ (tools/summarize_rocprof.py
     writes `*_kernel_stats.json` next to the table) -- counted by the profiler, not estimated, and tied to the kernel sources by their
     hash: a summary of another revision is refused (None + the reason).  In-process counting was tried and dropped: this stack's
@@ -219,9 +219,10 @@ def dispatches_per_step():
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_id import csrc_sha256
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.json")))
+    suffix = "_kernel_stats.json" if config in (1, 2, 3, 4) else "_kernel_stats_config%d.json" % config
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
-        return {"value": None, "source": "no profiles/*_kernel_stats.json"}
+        return {"value": None, "source": "no profiles/*" + suffix}
     name = "profiles/" + os.path.basename(files[-1])
     try:
         with open(files[-1]) as fh:
@@ -482,7 +483,7 @@ def main():
         "per_rank_pairs_per_s": per_rank,
         "skipped_steps": skipped,
         "kernel_options_overridden": args.kernel_option or None,
-        "dispatches_per_step": dispatches_per_step(),
+        "dispatches_per_step": dispatches_per_step(args.config),
         "conv_roofline_frac_whole_step": (pairs / elapsed) * pair_gflop / 1e3 / (FP32_MFMA_PEAK_TFLOPS * world),
         "depth_warp_fwd_bwd_ms_per_pair": warp_ms_per_pair,
         "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": achieved,

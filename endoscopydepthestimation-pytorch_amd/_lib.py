@@ -51,6 +51,7 @@ SIGNATURES = {
     "endo_net16_tape_bytes": (_L, [_P]),
     "endo_net16_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_net16_bwd_workspace_bytes": (_L, [_P]),
+    "endo_net16_set_wgrad_overlap": (_I, [_P, _I]),
     "endo_net16_offset": (_L, [_P, _I, _I]),
     "endo_net16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -300,7 +300,7 @@ struct endo_net16 {
     // the optimizer: they run on a side stream, forked after every prep_dy and joined once at the end (as in the fp32 family)
     hipStream_t wstream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int use_wstream = 0;
+    int use_wstream = 1;
 };
 
 extern "C" int endo_net16_create(endo_net16** out, int n_per_group, int h, int w, int groups) {
@@ -363,6 +363,13 @@ extern "C" void endo_net16_destroy(endo_net16* net) {
     if (net->wstream) (void)hipStreamDestroy(net->wstream);
     delete net;
 }
+// 1 (default): endo_net16_bwd issues the weight gradients on a side stream it owns (forked after every prep_dy, joined before it returns);
+// 0: everything in line on the caller's stream (what a caller capturing the step into a graph on one stream wants)
+extern "C" int endo_net16_set_wgrad_overlap(endo_net16* net, int on) {
+    if (!net) return ENDO_E_BADARG;
+    net->use_wstream = on ? 1 : 0;
+    return 0;
+}
 extern "C" int64_t endo_net16_tape_bytes(const endo_net16* net) { return net ? net->tape_bytes : 0; }
 extern "C" int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net) { return net ? net->ws_bytes : 0; }
 // Where things are (tests read the forward pass's decisions and the gradient buffers): byte offsets into the tape -- what 0: final
@@ -403,8 +410,9 @@ struct Ctx16 {
     float* partial() const { return reinterpret_cast<float*>(ws + net->ws_partial); }
     // the side stream, after everything issued on `stream` so far
     int fork_wgrad(hipStream_t& side) const {
-        side = net->wstream ? net->wstream : stream;
-        if (net->wstream) {
+        const bool on = net->wstream && net->use_wstream;
+        side = on ? net->wstream : stream;
+        if (on) {
             ENDO_CHECK(hipEventRecord(net->ev_fork, stream));
             ENDO_CHECK(hipStreamWaitEvent(net->wstream, net->ev_fork, 0));
         }
@@ -734,8 +742,6 @@ extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     Ctx16 c{net, params, nullptr, const_cast<char*>(static_cast<const char*>(tape_)), training, stream};
     c.grads = grads; c.ws = static_cast<char*>(ws_);
-    // (measured, profiles/r03_r: with the weight gradients on the side stream both they and the data-gradient kernels slow down by as
-    // much as the overlap buys -- 22.4 vs 21.6 ms per forward + backward of the two batches; the stream is created only on request)
     if (!net->wstream && net->use_wstream) {
         ENDO_CHECK(hipStreamCreateWithFlags(&net->wstream, hipStreamNonBlocking));
         ENDO_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
@@ -800,7 +806,7 @@ extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* 
         rc = launch_bf16_wgrad<3>(p, grads + tb.first.w, side);
         if (rc) return rc;
     }
-    if (net->wstream) {          // join: the caller's stream continues only after every weight gradient has landed
+    if (net->wstream && net->use_wstream) {          // join: the caller's stream continues only after every weight gradient has landed
         ENDO_CHECK(hipEventRecord(net->ev_join, net->wstream));
         ENDO_CHECK(hipStreamWaitEvent(stream, net->ev_join, 0));
     }

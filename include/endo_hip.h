@@ -391,6 +391,9 @@ int64_t endo_net16_tape_bytes(const endo_net16* net);
 int endo_net16_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape, int training,
                    void* stream);
 int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net);
+/* 1 (default): endo_net16_bwd runs the weight gradients on a side stream of its own, forked from and joined back into the caller's
+ * stream by events before it returns; 0: everything in line on the caller's stream */
+int endo_net16_set_wgrad_overlap(endo_net16* net, int on);
 /* byte offsets into the tape (what 0: final pre-activation fp32; 1: (mean, rstd) of BatchNorm `index` in module order; 2: max-pool
  * codes of transition down `index` ([n][h / 2][w / 2][cout] bytes); 3: level buffer `index`) or the backward workspace (4: gradient
  * buffer of level `index`); 5: channels of level buffer `index`.  Level buffers: [n][t / 32][h][w][32] bf16, channels [0, S) the
