@@ -18,9 +18,10 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
     3   512 x 640, batch 4 per GPU, fp32
     4   256 x 320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10 ("adjacent range 5-30");
         fp32 storage (the fp16-storage half of configs[4] does not exist in this library)
-    2   256 x 320, batch 8 per GPU, bf16 MFMA operands over fp32 tensors (a mixed-precision mode of the fp32 family)
-    5   256 x 320, batch 8 per GPU, BF16 STORAGE: the network over bf16 level buffers (endo_net16_fwd / endo_net16_bwd) -- the
+    2   256 x 320, batch 8 per GPU, BF16 STORAGE: the network over bf16 level buffers (endo_net16_fwd / endo_net16_bwd) -- the
         per-GPU half of BASELINE.json configs[2] (bs 64 bf16 over 8 GPUs); its own line, never compared with configs[1]
+    5   (not a BASELINE config) 256 x 320, batch 8 per GPU, bf16 MFMA operands over fp32 tensors: the mixed-precision mode of the
+        fp32 family (round 2's --config 2)
 
 Extra objects on that line:
   roofline             the dominant kernel family (dense-layer conv3x3 forward/dgrad/wgrad: whichever took the most
@@ -58,12 +59,12 @@ CONFIGS = {
             metric="train frame-pairs/sec at 256x320 bs=8",
             workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
                      "256x320, batch 8 per GPU, fp32 (BASELINE.json configs[1])"),
-    2: dict(height=256, width=320, batch=8, gap=None, bf16_operands=True,
+    5: dict(height=256, width=320, batch=8, gap=None, bf16_operands=True,
             metric="train frame-pairs/sec at 256x320 bs=8, bf16 MFMA operands",
             workload="full training step, 256x320, batch 8 per GPU, MIXED PRECISION: the dense layers' forward / data-gradient / "
                      "weight-gradient kernels round their MFMA operands to bf16 (fp32 accumulation; tensors in memory, BN, reductions, "
-                     "geometry, losses and optimizer fp32) -- the per-GPU half of BASELINE.json configs[2] (bs 64 over 8 GPUs) "
-                     "without bf16 storage; NOT comparable with the fp32 line of configs[1]"),
+                     "geometry, losses and optimizer fp32) -- a mode of the fp32 family, not a BASELINE.json config (the bf16 config is "
+                     "--config 2); NOT comparable with the fp32 line of configs[1]"),
     3: dict(height=512, width=640, batch=4, gap=None,
             metric="train frame-pairs/sec at 512x640 bs=4",
             workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
@@ -72,7 +73,7 @@ CONFIGS = {
             metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30",
             workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, "
                      "fp32 storage (BASELINE.json configs[4] without its fp16-storage half)"),
-    5: dict(height=256, width=320, batch=8, gap=None, bf16_storage=True,
+    2: dict(height=256, width=320, batch=8, gap=None, bf16_storage=True,
             metric="train frame-pairs/sec at 256x320 bs=8, bf16 storage",
             workload="full training step, 256x320, batch 8 per GPU, BF16 STORAGE: the network's activations and inter-layer gradients "
                      "are stored as bf16 in 32-channel blocks and multiplied on the bf16 matrix cores (fp32 accumulation; BatchNorm "
@@ -219,7 +220,7 @@ def dispatches_per_step(config=1):
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_id import csrc_sha256
-    suffix = "_kernel_stats.json" if config in (1, 2, 3, 4) else "_kernel_stats_config%d.json" % config
+    suffix = "_kernel_stats.json" if config in (1, 3, 4, 5) else "_kernel_stats_config%d.json" % config
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
         return {"value": None, "source": "no profiles/*" + suffix}

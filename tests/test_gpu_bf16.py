@@ -233,8 +233,9 @@ def _grads_by_name(model):
     return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 128, 160)])
-@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("shape,mode", [((2, 64, 96), "train"), ((1, 128, 160), "train"), ((2, 64, 96), "eval"), ((1, 128, 160), "eval"),
+                                        ((2, 256, 320), "train")],          # the last: the benchmark's frame size
+                         ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_bf16_storage_backward(shape, mode):
     """Parameter gradients of FCDenseNet57.forward_bf16_storage (endo_net16_bwd) against the fp64 oracle evaluated (a) with the SAME
     roundings in its forward direction (oracle.network.forward(quant=bf16_ste): input, stored convolution outputs, staged

@@ -505,7 +505,7 @@ BF16_GRAD_TOL = 1e-1      # ... and every parameter gradient, max error / the te
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (2, 256, 320)])
 def test_bf16_operand_mode_on_pattern(shape):
-    """ENDO_OPT_MFMA_BF16 = 1 (the mixed-precision mode behind bench.py --config 2): the dense layers' forward, data-gradient and
+    """ENDO_OPT_MFMA_BF16 = 1 (the mixed-precision mode behind bench.py --config 5): the dense layers' forward, data-gradient and
     weight-gradient kernels round their MFMA operands to bf16 and accumulate in fp32; tensors in memory, BN statistics, the
     BN / ReLU / pooling arithmetic, reductions and the optimizer stay fp32.  It is a different function from the fp32 path, so it
     has its own stated tolerance: depth and all 210 gradients against the fp64 oracle evaluated on the activation pattern this
@@ -535,7 +535,7 @@ def test_bf16_operand_mode_on_pattern(shape):
 
 
 def test_bf16_operand_pair_forward_on_pattern():
-    """The grouped pair forward / backward of the training step (both frames per launch, what bench.py --config 2 runs) in
+    """The grouped pair forward / backward of the training step (both frames per launch, what bench.py --config 5 runs) in
     bf16-operand mode: each frame's depth and the summed parameter gradients against the fp64 oracle on the two patterns the
     grouped pass took, at the mode's tolerance; and against the mode's own two separate calls (other tile shapes and summation
     orders at twice the samples per launch: fp32-level differences in the BN statistics move operands across bf16 rounding
@@ -1353,7 +1353,7 @@ BF16_FULL_GRAD_TOL = 1e-1          # measured on MI355X: worst tensor 6.1e-2 (bo
 
 
 def test_bf16_operand_pair_at_benchmark_batch():
-    """The bf16-operand mode at the per-GPU workload bench.py --config 2 times: the grouped pair pass at 2 x 8 x 256 x 320 (16 samples
+    """The bf16-operand mode at the per-GPU workload bench.py --config 5 times: the grouped pair pass at 2 x 8 x 256 x 320 (16 samples
     per launch: the n-split weight gradient's bf16 form, the fused bf16 data gradients and the 32x16 forward tiles only these grids
     select), each frame's depth and the summed parameter gradients against the CPU oracle on the patterns the pass itself took
     (fp32 oracle, as test_full_size_pair_backward_on_pattern: fp64 at this size costs minutes and 40 GB; its own ~1e-5 is far below

@@ -23,16 +23,16 @@ cd $R
 # the bench line reads profiles/*_pmc_traffic.json and *_kernel_stats.json of THIS source revision: put them in place first
 cp $O/${TAG}_pmc_traffic.json $O/${TAG}_kernel_stats.json $R/profiles/
 python bench.py > $O/${TAG}_bench.json 2> $O/bench.err
-# the bf16-storage mode (bench.py --config 5): kernel trace, HBM traffic of its families, its bench line
+# the bf16-storage mode (bench.py --config 2): kernel trace, HBM traffic of its families, its bench line
 cd /tmp
-rocprofv3 --kernel-trace --stats -d /tmp/kt5 -o kt -- python3 $R/bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config5_under_rocprof.json 2> $O/kt5.err
-python3 $R/tools/summarize_rocprof.py /tmp/kt5/kt_results.db $O/${TAG}_kernel_stats_config5.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline" 7
-python3 $R/tools/summarize_rocprof.py --by-grid /tmp/kt5/kt_results.db $O/${TAG}_kernel_stats_config5_by_grid.txt
-rocprofv3 --pmc FETCH_SIZE -d /tmp/pf5 -o f -- python3 $R/bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pf5.err
-rocprofv3 --pmc WRITE_SIZE -d /tmp/pw5 -o w -- python3 $R/bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pw5.err
-python3 $R/tools/pmc_traffic.py /tmp/pf5/f_results.db /tmp/pw5/w_results.db $O/${TAG}_pmc_traffic_config5.json 7 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --config 5 --steps 5 --warmup 2 --no-cpu-baseline" > $O/pmc_traffic5.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o kt -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config2_under_rocprof.json 2> $O/kt2.err
+python3 $R/tools/summarize_rocprof.py /tmp/kt2/kt_results.db $O/${TAG}_kernel_stats_config2.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline" 7
+python3 $R/tools/summarize_rocprof.py --by-grid /tmp/kt2/kt_results.db $O/${TAG}_kernel_stats_config2_by_grid.txt
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pf2 -o f -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pf2.err
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pw2 -o w -- python3 $R/bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pw2.err
+python3 $R/tools/pmc_traffic.py /tmp/pf2/f_results.db /tmp/pw2/w_results.db $O/${TAG}_pmc_traffic_config2.json 7 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --config 2 --steps 5 --warmup 2 --no-cpu-baseline" > $O/pmc_traffic2.log 2>&1
 cd $R
-cp $O/${TAG}_pmc_traffic_config5.json $O/${TAG}_kernel_stats_config5.json $R/profiles/
-python bench.py --config 5 --no-cpu-baseline > $O/${TAG}_bench_config5.json 2> $O/bench5.err
+cp $O/${TAG}_pmc_traffic_config2.json $O/${TAG}_kernel_stats_config2.json $R/profiles/
+python bench.py --config 2 --no-cpu-baseline > $O/${TAG}_bench_config2.json 2> $O/bench2.err
 tail -1 $O/${TAG}_bench.json | cut -c1-900
 ls -la $O

@@ -23,7 +23,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_id import source_id          # noqa: E402 -- ties the file to the kernel sources it was measured on (bench.py checks it)
 
 FAMILIES = [
-    # (the bf16-storage family's kernels, bench.py --config 5: bf16_dgrad_block_kernel and bf16_conv_kernel<3, 3, 2, ...> serve only the
+    # (the bf16-storage family's kernels, bench.py --config 2: bf16_dgrad_block_kernel and bf16_conv_kernel<3, 3, 2, ...> serve only the
     # dense layers' data gradients; bf16_wgrad_kernel<3> also the five transition-up and the first convolution -- 6 of 50 launches)
     ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_wino8_kernel|dgrad_wino3_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,|"
                                r"bf16_dgrad_block_kernel|bf16_conv_kernel<3, 3, 2,")),
