@@ -111,7 +111,9 @@ __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict_
         const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(x + off);
         const float g0 = bf16_lo(dv[0]) + fmaf(pc[0], bf16_lo(xv[0]), qc[0]), g1 = bf16_hi(dv[0]) + fmaf(pc[1], bf16_hi(xv[0]), qc[1]);
         const float g2 = bf16_lo(dv[1]) + fmaf(pc[2], bf16_lo(xv[1]), qc[2]), g3 = bf16_hi(dv[1]) + fmaf(pc[3], bf16_hi(xv[1]), qc[3]);
-        *reinterpret_cast<u32x2_t*>(d + off) = u32x2_t{pack_bf16x2(g0, g1), pack_bf16x2(g2, g3)};
+        // stochastic rounding: P x + Q is mostly below half an ulp of d (pack_bf16x2_sr)
+        const unsigned key = (static_cast<unsigned>(off - n * ns) + static_cast<unsigned>(group_n > 0 ? n % group_n : n) * 0x632BE5ABu) ^ 0x51ED270Bu;
+        *reinterpret_cast<u32x2_t*>(d + off) = u32x2_t{pack_bf16x2_sr(g0, g1, key), pack_bf16x2_sr(g2, g3, key + 2)};
     }
 }
 

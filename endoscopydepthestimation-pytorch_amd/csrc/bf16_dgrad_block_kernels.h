@@ -43,6 +43,7 @@ struct DgradBlock16Params {
     const float* beta[kDbLayers];
     double* sums[kDbLayers];         // [cin_j][2] (sum da, sum da * x), accumulated
     int rot, rot_n;
+    unsigned sr_salt;                // stochastic rounding of the gradient stores (pack_bf16x2_sr)
     int group_n;                     // sample groups (bf16_conv_kernels.h): group g's saved / sums start gs_saved / gs_sums elements later
     int64_t gs_saved, gs_sums;
 };
@@ -247,8 +248,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
                 if (pix[r][hh] < 0) continue;
                 const u32x2_t o = old[t][r][hh];
                 const float* tt = total[t][r][hh];
-                *reinterpret_cast<u32x2_t*>(out_n + quad_off(t, pix[r][hh])) = u32x2_t{pack_bf16x2(bf16_lo(o[0]) + tt[0], bf16_hi(o[0]) + tt[1]),
-                                                                                      pack_bf16x2(bf16_lo(o[1]) + tt[2], bf16_hi(o[1]) + tt[3])};
+                const int qo = quad_off(t, pix[r][hh]);
+                const unsigned key = (static_cast<unsigned>(qo) + static_cast<unsigned>(n - grp * (p.group_n > 0 ? p.group_n : 0)) * 0x632BE5ABu) ^ p.sr_salt;
+                *reinterpret_cast<u32x2_t*>(out_n + qo) = u32x2_t{pack_bf16x2_sr(bf16_lo(o[0]) + tt[0], bf16_hi(o[0]) + tt[1], key),
+                                                                  pack_bf16x2_sr(bf16_lo(o[1]) + tt[2], bf16_hi(o[1]) + tt[3], key + 2)};
             }
 }
 

@@ -386,6 +386,7 @@ extern "C" int64_t endo_net16_offset(const endo_net16* net, int what, int index)
         case 3: return index <= k16Levels ? net->lv[index].act : -1;
         case 4: return index <= k16Levels ? net->ws_d[index] : -1;
         case 5: return index <= k16Levels ? net->lv[index].t : -1;
+        case 6: return index <= k16Levels ? net->ws_pq[index] : -1;          // workspace: deferred BatchNorm terms of the level, fp32 [P[t]][Q[t]] per group
         default: return -1;
     }
 }
@@ -608,6 +609,7 @@ void fill_dgrad(const Ctx16& c, Conv16Params& p, int g_level, int gc0, int level
     p.x = c.act(level); p.x_saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
     p.out_sums = c.bnsums(b);
     p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_out_sums = c.net->gs_saved;
+    p.sr_salt = static_cast<unsigned>(cv.w) * 2654435761u;          // a different rounding sequence per layer
 }
 
 // dense layer j of a block with `c0` base channels (reads [0, c0 + 12 j), wrote [c0 + 12 j, + 12)): bias gradient + deferred terms,
@@ -659,6 +661,7 @@ int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const C
     }
     p.rot = cv[0].rot; p.rot_n = cv[0].rot_n;
     p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_sums = c.net->gs_saved;
+    p.sr_salt = static_cast<unsigned>(cv[0].w) * 2246822519u;
     {
         // per base channel and pixel: forward value 2 B, gradient read + written 4 B; the 48 gradient maps 2 B each
         const double px = static_cast<double>(c.net->n) * lv.plane;
@@ -725,6 +728,7 @@ int tu_bwd16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16&
     p.wgt = c.w16d(cv);
     p.out = c.dbuf(src_level); p.out_t = sv.t; p.out_blk = k16Blk; p.out_ns = sv.plane * sv.t; p.oc0 = src_c0; p.cout = cv.cin;
     p.out_sums = c.gsum(src_level) + 2 * src_c0;
+    p.sr_salt = static_cast<unsigned>(cv.w) * 3266489917u;
     return launch_bf16_conv<3, 3, kEpiSumPool, 8, 2>(p, c.stream);
 }
 

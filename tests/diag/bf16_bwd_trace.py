@@ -82,4 +82,10 @@ for name, level, c0, count in maps:
     got = dbuf(level, c0, count)
     err = float((got - want).abs().max() / want.abs().max())
     l2 = float((got - want).norm() / want.norm())
-    print("%-44s level %d ch %3d +%3d   max err / max %.2e   relative L2 %.2e   (max |g| %.2e)" % (name, level, c0, count, err, l2, float(want.abs().max())))
+    # coherent parts of the error, per channel: its mean over the pixels (an offset) against the channel's rms, and how the sum over
+    # the pixels compares (a training-mode BatchNorm makes the true sum of most maps exactly zero)
+    d = got - want
+    rms = want.pow(2).mean(dim=(0, 2, 3)).sqrt()
+    off = float((d.mean(dim=(0, 2, 3)).abs() / rms).max())
+    print("%-44s level %d ch %3d +%3d   max err / max %.2e   relative L2 %.2e   worst channel offset / rms %.2e   (max |g| %.2e)" % (
+        name, level, c0, count, err, l2, off, float(want.abs().max())))

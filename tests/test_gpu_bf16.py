@@ -219,14 +219,14 @@ def test_bf16_storage_forward_timing():
 # ---------------------------------------------------------------------------------------------
 # the backward pass over bf16 level buffers
 # ---------------------------------------------------------------------------------------------
-# per parameter tensor, max |g16 - g| / max(max |g|, floor), on the pass's own pattern; measured (printed by the test): weights and
-# BatchNorm parameters <= 2.1e-2 in inference mode, <= 5e-2 in training mode.  Conv BIASES in training mode are a sum over all pixels
-# of a gradient map whose mean BatchNorm has removed: what is left is border terms, and the bf16 roundings of the gradient buffers
-# (relative to the un-cancelled magnitude) do not average out against it -- up to 4e-1 of the tensor's largest entry on up-path layers
-# whose maps reach a transition up; every bias whose gradient is mathematically zero is exactly zero.
-BF16_STORAGE_GRAD_TOL = 4e-2                 # inference mode (measured <= 2.1e-2)
-BF16_STORAGE_GRAD_TOL_TRAIN = 1e-1           # training mode (measured <= 6.4e-2: 2 x 64 x 96, level 4, where a BatchNorm sees 48 values per channel)
-BF16_STORAGE_BIAS_GRAD_TOL_TRAIN = 5e-1
+# per parameter tensor, max |g16 - g| / max(max |g|, floor), on the pass's own pattern; measured (printed by the test) with the
+# stochastically rounded gradient stores: weights and BatchNorm parameters <= 3.2e-2 in inference mode, <= 6e-2 in training mode, all
+# parameters in relative L2 5e-3..1.1e-2 (2 x 256 x 320, training mode: 1.03e-2; with round-to-nearest stores it was 7.2e-2 there, DESIGN.md
+# 4.14).  Conv BIASES in training mode are sums over all pixels of gradient maps whose mean BatchNorm has removed: <= 7.7e-2 of the tensor's
+# largest entry; every bias whose gradient is mathematically zero is exactly zero.
+BF16_STORAGE_GRAD_TOL = 5e-2                 # inference mode
+BF16_STORAGE_GRAD_TOL_TRAIN = 1e-1           # training mode
+BF16_STORAGE_BIAS_GRAD_TOL_TRAIN = 1.5e-1
 
 
 def _grads_by_name(model):
@@ -291,7 +291,7 @@ def test_bf16_storage_backward(shape, mode):
     for err, k, _, _ in rows:
         loose = mode == "train" and (k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias")
         assert err <= (BF16_STORAGE_BIAS_GRAD_TOL_TRAIN if loose else (BF16_STORAGE_GRAD_TOL_TRAIN if mode == "train" else BF16_STORAGE_GRAD_TOL)), (k, err)
-    assert (l2_num / l2_den) ** 0.5 <= 3e-2
+    assert (l2_num / l2_den) ** 0.5 <= 2.5e-2
 
 
 def test_bf16_storage_step_timing():
@@ -366,6 +366,13 @@ def test_bf16_storage_pair_as_two_groups():
         else:
             assert float((sa[k] - sb[k]).abs().max() / (sa[k].abs().max() + 1e-6)) <= 1e-5, k
     floor = 1e-3 * max(float(v.abs().max()) for v in ga.values())
-    worst = max((float((ga[k] - gb[k]).abs().max()) / max(float(ga[k].abs().max()), floor), k) for k in ga)
-    print("two groups vs two calls: worst gradient tensor %s, %.2e" % (worst[1], worst[0]))
-    assert worst[0] <= 2e-3, worst
+    # the gradient stores round stochastically with a key made of position and sample index inside the group, so both runs draw the same
+    # bits -- but the fp64 atomics behind the BatchNorm sums land in another order, P and Q differ in their last bit, and a stored value
+    # that sat on a rounding threshold moves by one bf16 ulp: noise of that size, largest on the up-path biases (sums of zero-mean maps)
+    err = {k: float((ga[k] - gb[k]).abs().max()) / max(float(ga[k].abs().max()), floor) for k in ga}
+    is_bias = lambda k: k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias"
+    worst_b = max((v, k) for k, v in err.items() if is_bias(k))
+    worst_w = max((v, k) for k, v in err.items() if not is_bias(k))
+    print("two groups vs two calls: worst weight / BatchNorm tensor %s %.2e, worst bias %s %.2e" % (worst_w[1], worst_w[0], worst_b[1], worst_b[0]))
+    assert worst_w[0] <= 3e-2, worst_w          # measured 1.2e-2 (a level-5 tensor: 6 pixels per sample at this size)
+    assert worst_b[0] <= 6e-2, worst_b
