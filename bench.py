@@ -2,7 +2,7 @@
 """Headline benchmark: training frame-pairs/s of the full hot-path step (BASELINE.json metric) on
 synthetic frame pairs -- by default config 2 of BASELINE.json (configs[1]): 256 x 320, batch 8 per GPU, fp32.
 
-    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5]
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5|6]
 
 With N > 1 and no WORLD_SIZE in the environment the script starts N fresh rank processes itself
 (``python -m torch.distributed.run --nproc-per-node N ... bench.py``, before this process touches the GPU) and relays
@@ -16,8 +16,9 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 --config selects the BASELINE.json workload by its index in ``configs``:
     1   256 x 320, batch 8 per GPU, fp32                                   (default; the metric's configuration)
     3   512 x 640, batch 4 per GPU, fp32
-    4   256 x 320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10 ("adjacent range 5-30");
-        fp32 storage (the fp16-storage half of configs[4] does not exist in this library)
+    4   256 x 320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10 ("adjacent range 5-30"), FP16 STORAGE
+        (the 16-bit-storage family compiled for IEEE half): the per-GPU half of BASELINE.json configs[4]; its own line
+    6   (not a BASELINE config) the pose regime of configs[4] in the fp32 family (round 2's --config 4)
     2   256 x 320, batch 8 per GPU, BF16 STORAGE: the network over bf16 level buffers (endo_net16_fwd / endo_net16_bwd) -- the
         per-GPU half of BASELINE.json configs[2] (bs 64 bf16 over 8 GPUs); its own line, never compared with configs[1]
     5   (not a BASELINE config) 256 x 320, batch 8 per GPU, bf16 MFMA operands over fp32 tensors: the mixed-precision mode of the
@@ -69,10 +70,16 @@ CONFIGS = {
             metric="train frame-pairs/sec at 512x640 bs=4",
             workload="full training step (FC-DenseNet57 x2 fwd+bwd, depth scaling, flow, warp, losses, clip+SGD), "
                      "512x640, batch 4 per GPU, fp32 (BASELINE.json configs[3])"),
-    4: dict(height=256, width=320, batch=8, gap=(5, 30),
-            metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30",
-            workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, "
-                     "fp32 storage (BASELINE.json configs[4] without its fp16-storage half)"),
+    4: dict(height=256, width=320, batch=8, gap=(5, 30), fp16_storage=True,
+            metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30, fp16 storage",
+            workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, FP16 STORAGE: the "
+                     "network's activations and inter-layer gradients are stored as IEEE half in 32-channel blocks (endo_net16h_*: the "
+                     "bf16-storage family compiled for half, power-of-two gradient scale per backward call), fp32 accumulation, statistics, "
+                     "parameter gradients, geometry, losses, clipping and SGD -- the per-GPU half of BASELINE.json configs[4]; its own line"),
+    6: dict(height=256, width=320, batch=8, gap=(5, 30),
+            metric="train frame-pairs/sec at 256x320 bs=8, adjacent range 5-30, fp32",
+            workload="full training step, 256x320, batch 8 per GPU, poses scaled by a per-sample frame gap U{5..30}/10, fp32 storage "
+                     "(the pose regime of BASELINE.json configs[4] in the fp32 family; round 2's --config 4)"),
     2: dict(height=256, width=320, batch=8, gap=None, bf16_storage=True,
             metric="train frame-pairs/sec at 256x320 bs=8, bf16 storage",
             workload="full training step, 256x320, batch 8 per GPU, BF16 STORAGE: the network's activations and inter-layer gradients "
@@ -220,7 +227,7 @@ def dispatches_per_step(config=1):
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_id import csrc_sha256
-    suffix = "_kernel_stats.json" if config in (1, 3, 4, 5) else "_kernel_stats_config%d.json" % config
+    suffix = "_kernel_stats.json" if config in (1, 3, 5, 6) else "_kernel_stats_config%d.json" % config
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
         return {"value": None, "source": "no profiles/*" + suffix}
@@ -306,7 +313,8 @@ def main():
     dev = torch.device("cuda", local)
     lib = pkg._lib.load()
     bf16 = bool(cfg.get("bf16_operands"))
-    bf16_storage = bool(cfg.get("bf16_storage"))
+    fp16_storage = bool(cfg.get("fp16_storage"))
+    bf16_storage = bool(cfg.get("bf16_storage")) or fp16_storage          # the 16-bit-storage family (bf16 or half)
 
     torch.manual_seed(10085)                                            # reference train.py:80
     model = pkg.models.FCDenseNet57(n_classes=1)
@@ -320,7 +328,8 @@ def main():
         model.set_kernel_option(option_id, value)
     optimizer = pkg.optim.FusedClipSGD(model, lr=1.0e-3, momentum=0.9, max_norm=10.0)
     scheduler = pkg.scheduler.CyclicLR(optimizer, base_lr=1.0e-4, max_lr=1.0e-3, step_size=2000)
-    step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, bf16_storage=bf16_storage)
+    step_fn = pkg.train_step.TrainingStep(model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, bf16_storage=bf16_storage and not fp16_storage,
+                                          fp16_storage=fp16_storage)
     batch = {k: v.to(dev) for k, v in pkg.synthetic.make_batch(batch_size, height, width, seed=rank, gap_scale=cfg["gap"]).items()}
 
     def barrier():
@@ -457,7 +466,7 @@ def main():
     achieved = fl / ms / 1e9 if ms > 0 else 0.0                         # TFLOP/s
     dom_name = lib.endo_prof_family_name(dominant).decode()
     traffic, traffic_src = (None, None)
-    if args.config in (1, 2, 5):
+    if args.config in (1, 2, 4, 5):
         traffic, traffic_src = pmc_traffic(dom_name, args.config)      # bytes per step -> per launch with the launches counted here
     if traffic is not None and cnt:
         traffic = traffic / (cnt / args.steps)
@@ -473,7 +482,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16 storage and MFMA operands, f32 accumulate" if bf16_storage else (
+        "dtype": "f16 storage and MFMA operands, f32 accumulate" if fp16_storage else "bf16 storage and MFMA operands, f32 accumulate" if bf16_storage else (
             "bf16 MFMA operands, f32 accumulate, f32 storage" if bf16 else "f32"),
         "data": "synthetic",
         "config": {"workload": cfg["workload"], "baseline_config_index": args.config,

@@ -42,18 +42,28 @@ SIGNATURES = {
     "endo_warp_consistency": (_I, [_P] * 8 + [_F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
     "endo_warp_fallback_blocks": (_I, [_P, _P, _I]),
     "endo_bf16_pack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "endo_f16_pack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "endo_bf16_unpack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "endo_f16_unpack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "endo_bf16_conv_weight_elems": (_L, [_I, _I, _I]),
     "endo_bf16_conv_weights": (_I, [_P, _I, _I, _I, _P, _P]),
     "endo_bf16_conv": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _I, _I, _I, _I, _P]),
     "endo_net16_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
+    "endo_net16h_create": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),
     "endo_net16_destroy": (None, [_P]),
+    "endo_net16h_destroy": (None, [_P]),
     "endo_net16_tape_bytes": (_L, [_P]),
+    "endo_net16h_tape_bytes": (_L, [_P]),
     "endo_net16_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "endo_net16h_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_net16_bwd_workspace_bytes": (_L, [_P]),
+    "endo_net16h_bwd_workspace_bytes": (_L, [_P]),
     "endo_net16_set_wgrad_overlap": (_I, [_P, _I]),
+    "endo_net16h_set_wgrad_overlap": (_I, [_P, _I]),
     "endo_net16_offset": (_L, [_P, _I, _I]),
+    "endo_net16h_offset": (_L, [_P, _I, _I]),
     "endo_net16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
+    "endo_net16h_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_mask_mul": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "endo_net_create": (_I, [ctypes.POINTER(_P), _I, _I, _I]),
     "endo_net_create_grouped": (_I, [ctypes.POINTER(_P), _I, _I, _I, _I]),

@@ -16,6 +16,7 @@
 #include "bf16_conv_kernels.h"
 
 namespace endo {
+inline namespace ENDO16_NS {
 
 __device__ __forceinline__ int rot_index(int c, int rot, int rot_n) { return c < rot_n ? (c + rot < rot_n ? c + rot : c + rot - rot_n) : c; }
 // element offset of channel ca of pixel pix in a [t / blk][plane][blk] sample
@@ -24,17 +25,41 @@ __device__ __forceinline__ int64_t blk_off(int ca, int64_t pix, int64_t plane, i
     return (cb * plane + pix) * blk + (ca - cb * blk);
 }
 
+// ---- gradient scale (half storage only): S = the power of two that brings max |grad_out| to ~2^9; every stored gradient carries the factor
+// S, the parameter gradients are multiplied by 1 / S where they leave (weight-gradient reduction, BatchNorm parameters, biases); the
+// deferred BatchNorm terms are linear in the gradient and carry S by themselves.  One block; `scale` = {S, 1 / S}.
+__global__ void __launch_bounds__(1024) s16_grad_scale_kernel(const float* __restrict__ g, int64_t count, float* __restrict__ scale) {
+    __shared__ float s_max[16];
+    float m = 0.f;
+    for (int64_t i = threadIdx.x; i < count; i += 1024) m = fmaxf(m, fabsf(g[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 16; ++i) m = fmaxf(m, s_max[i]);
+        float sc = 1.f;
+        if (m > 0.f && m < 3.0e38f) {
+            int e = 9 - static_cast<int>(floorf(log2f(m)));
+            e = e < -24 ? -24 : (e > 40 ? 40 : e);
+            sc = exp2f(static_cast<float>(e));
+        }
+        scale[0] = sc; scale[1] = 1.f / sc;
+    }
+}
+
 // ---- final 1 x 1 + |.| backward (reference models.py:167, 186): du[c] = g * sign(pre) * w[c] for all 192 channels (first writer of the
 // level-0 gradient buffer); grad_w[c] += sum g * sign(pre) * u[c]; grad_b += sum g * sign(pre).  8 lanes per pixel, 24 channels each.
 __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                              const uint16_t* __restrict__ u, uint16_t* __restrict__ du, int64_t ns, int plane,
                                                              const float* __restrict__ w, int rot, int rot_n, float* __restrict__ grad_w,
-                                                             float* __restrict__ grad_b, double* __restrict__ gsum) {
+                                                             float* __restrict__ grad_b, double* __restrict__ gsum, const float* __restrict__ gscale) {
     __shared__ float s_part[4][8][25];
     const int n = blockIdx.y;
     const int sub = threadIdx.x & 7;
     float wv[24], gw[24];
     float gb = 0.f;
+    const float S = gscale ? gscale[0] : 1.f;          // what is written to the gradient buffer carries S; the parameter gradients here do not
 #pragma unroll
     for (int k = 0; k < 24; ++k) { wv[k] = w[rot_index(sub * 24 + k, rot, rot_n)]; gw[k] = 0.f; }
     for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; px < plane; px += (gridDim.x * blockDim.x) >> 3) {
@@ -49,9 +74,9 @@ __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __rest
             u32x4_t o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                gw[8 * j + 2 * k] = fmaf(gs, bf16_lo(v[k]), gw[8 * j + 2 * k]);
-                gw[8 * j + 2 * k + 1] = fmaf(gs, bf16_hi(v[k]), gw[8 * j + 2 * k + 1]);
-                o[k] = pack_bf16x2(gs * wv[8 * j + 2 * k], gs * wv[8 * j + 2 * k + 1]);
+                gw[8 * j + 2 * k] = fmaf(gs, s16_lo(v[k]), gw[8 * j + 2 * k]);
+                gw[8 * j + 2 * k + 1] = fmaf(gs, s16_hi(v[k]), gw[8 * j + 2 * k + 1]);
+                o[k] = pack_s16x2(gs * S * wv[8 * j + 2 * k], gs * S * wv[8 * j + 2 * k + 1]);
             }
             *reinterpret_cast<u32x4_t*>(du + off) = o;
         }
@@ -74,7 +99,7 @@ __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __rest
         const int s = threadIdx.x / 24, k = threadIdx.x - 24 * s;
         atomicAdd(grad_w + rot_index(threadIdx.x, rot, rot_n), s_part[0][s][k] + s_part[1][s][k] + s_part[2][s][k] + s_part[3][s][k]);
         // sum over pixels of what this kernel writes into channel c of the gradient buffer (see bf16_prep_dy_kernel)
-        atomicAdd(gsum + 2 * threadIdx.x, static_cast<double>(w[rot_index(threadIdx.x, rot, rot_n)]) * static_cast<double>(gb_block));
+        atomicAdd(gsum + 2 * threadIdx.x, static_cast<double>(w[rot_index(threadIdx.x, rot, rot_n)]) * static_cast<double>(gb_block) * static_cast<double>(S));
     }
     if (threadIdx.x == 192) atomicAdd(grad_b, gb_block);
 }
@@ -92,9 +117,9 @@ __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __rest
 __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict__ d, const uint16_t* __restrict__ x, int64_t ns, int plane, int blk,
                                                            int c0, int count, const float* __restrict__ pq_p, const float* __restrict__ pq_q,
                                                            float* __restrict__ bias_grad, const double* __restrict__ gsum, int apply, int group_n,
-                                                           int64_t gs_pq) {
+                                                           int64_t gs_pq, const float* __restrict__ gscale) {
     if (bias_grad && blockIdx.x == 0 && blockIdx.y == 0)
-        for (int c = threadIdx.x; c < count; c += 256) bias_grad[c] += static_cast<float>(gsum[2 * (c0 + c)]);
+        for (int c = threadIdx.x; c < count; c += 256) bias_grad[c] += static_cast<float>(gsum[2 * (c0 + c)] * (gscale ? gscale[1] : 1.f));
     if (!apply) return;          // inference mode: P = Q = 0
     const int n = blockIdx.y;
     const int quads = count >> 2;
@@ -109,11 +134,11 @@ __global__ void __launch_bounds__(256) bf16_prep_dy_kernel(uint16_t* __restrict_
         const int64_t off = n * ns + blk_off(c0 + 4 * q, px, plane, blk);
         const u32x2_t dv = *reinterpret_cast<const u32x2_t*>(d + off);
         const u32x2_t xv = *reinterpret_cast<const u32x2_t*>(x + off);
-        const float g0 = bf16_lo(dv[0]) + fmaf(pc[0], bf16_lo(xv[0]), qc[0]), g1 = bf16_hi(dv[0]) + fmaf(pc[1], bf16_hi(xv[0]), qc[1]);
-        const float g2 = bf16_lo(dv[1]) + fmaf(pc[2], bf16_lo(xv[1]), qc[2]), g3 = bf16_hi(dv[1]) + fmaf(pc[3], bf16_hi(xv[1]), qc[3]);
-        // stochastic rounding: P x + Q is mostly below half an ulp of d (pack_bf16x2_sr)
+        const float g0 = s16_lo(dv[0]) + fmaf(pc[0], s16_lo(xv[0]), qc[0]), g1 = s16_hi(dv[0]) + fmaf(pc[1], s16_hi(xv[0]), qc[1]);
+        const float g2 = s16_lo(dv[1]) + fmaf(pc[2], s16_lo(xv[1]), qc[2]), g3 = s16_hi(dv[1]) + fmaf(pc[3], s16_hi(xv[1]), qc[3]);
+        // stochastic rounding: P x + Q is mostly below half an ulp of d (pack_s16x2_sr)
         const unsigned key = (static_cast<unsigned>(off - n * ns) + static_cast<unsigned>(group_n > 0 ? n % group_n : n) * 0x632BE5ABu) ^ 0x51ED270Bu;
-        *reinterpret_cast<u32x2_t*>(d + off) = u32x2_t{pack_bf16x2_sr(g0, g1, key), pack_bf16x2_sr(g2, g3, key + 2)};
+        *reinterpret_cast<u32x2_t*>(d + off) = u32x2_t{pack_s16x2_sr(g0, g1, key), pack_s16x2_sr(g2, g3, key + 2)};
     }
 }
 
@@ -127,15 +152,16 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __r
                                                                const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                                float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum, int first,
                                                                int cnt, int rot, int rot_n, double count, int training, int64_t gs_sums, int64_t gs_saved,
-                                                               int64_t gs_pq) {
+                                                               int64_t gs_pq, const float* __restrict__ gscale) {
+    const double inv = gscale ? gscale[1] : 1.0;          // the parameter gradients leave without the gradient scale
     // blockIdx.y = sample group: its own sums, statistics and deferred terms; the parameter gradients add up over the groups
     sums += blockIdx.y * gs_sums; saved += blockIdx.y * gs_saved; pq_p += blockIdx.y * gs_pq; pq_q += blockIdx.y * gs_pq;
     for (int ci = first + blockIdx.x * blockDim.x + threadIdx.x; ci < first + cnt; ci += gridDim.x * blockDim.x) {
         const int pc = rot_index(ci, rot, rot_n);
         const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
         const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
-        atomicAdd(ggamma + pc, static_cast<float>(s2));
-        atomicAdd(gbeta + pc, static_cast<float>(s1));
+        atomicAdd(ggamma + pc, static_cast<float>(s2 * inv));
+        atomicAdd(gbeta + pc, static_cast<float>(s1 * inv));
         const double scale = gamma[pc] * rstd;
         if (training) {
             const double k = scale * rstd * s2 / count;
@@ -176,6 +202,7 @@ struct Wgrad16Params {
     int gc0, cout;
     const uint8_t* g_idx;              // 1 x 1 only: g is the POOLED gradient ([h / 2][w / 2]) and g_idx the forward max-pool codes
     float* partial;                    // [gridDim.x][co groups][9][16][ci_pad] fp32
+    const float* gscale;               // {S, 1 / S} of the stored gradients or null (s16_grad_scale_kernel)
     int ci_pad;                        // cin rounded up to 16
 };
 
@@ -317,7 +344,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
                 const bool ok = aok[i];
                 float z[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { z[2 * j] = bf16_lo(v[j]); z[2 * j + 1] = bf16_hi(v[j]); }
+                for (int j = 0; j < 4; ++j) { z[2 * j] = s16_lo(v[j]); z[2 * j + 1] = s16_hi(v[j]); }
                 if (p.saved) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -328,7 +355,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const unsigned pk = pack_bf16x2(z[2 * j], z[2 * j + 1]);
+                    const unsigned pk = pack_s16x2(z[2 * j], z[2 * j + 1]);
                     *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk & 0xffffu);
                     *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk >> 16);
                 }
@@ -339,16 +366,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         if (3 * wave < ntiles_ci) {
 #pragma unroll
             for (int row = 0; row < kWgRows; ++row) {
-                bf16x8_t b[3];
+                s16x8_t b[3];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const bf16x8_t*>(s_a + (16 * (3 * wave + t) + li) * kWgPitchA + row * 64 + lk * 16);
+                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const s16x8_t*>(s_a + (16 * (3 * wave + t) + li) * kWgPitchA + row * 64 + lk * 16);
 #pragma unroll
                 for (int f = 0; f < 9; ++f) {
-                    bf16x8_t a;
-                    if constexpr (KS == 3) a = *reinterpret_cast<const bf16x8_t*>(s_g + li * kWgPitchG3 + ((row - f / 3 + 2) * 3 + f % 3) * 64 + lk * 16);
-                    else a = *reinterpret_cast<const bf16x8_t*>(s_g + (16 * f + li) * kWgPitchA + row * 64 + lk * 16);
+                    s16x8_t a;
+                    if constexpr (KS == 3) a = *reinterpret_cast<const s16x8_t*>(s_g + li * kWgPitchG3 + ((row - f / 3 + 2) * 3 + f % 3) * 64 + lk * 16);
+                    else a = *reinterpret_cast<const s16x8_t*>(s_g + (16 * f + li) * kWgPitchA + row * 64 + lk * 16);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[f][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[t], acc[f][t], 0, 0, 0);
+                    for (int t = 0; t < 3; ++t) acc[f][t] = S16_MFMA(a, b[t], acc[f][t], 0, 0, 0);
                 }
             }
         }
@@ -370,7 +397,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
 // grid.y splits the blocks into slices of 64 (one fp32 atomic per element and slice): a single thread walking 512 partials is a chain
 // of 512 dependent loads
 __global__ void __launch_bounds__(256) bf16_wgrad_reduce_kernel(const float* __restrict__ partial, int blocks, int co_groups, int ci_pad, int cin, int cout,
-                                                                int ks, int rot, int rot_n, float* __restrict__ dw, int cin_w) {
+                                                                int ks, int rot, int rot_n, float* __restrict__ dw, int cin_w, const float* __restrict__ gscale) {
+    const float inv = gscale ? gscale[1] : 1.f;
     const int64_t per_block = static_cast<int64_t>(co_groups) * 9 * 16 * ci_pad;
     for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < per_block; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int ci = e % ci_pad;
@@ -388,7 +416,7 @@ __global__ void __launch_bounds__(256) bf16_wgrad_reduce_kernel(const float* __r
         }
         for (; b < b_end; ++b) s0 += partial[b * per_block + e];
         const int pci = rot_index(ci, rot, rot_n);
-        atomicAdd(ks == 3 ? dw + (static_cast<int64_t>(co) * cin_w + pci) * 9 + f : dw + static_cast<int64_t>(co) * cin_w + pci, (s0 + s1) + (s2 + s3));
+        atomicAdd(ks == 3 ? dw + (static_cast<int64_t>(co) * cin_w + pci) * 9 + f : dw + static_cast<int64_t>(co) * cin_w + pci, ((s0 + s1) + (s2 + s3)) * inv);
     }
 }
 
@@ -426,9 +454,10 @@ inline int launch_bf16_wgrad(Wgrad16Params p, float* dw, hipStream_t stream) {
     ENDO_LAUNCH_CHECK();
     const int64_t per_block = static_cast<int64_t>(co_groups) * 9 * 16 * p.ci_pad;
     bf16_wgrad_reduce_kernel<<<dim3(static_cast<int>((per_block + 255) / 256), (blocks + 63) / 64), 256, 0, stream>>>(p.partial, blocks, co_groups, p.ci_pad, p.cin, p.cout, KS, p.rot,
-                                                                                            p.rot_n, dw, p.cin_w > 0 ? p.cin_w : p.cin);
+                                                                                            p.rot_n, dw, p.cin_w > 0 ? p.cin_w : p.cin, p.gscale);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
+}  // inline namespace
 }  // namespace endo

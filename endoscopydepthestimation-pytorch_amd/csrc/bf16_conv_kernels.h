@@ -28,7 +28,20 @@
 
 #include "common.h"
 
+// ELEMENT TYPE.  The family is written once for a 16-bit storage type "s16": bf16 (net16.hip; BASELINE configs[2]) or, compiled a second
+// time with ENDO16_HALF (net16h.hip; configs[4]'s "fp16 storage / fp32 accumulate"), IEEE half.  What differs: the two conversions, the
+// matrix instruction (v_mfma_f32_16x16x32_bf16 / _f16), the stochastic-rounding step, and -- half only -- a power-of-two gradient scale
+// (the per-pixel gradients of a mean loss are ~1e-6, below half's smallest normal 6e-5).  Each build lives in its own inline namespace.
+#ifdef ENDO16_HALF
+#define ENDO16_NS h16
+#define S16_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+#define ENDO16_NS b16
+#define S16_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
 namespace endo {
+inline namespace ENDO16_NS {
 
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -93,7 +106,7 @@ struct Conv16Params {
     // launch's first block with group 0's statistics first, then group 1's, as two consecutive calls would.
     int group_n;
     int64_t gs_in_sums, gs_saved, gs_out_sums;
-    unsigned sr_salt;                // gradient stores: per-launch salt of the stochastic rounding (pack_bf16x2_sr)
+    unsigned sr_salt;                // gradient stores: per-launch salt of the stochastic rounding (pack_s16x2_sr)
     // UNPOOL input (transition down backward): `in` is the pooled-resolution gradient (ups = 1 addressing) and a full-resolution pixel
     // takes a channel's value only where in_idx ([n][h / 2][w / 2][cin] bytes, the forward pass's out_idx) names its position
     const uint8_t* in_idx;
@@ -101,14 +114,27 @@ struct Conv16Params {
 
 constexpr int kEpiFwd = 0, kEpiPool = 1, kEpiDgradBn = 2, kEpiSumPool = 3;
 
-__device__ __forceinline__ float bf16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
+#ifdef ENDO16_HALF
+typedef _Float16 s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ float s16_lo(unsigned v) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v & 0xffffu))); }
+__device__ __forceinline__ float s16_hi(unsigned v) { return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(v >> 16))); }
+// two floats -> two halves (round to nearest even) in one dword, low half first
+__device__ __forceinline__ unsigned pack_s16x2(float a, float b) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, f16x2_t));
+}
+#else
+typedef bf16x8_t s16x8_t;
+__device__ __forceinline__ float s16_lo(unsigned v) { return __builtin_bit_cast(float, v << 16); }
+__device__ __forceinline__ float s16_hi(unsigned v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 // two floats -> two bf16 (round to nearest even) in one dword, low half first
-__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+__device__ __forceinline__ unsigned pack_s16x2(float a, float b) {
     typedef float f32x2_t __attribute__((ext_vector_type(2)));
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
 }
+#endif
 
 // Two floats -> two bf16 with STOCHASTIC rounding (16 pseudo-random bits added below the kept mantissa, then truncation): for the
 // gradient buffers.  A gradient value is stored, read back and re-stored after something small has been added to it -- another consumer's
@@ -122,11 +148,25 @@ __device__ __forceinline__ unsigned sr_hash(unsigned key) {
     key *= 0x9E3779B1u; key ^= key >> 15; key *= 0x85EBCA77u; key ^= key >> 13;
     return key;
 }
-__device__ __forceinline__ unsigned pack_bf16x2_sr(float a, float b, unsigned key) {
+#ifdef ENDO16_HALF
+// half: dither by (u - 1/2) ulp of the half grid at the value (2^(e - 10), e >= -14), then round to nearest
+__device__ __forceinline__ float s16_dither(float v, unsigned r16) {
+    int e = static_cast<int>((__builtin_bit_cast(unsigned, v) >> 23) & 0xffu) - 127;
+    e = (e < -14 ? -14 : e) - 10;
+    const float ulp = __builtin_bit_cast(float, static_cast<unsigned>(e + 127) << 23);
+    return fmaf(static_cast<float>(r16) * (1.0f / 65536.0f) - 0.5f, ulp, v);
+}
+__device__ __forceinline__ unsigned pack_s16x2_sr(float a, float b, unsigned key) {
+    const unsigned r = sr_hash(key);
+    return pack_s16x2(s16_dither(a, r & 0xffffu), s16_dither(b, r >> 16));
+}
+#else
+__device__ __forceinline__ unsigned pack_s16x2_sr(float a, float b, unsigned key) {
     const unsigned r = sr_hash(key);
     const unsigned ua = __builtin_bit_cast(unsigned, a) + (r & 0xffffu), ub = __builtin_bit_cast(unsigned, b) + (r >> 16);
     return (ua >> 16) | (ub & 0xffff0000u);
 }
+#endif
 
 // sum over the 16 lanes of a DPP row (the 16 pixels li of one lane group): four v_add with row_shr 8 / 4 / 2 / 1, valid in lane 15 of the
 // row.  (__shfl_xor is a ds_bpermute -- an LDS-pipe instruction; the BatchNorm sums need 8 of them per value and a fused
@@ -346,9 +386,9 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                 if (u_off[i] >= 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float z0 = fmaxf(fmaf(bf16_lo(v[k]), sc[2 * k], sh[2 * k]), 0.f);
-                        const float z1 = fmaxf(fmaf(bf16_hi(v[k]), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
-                        v[k] = pack_bf16x2(z0, z1);
+                        const float z0 = fmaxf(fmaf(s16_lo(v[k]), sc[2 * k], sh[2 * k]), 0.f);
+                        const float z1 = fmaxf(fmaf(s16_hi(v[k]), sc[2 * k + 1], sh[2 * k + 1]), 0.f);
+                        v[k] = pack_s16x2(z0, z1);
                     }
                 } else {
                     v = u32x4_t{0u, 0u, 0u, 0u};          // the zero padding of the post-activation tensor
@@ -401,7 +441,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                     for (int kx = 0; kx < KS; ++kx) {
                         const int lx = 16 * hh + li + kx;
-                        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(s_act + bf_slot<kCols>(R * wave + lr, lx, lk));
+                        const s16x8_t b = *reinterpret_cast<const s16x8_t*>(s_act + bf_slot<kCols>(R * wave + lr, lx, lk));
 #pragma unroll
                         for (int ky = 0; ky < KS; ++ky) {
                             const int r = lr - ky;
@@ -409,8 +449,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
                             for (int t = 0; t < NT; ++t) {
                                 const int wrow = (ky * KS + kx) * NT + t;
-                                const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(s_w + ((wrow * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
-                                acc[r][hh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[r][hh][t], 0, 0, 0);
+                                const s16x8_t a = *reinterpret_cast<const s16x8_t*>(s_w + ((wrow * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
+                                acc[r][hh][t] = S16_MFMA(a, b, acc[r][hh][t], 0, 0, 0);
                             }
                         }
                     }
@@ -456,11 +496,11 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         if (co >= p.cout || !pix_ok) continue;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) best[i] += p.bias ? p.bias[co + i] : 0.f;
-                        const unsigned lo = pack_bf16x2(best[0], best[1]), hi = pack_bf16x2(best[2], best[3]);
+                        const unsigned lo = pack_s16x2(best[0], best[1]), hi = pack_s16x2(best[2], best[3]);
                         const int64_t pix = static_cast<int64_t>(yp) * wp + xp;
                         *reinterpret_cast<u32x2_t*>(out_ptr(pix, co)) = u32x2_t{lo, hi};
                         *reinterpret_cast<unsigned*>(p.out_idx + (static_cast<int64_t>(n) * hp * wp + pix) * p.cout + co) = code;
-                        const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+                        const float q[4] = {s16_lo(lo), s16_hi(lo), s16_lo(hi), s16_hi(hi)};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
                     }
@@ -489,8 +529,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         uint16_t* dst = out_ptr(static_cast<int64_t>(yp) * wp + xp, co);
                         const u32x2_t old = *reinterpret_cast<const u32x2_t*>(dst);
                         const unsigned key = (static_cast<unsigned>(dst - out_n) + sr_sample) ^ p.sr_salt;
-                        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_bf16x2_sr(bf16_lo(old[0]) + sum[0], bf16_hi(old[0]) + sum[1], key),
-                                                                    pack_bf16x2_sr(bf16_lo(old[1]) + sum[2], bf16_hi(old[1]) + sum[3], key + 2)};
+                        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_s16x2_sr(s16_lo(old[0]) + sum[0], s16_hi(old[0]) + sum[1], key),
+                                                                    pack_s16x2_sr(s16_lo(old[1]) + sum[2], s16_hi(old[1]) + sum[3], key + 2)};
                     }
                 }
         } else if constexpr (EPI == kEpiDgradBn) {
@@ -534,8 +574,8 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                     for (int hh = 0; hh < 2; ++hh) {
                         if (offs[r][hh] < 0) continue;
                         const u32x2_t xq = xv[t][r][hh], oq = old[t][r][hh];
-                        const float xf[4] = {bf16_lo(xq[0]), bf16_hi(xq[0]), bf16_lo(xq[1]), bf16_hi(xq[1])};
-                        const float of[4] = {bf16_lo(oq[0]), bf16_hi(oq[0]), bf16_lo(oq[1]), bf16_hi(oq[1])};
+                        const float xf[4] = {s16_lo(xq[0]), s16_hi(xq[0]), s16_lo(xq[1]), s16_hi(xq[1])};
+                        const float of[4] = {s16_lo(oq[0]), s16_hi(oq[0]), s16_lo(oq[1]), s16_hi(oq[1])};
                         float nw[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
@@ -545,7 +585,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         }
                         uint16_t* dst = out_ptr(offs[r][hh], co);
                         const unsigned key = (static_cast<unsigned>(dst - out_n) + sr_sample) ^ p.sr_salt;
-                        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_bf16x2_sr(nw[0], nw[1], key), pack_bf16x2_sr(nw[2], nw[3], key + 2)};
+                        *reinterpret_cast<u32x2_t*>(dst) = u32x2_t{pack_s16x2_sr(nw[0], nw[1], key), pack_s16x2_sr(nw[2], nw[3], key + 2)};
                     }
             }
         } else {
@@ -562,10 +602,10 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
                         float v[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = acc[r][hh][t][i] + (p.bias ? p.bias[co + i] : 0.f);
-                        const unsigned lo = pack_bf16x2(v[0], v[1]), hi = pack_bf16x2(v[2], v[3]);
+                        const unsigned lo = pack_s16x2(v[0], v[1]), hi = pack_s16x2(v[2], v[3]);
                         if (pix_ok) {
                             *reinterpret_cast<u32x2_t*>(out_ptr(static_cast<int64_t>(y) * p.w + x, co)) = u32x2_t{lo, hi};
-                            const float q[4] = {bf16_lo(lo), bf16_hi(lo), bf16_lo(hi), bf16_hi(hi)};
+                            const float q[4] = {s16_lo(lo), s16_hi(lo), s16_lo(hi), s16_hi(hi)};
 #pragma unroll
                             for (int i = 0; i < 4; ++i) { s1[t][i] += q[i]; s2[t][i] = fmaf(q[i], q[i], s2[t][i]); }
                         }
@@ -646,8 +686,9 @@ __global__ void __launch_bounds__(256) bf16_conv_weights_kernel(const float* __r
         float v = 0.f;
         const int pci = ci < rot_n ? (ci + rot < rot_n ? ci + rot : ci + rot - rot_n) : ci;
         if (co < cout && ci < cin) v = w[(static_cast<int64_t>(co) * cin + pci) * taps + tap];
-        out[e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+        out[e] = static_cast<uint16_t>(pack_s16x2(v, 0.f) & 0xffffu);
     }
 }
 
+}  // inline namespace
 }  // namespace endo

@@ -23,6 +23,7 @@
 #include "bf16_conv_kernels.h"
 
 namespace endo {
+inline namespace ENDO16_NS {
 
 constexpr int kDbLayers = 4;
 constexpr int kDbPitch = 112;                        // bytes per staged pixel
@@ -43,7 +44,7 @@ struct DgradBlock16Params {
     const float* beta[kDbLayers];
     double* sums[kDbLayers];         // [cin_j][2] (sum da, sum da * x), accumulated
     int rot, rot_n;
-    unsigned sr_salt;                // stochastic rounding of the gradient stores (pack_bf16x2_sr)
+    unsigned sr_salt;                // stochastic rounding of the gradient stores (pack_s16x2_sr)
     int group_n;                     // sample groups (bf16_conv_kernels.h): group g's saved / sums start gs_saved / gs_sums elements later
     int64_t gs_saved, gs_sums;
 };
@@ -174,17 +175,17 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                bf16x8_t a[NT];
+                s16x8_t a[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    a[t] = *reinterpret_cast<const bf16x8_t*>(wj + ((((ky * 3 + kx) * NT + t) * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
+                    a[t] = *reinterpret_cast<const s16x8_t*>(wj + ((((ky * 3 + kx) * NT + t) * 16 + li) * 4 + (lk ^ ((li >> 1) & 3))) * 16);
 #pragma unroll
                 for (int r = 0; r < R; ++r)
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        const bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(s_g + ((R * wave + r + ky) * kDbCols + 16 * hh + li + kx) * kDbPitch + (u0 + lk) * 16);
+                        const s16x8_t b = *reinterpret_cast<const s16x8_t*>(s_g + ((R * wave + r + ky) * kDbCols + 16 * hh + li + kx) * kDbPitch + (u0 + lk) * 16);
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) acc[r][hh][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[t], b, acc[r][hh][t], 0, 0, 0);
+                        for (int t = 0; t < NT; ++t) acc[r][hh][t] = S16_MFMA(a[t], b, acc[r][hh][t], 0, 0, 0);
                     }
             }
         // ---- layer j's BatchNorm / ReLU backward on its share ----
@@ -202,7 +203,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
                 for (int hh = 0; hh < 2; ++hh) {
                     if (pix[r][hh] < 0) continue;
                     const u32x2_t xq = xv[t][r][hh];
-                    const float xf[4] = {bf16_lo(xq[0]), bf16_hi(xq[0]), bf16_lo(xq[1]), bf16_hi(xq[1])};
+                    const float xf[4] = {s16_lo(xq[0]), s16_hi(xq[0]), s16_lo(xq[1]), s16_hi(xq[1])};
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const float da = fmaf(xf[i], sc[i], sh[i]) > 0.f ? acc[r][hh][t][i] : 0.f;
@@ -250,8 +251,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
                 const float* tt = total[t][r][hh];
                 const int qo = quad_off(t, pix[r][hh]);
                 const unsigned key = (static_cast<unsigned>(qo) + static_cast<unsigned>(n - grp * (p.group_n > 0 ? p.group_n : 0)) * 0x632BE5ABu) ^ p.sr_salt;
-                *reinterpret_cast<u32x2_t*>(out_n + qo) = u32x2_t{pack_bf16x2_sr(bf16_lo(o[0]) + tt[0], bf16_hi(o[0]) + tt[1], key),
-                                                                  pack_bf16x2_sr(bf16_lo(o[1]) + tt[2], bf16_hi(o[1]) + tt[3], key + 2)};
+                *reinterpret_cast<u32x2_t*>(out_n + qo) = u32x2_t{pack_s16x2_sr(s16_lo(o[0]) + tt[0], s16_hi(o[0]) + tt[1], key),
+                                                                  pack_s16x2_sr(s16_lo(o[1]) + tt[2], s16_hi(o[1]) + tt[3], key + 2)};
             }
 }
 
@@ -270,4 +271,5 @@ inline int launch_bf16_dgrad_block(const DgradBlock16Params& p, hipStream_t stre
     return 0;
 }
 
+}  // inline namespace
 }  // namespace endo

@@ -12,7 +12,15 @@
 extern "C" int64_t endo_net_param_offset(int index);
 extern "C" int64_t endo_net_bn_offset(int bn_index, int which);
 
+// the half-storage build (net16h.hip) exports the network entry points as endo_net16h_*; the single-convolution bricks exist once (bf16)
+#ifdef ENDO16_HALF
+#define N16(name) endo_net16h_##name
+#else
+#define N16(name) endo_net16_##name
+#endif
+
 namespace endo {
+inline namespace ENDO16_NS {
 
 constexpr int k16Levels = 5, k16Layers = 4, k16Growth = 12, k16First = 48, k16New = 48;
 inline int c16_down_in(int level) { return k16First + k16New * level; }
@@ -141,7 +149,7 @@ __global__ void __launch_bounds__(256) bf16_all_weights_kernel(const W16Table t,
             const int pci = ci < t.rot_n[l] ? (ci + t.rot[l] < t.rot_n[l] ? ci + t.rot[l] : ci + t.rot[l] - t.rot_n[l]) : ci;
             if (co < t.cout[l] && ci < t.cin[l]) v = params[t.w[l] + (static_cast<int64_t>(co) * t.cin[l] + pci) * taps + tap];
         }
-        w16[t.out[l] + e] = static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+        w16[t.out[l] + e] = static_cast<uint16_t>(pack_s16x2(v, 0.f) & 0xffffu);
     }
 }
 
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(256) bf16_pack_input_kernel(const float* __res
     const int n = blockIdx.y;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
         const float* xp = x + static_cast<int64_t>(n) * 3 * plane + i;
-        const unsigned a = pack_bf16x2(xp[0], xp[plane]), b = pack_bf16x2(xp[2 * static_cast<int64_t>(plane)], 0.f);
+        const unsigned a = pack_s16x2(xp[0], xp[plane]), b = pack_s16x2(xp[2 * static_cast<int64_t>(plane)], 0.f);
         *reinterpret_cast<u32x4_t*>(out + (static_cast<int64_t>(n) * plane + i) * 8) = u32x4_t{a, b, 0u, 0u};
     }
 }
@@ -176,8 +184,8 @@ __global__ void __launch_bounds__(256) bf16_final_fwd_kernel(const uint16_t* __r
             const u32x4_t v = *reinterpret_cast<const u32x4_t*>(u + n * ns + (static_cast<int64_t>(c0 >> 5) * plane + px) * k16Blk + (c0 & 31));
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                acc = fmaf(bf16_lo(v[k]), wv[8 * j + 2 * k], acc);
-                acc = fmaf(bf16_hi(v[k]), wv[8 * j + 2 * k + 1], acc);
+                acc = fmaf(s16_lo(v[k]), wv[8 * j + 2 * k], acc);
+                acc = fmaf(s16_hi(v[k]), wv[8 * j + 2 * k + 1], acc);
             }
         }
         acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
@@ -198,7 +206,7 @@ __global__ void __launch_bounds__(256) bf16_pack_nhwc_kernel(const float* __rest
         const float v = x[(static_cast<int64_t>(n) * c + ch) * plane + px];
         const int ca = oc0 + ch, cb = ca / blk;
         out[static_cast<int64_t>(n) * plane * t + (static_cast<int64_t>(cb) * plane + px) * blk + (ca - cb * blk)] =
-            static_cast<uint16_t>(pack_bf16x2(v, 0.f) & 0xffffu);
+            static_cast<uint16_t>(pack_s16x2(v, 0.f) & 0xffffu);
     }
 }
 
@@ -209,16 +217,22 @@ __global__ void __launch_bounds__(256) bf16_unpack_nhwc_kernel(const uint16_t* _
         const int ch = i % c, px = i / c;
         const int ca = ic0 + ch, cb = ca / blk;
         x[(static_cast<int64_t>(n) * c + ch) * plane + px] =
-            bf16_lo(in[static_cast<int64_t>(n) * plane * t + (static_cast<int64_t>(cb) * plane + px) * blk + (ca - cb * blk)]);
+            s16_lo(in[static_cast<int64_t>(n) * plane * t + (static_cast<int64_t>(cb) * plane + px) * blk + (ca - cb * blk)]);
     }
 }
 
+}  // inline namespace
 }  // namespace endo
 
 using namespace endo;
 
+#ifdef ENDO16_HALF
+#define B16(name) endo_f16_##name
+#else
+#define B16(name) endo_bf16_##name
+#endif
 // blk: channels per block of the buffer ([n][t / blk][h][w][blk]); 0 or t = plain channels-last
-extern "C" int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int blk, int oc0, void* stream) {
+extern "C" int B16(pack_nhwc)(const float* x, void* out, int n, int c, int h, int w, int t, int blk, int oc0, void* stream) {
     if (blk <= 0) blk = t;
     if (!x || !out || n <= 0 || c <= 0 || h <= 0 || w <= 0 || oc0 < 0 || oc0 + c > t || t % blk) return ENDO_E_BADARG;
     bf16_pack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(x, static_cast<uint16_t*>(out), c, h * w, t, blk, oc0);
@@ -226,13 +240,14 @@ extern "C" int endo_bf16_pack_nhwc(const float* x, void* out, int n, int c, int 
     return 0;
 }
 
-extern "C" int endo_bf16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream) {
+extern "C" int B16(unpack_nhwc)(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream) {
     if (blk <= 0) blk = t;
     if (!x || !in || n <= 0 || c <= 0 || h <= 0 || w <= 0 || ic0 < 0 || ic0 + c > t || t % blk) return ENDO_E_BADARG;
     bf16_unpack_nhwc_kernel<<<dim3(256, n), 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(in), x, c, h * w, t, blk, ic0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
+#ifndef ENDO16_HALF
 extern "C" int64_t endo_bf16_conv_weight_elems(int cout, int cin, int ks) {
     if (cout <= 0 || cin <= 0 || (ks != 1 && ks != 3)) return -1;
     const int nt = cout <= 16 ? 1 : 3;
@@ -271,6 +286,8 @@ extern "C" int endo_bf16_conv(const void* in, int in_t, int in_blk, int ic0, int
 }
 
 
+#endif  // !ENDO16_HALF
+
 // ---------------------------------------------------------------------------------------------
 // FCDenseNet57 forward over bf16 level buffers (reference models.py:171-187)
 // ---------------------------------------------------------------------------------------------
@@ -295,6 +312,7 @@ struct endo_net16 {
     int64_t ws_zero_begin, ws_zero_end;   // everything but the level-0 gradient buffer starts at zero
     int64_t ws_w16d;                      // bytes
     int64_t ws_partial;                   // bytes
+    int64_t ws_gscale;                    // bytes: {S, 1 / S} of the stored gradients (half storage)
     int64_t ws_bytes;
     // the weight gradients read only finished tensors (forward activations, a prepared gradient range) and nothing waits for them but
     // the optimizer: they run on a side stream, forked after every prep_dy and joined once at the end (as in the fp32 family)
@@ -303,7 +321,7 @@ struct endo_net16 {
     int use_wstream = 1;
 };
 
-extern "C" int endo_net16_create(endo_net16** out, int n_per_group, int h, int w, int groups) {
+extern "C" int N16(create)(endo_net16** out, int n_per_group, int h, int w, int groups) {
     if (!out || n_per_group <= 0 || h <= 0 || w <= 0 || (h % 32) || (w % 32) || groups < 1 || groups > 2) return ENDO_E_BADARG;
     const int n = n_per_group * groups;
     const Table16& tb = table16();
@@ -351,12 +369,13 @@ extern "C" int endo_net16_create(endo_net16** out, int n_per_group, int h, int w
         }
         wg(k16Levels, 288 + k16Growth * 3, k16Growth, 3);
         net->ws_partial = o; o += align(need * 4);
+        net->ws_gscale = o; o += 256;
         net->ws_bytes = o;
     }
     *out = net;
     return 0;
 }
-extern "C" void endo_net16_destroy(endo_net16* net) {
+extern "C" void N16(destroy)(endo_net16* net) {
     if (!net) return;
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
@@ -365,18 +384,18 @@ extern "C" void endo_net16_destroy(endo_net16* net) {
 }
 // 1 (default): endo_net16_bwd issues the weight gradients on a side stream it owns (forked after every prep_dy, joined before it returns);
 // 0: everything in line on the caller's stream (what a caller capturing the step into a graph on one stream wants)
-extern "C" int endo_net16_set_wgrad_overlap(endo_net16* net, int on) {
+extern "C" int N16(set_wgrad_overlap)(endo_net16* net, int on) {
     if (!net) return ENDO_E_BADARG;
     net->use_wstream = on ? 1 : 0;
     return 0;
 }
-extern "C" int64_t endo_net16_tape_bytes(const endo_net16* net) { return net ? net->tape_bytes : 0; }
-extern "C" int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net) { return net ? net->ws_bytes : 0; }
+extern "C" int64_t N16(tape_bytes)(const endo_net16* net) { return net ? net->tape_bytes : 0; }
+extern "C" int64_t N16(bwd_workspace_bytes)(const endo_net16* net) { return net ? net->ws_bytes : 0; }
 // Where things are (tests read the forward pass's decisions and the gradient buffers): byte offsets into the tape -- what 0: final
 // pre-activation (fp32), 1: (mean, rstd) of BatchNorm layer `index` in module order (fp32), 2: max-pool codes of transition down
 // `index`, 3: level buffer `index` -- or into the backward workspace -- 4: gradient buffer of level `index`; 5: channels of level
 // buffer `index` (not an offset).  -1 for anything else.
-extern "C" int64_t endo_net16_offset(const endo_net16* net, int what, int index) {
+extern "C" int64_t N16(offset)(const endo_net16* net, int what, int index) {
     if (!net || index < 0) return -1;
     const Table16& tb = table16();
     switch (what) {
@@ -409,6 +428,11 @@ struct Ctx16 {
     double* bnsums(const Bn16& b) const { return reinterpret_cast<double*>(ws + net->ws_bnsums) + b.saved; }
     const uint16_t* w16d(const Conv16& c) const { return reinterpret_cast<const uint16_t*>(ws + net->ws_w16d) + c.w16d; }
     float* partial() const { return reinterpret_cast<float*>(ws + net->ws_partial); }
+#ifdef ENDO16_HALF
+    const float* gscale() const { return reinterpret_cast<const float*>(ws + net->ws_gscale); }
+#else
+    const float* gscale() const { return nullptr; }
+#endif
     // the side stream, after everything issued on `stream` so far
     int fork_wgrad(hipStream_t& side) const {
         const bool on = net->wstream && net->use_wstream;
@@ -487,7 +511,7 @@ int tu16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16& cv)
 // x: fp32 [n][3][H][W] (already multiplied by the boundary, train.py:272-273; rounded to bf16 on the way in); out: fp32 [n][1][H][W] >= 0.
 // training != 0: batch statistics + running-statistics update (momentum 0.1, eps 1e-5); 0: running statistics.  tape:
 // endo_net16_tape_bytes() bytes, 256-byte aligned.  H, W multiples of 32.
-extern "C" int endo_net16_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape_, int training,
+extern "C" int N16(fwd)(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape_, int training,
                               void* stream_) {
     if (!net || !params || !bn_running || !x || !out || !tape_) return ENDO_E_BADARG;
     const Table16& tb = table16();
@@ -572,7 +596,7 @@ int prep_dy16(const Ctx16& c, int level, int c0, int count, float* bias_grad) {
     const dim3 grid = c.training ? dim3(bx, c.net->n) : dim3(1, 1);          // inference mode: only the bias gradient
     bf16_prep_dy_kernel<<<grid, 256, 0, c.stream>>>(c.dbuf(level), c.act(level), lv.plane * lv.t, static_cast<int>(lv.plane), k16Blk, c0, count,
                                                                   c.pq_p(level), c.pq_q(level), bias_grad, c.gsum(level), c.training,
-                                                                  c.net->groups > 1 ? c.net->gn : 0, 2 * lv.t);
+                                                                  c.net->groups > 1 ? c.net->gn : 0, 2 * lv.t, c.gscale());
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -584,7 +608,7 @@ int bn_finalize16(const Ctx16& c, const Bn16& b, const Conv16& cv, int level, in
     if (count == 0) return 0;
     bf16_bn_finalize_kernel<<<dim3((count + 127) / 128, c.net->groups), 128, 0, c.stream>>>(
         c.bnsums(b), c.saved(b), c.params + b.g, c.grads + b.g, c.grads + b.b, c.pq_p(level), c.pq_q(level), c.gsum(level), first, count, cv.rot, cv.rot_n,
-        static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved, 2 * lv.t);
+        static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved, 2 * lv.t, c.gscale());
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -595,7 +619,7 @@ void fill_wgrad_a(const Ctx16& c, Wgrad16Params& p, int level, int ac0, int cin,
     if (b) { p.saved = c.saved(*b); p.gamma = c.params + b->g; p.beta = c.params + b->b; }
     p.rot = cv.rot; p.rot_n = cv.rot_n;
     p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved;
-    p.partial = c.partial();
+    p.partial = c.partial(); p.gscale = c.gscale();
 }
 
 // the data gradient of a BN -> ReLU -> conv layer: a convolution over the gradient of its outputs with the kEpiDgradBn epilogue
@@ -739,7 +763,7 @@ int tu_bwd16(const Ctx16& c, int level, int src_level, int src_c0, const Conv16&
 // aligned.  `training` as in the forward call (0: BatchNorm as a fixed affine map, the reference's .eval() backward).  Gradients
 // between layers are stored as bf16 (fp32 accumulation inside every kernel); BatchNorm sums, parameter gradients and the deferred
 // BatchNorm terms are fp32 / fp64.
-extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* tape_, const float* grad_out, float* grads, void* ws_, int training,
+extern "C" int N16(bwd)(endo_net16* net, const float* params, const void* tape_, const float* grad_out, float* grads, void* ws_, int training,
                               void* stream_) {
     if (!net || !params || !tape_ || !grad_out || !grads || !ws_) return ENDO_E_BADARG;
     const Table16& tb = table16();
@@ -770,13 +794,18 @@ extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* 
         ENDO_LAUNCH_CHECK();
     }
     int rc;
+#ifdef ENDO16_HALF
+    s16_grad_scale_kernel<<<1, 1024, 0, stream>>>(grad_out, static_cast<int64_t>(net->n) * net->lv[0].plane,
+                                                  reinterpret_cast<float*>(c.ws + net->ws_gscale));
+    ENDO_LAUNCH_CHECK();
+#endif
     {
         const auto& lv = net->lv[0];
         int bx = static_cast<int>((lv.plane * 8 + 255) / 256);
         bx = bx > 512 ? 512 : bx;
         bf16_final_bwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(grad_out, reinterpret_cast<const float*>(c.tape + net->pre_off), c.act(0), c.dbuf(0),
                                                                     lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w, tb.final_.rot,
-                                                                    tb.final_.rot_n, grads + tb.final_.w, grads + tb.final_.b, c.gsum(0));
+                                                                    tb.final_.rot_n, grads + tb.final_.w, grads + tb.final_.b, c.gsum(0), c.gscale());
         ENDO_LAUNCH_CHECK();
     }
     for (int i = k16Levels - 1; i >= 0; --i) {
@@ -803,7 +832,7 @@ extern "C" int endo_net16_bwd(endo_net16* net, const float* params, const void* 
         p.a = reinterpret_cast<const uint16_t*>(c.tape + net->in_off); p.a_ns = lv.plane * 8; p.a_blk = 8; p.a_h = lv.h; p.a_w = lv.w; p.ac0 = 0; p.cin = 4;
         p.cin_w = 3;
         p.g = c.dbuf(0); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = 0; p.cout = k16First;
-        p.partial = c.partial();
+        p.partial = c.partial(); p.gscale = c.gscale();
         hipStream_t side;
         rc = c.fork_wgrad(side);
         if (rc) return rc;

@@ -123,9 +123,10 @@ class _Net16Function(torch.autograd.Function):
     """The bf16-storage network (endo_net16_fwd / endo_net16_bwd) as one autograd node."""
 
     @staticmethod
-    def forward(ctx, x, anchor, net):
+    def forward(ctx, x, anchor, net, half=False):
         x = _lib.dev_f32(x, "FCDenseNet57 input")
-        out, tape = net._run_forward16(x)
+        out, tape = net._run_forward16(x, 1, half)
+        ctx.half = half
         ctx.net = net
         ctx.training = net.training
         ctx.tape = tape
@@ -138,9 +139,9 @@ class _Net16Function(torch.autograd.Function):
             raise RuntimeError("FCDenseNet57 on the MI355X path does not produce a gradient for its input image; detach the input")
         if ctx.tape is None:
             raise RuntimeError("FCDenseNet57: the forward tape of this call was released by its first backward pass")
-        ctx.net._run_backward16(ctx.shape, ctx.tape, grad_out, ctx.training)
+        ctx.net._run_backward16(ctx.shape, ctx.tape, grad_out, ctx.training, 1, ctx.half)
         ctx.tape = None
-        return None, None, None
+        return None, None, None, None
 
 
 class FCDenseNet(nn.Module):
@@ -293,7 +294,7 @@ class FCDenseNet(nn.Module):
         options[option_id] = value
         lib = _lib.load()
         for key, (hnd, _, _) in self._handles.items():
-            if key[0] == "bf16":
+            if key[0] in ("bf16", "fp16"):
                 continue
             rc = lib.endo_net_set_option(hnd, option_id, value)
             if rc < 0:
@@ -307,7 +308,7 @@ class FCDenseNet(nn.Module):
         try:
             lib = _lib.load()
             for key, (hnd, _, _) in self._handles.items():
-                (lib.endo_net16_destroy if key[0] == "bf16" else lib.endo_net_destroy)(hnd)
+                {"bf16": lib.endo_net16_destroy, "fp16": lib.endo_net16h_destroy}.get(key[0], lib.endo_net_destroy)(hnd)
             self._handles = {}
         except Exception:
             pass
@@ -393,14 +394,30 @@ class FCDenseNet(nn.Module):
         out, _ = self._run_forward16(_lib.dev_f32(x, "FCDenseNet57 input"))
         return out
 
-    def _handle16(self, n, h, w, groups=1):
-        """n: samples per group"""
+    def forward_fp16_storage(self, x):
+        """``forward_bf16_storage`` over IEEE half level buffers (``endo_net16h_*``: BASELINE configs[4]'s "fp16 storage / fp32
+        accumulate"): the same kernels compiled for another element type; the backward pass scales the stored gradients by a power of
+        two chosen from max |grad_output| (half's range) and returns unscaled parameter gradients.  Its own bounds: tests/test_gpu_bf16.py."""
+        if torch.is_grad_enabled():
+            return _Net16Function.apply(x, self._anchor, self, True)
+        out, _ = self._run_forward16(_lib.dev_f32(x, "FCDenseNet57 input"), 1, True)
+        return out
+
+    @staticmethod
+    def _api16(half):
+        """the entry points of the 16-bit-storage family for bf16 (endo_net16_*) or half (endo_net16h_*)"""
         lib = _lib.load()
-        key = ("bf16", n, h, w, groups)
+        prefix = "endo_net16h_" if half else "endo_net16_"
+        return lambda name: getattr(lib, prefix + name)
+
+    def _handle16(self, n, h, w, groups=1, half=False):
+        """n: samples per group"""
+        api = self._api16(half)
+        key = ("fp16" if half else "bf16", n, h, w, groups)
         if key not in self._handles:
             hnd = ctypes.c_void_p()
-            _lib.check(lib.endo_net16_create(ctypes.byref(hnd), n, h, w, groups), "endo_net16_create(%d,%d,%d,%d)" % (n, h, w, groups))
-            self._handles[key] = (hnd, int(lib.endo_net16_tape_bytes(hnd)), int(lib.endo_net16_bwd_workspace_bytes(hnd)))
+            _lib.check(api("create")(ctypes.byref(hnd), n, h, w, groups), "endo_net16_create(%d,%d,%d,%d)" % (n, h, w, groups))
+            self._handles[key] = (hnd, int(api("tape_bytes")(hnd)), int(api("bwd_workspace_bytes")(hnd)))
         return self._handles[key]
 
     def forward_pair_bf16_storage(self, x1, x2):
@@ -412,8 +429,8 @@ class FCDenseNet(nn.Module):
         n = x1.shape[0]
         return out[:n], out[n:]
 
-    def _run_forward16(self, x, groups=1):
-        lib = _lib.load()
+    def _run_forward16(self, x, groups=1, half=False):
+        api = self._api16(half)
         if x.dim() != 4 or x.shape[1] != 3:
             raise RuntimeError("expected N x 3 x H x W input")
         if x.device != self._flat.device:
@@ -421,27 +438,27 @@ class FCDenseNet(nn.Module):
         if not self._views_intact():
             self._flatten()
         n, _, h, w = x.shape
-        hnd, tape_bytes, _ = self._handle16(n // groups, h, w, groups)
+        hnd, tape_bytes, _ = self._handle16(n // groups, h, w, groups, half)
         tape = torch.empty(tape_bytes, dtype=torch.uint8, device=x.device)
         out = torch.empty((n, 1, h, w), dtype=torch.float32, device=x.device)
         with torch.no_grad():
-            _lib.check(lib.endo_net16_fwd(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out), _lib.ptr(tape),
-                                          1 if self.training else 0, _lib.stream()), "endo_net16_fwd")
+            _lib.check(api("fwd")(hnd, _lib.ptr(self._flat), _lib.ptr(self._flat_bn), _lib.ptr(x), _lib.ptr(out), _lib.ptr(tape),
+                                  1 if self.training else 0, _lib.stream()), "endo_net16_fwd")
         if self.training:
             self._nbt.add_(groups)
         return out, tape
 
-    def _run_backward16(self, shape, tape, grad_out, training, groups=1):
-        lib = _lib.load()
+    def _run_backward16(self, shape, tape, grad_out, training, groups=1, half=False):
+        api = self._api16(half)
         n, _, h, w = shape
-        hnd, _, ws_bytes = self._handle16(n // groups, h, w, groups)
-        key = ("bf16", n // groups, h, w, groups)
+        hnd, _, ws_bytes = self._handle16(n // groups, h, w, groups, half)
+        key = ("fp16" if half else "bf16", n // groups, h, w, groups)
         if key not in self._gradws:
             self._gradws[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=tape.device)
         self._attach_grads()
         grad_out = _lib.dev_f32(grad_out, "grad_output")
-        _lib.check(lib.endo_net16_bwd(hnd, _lib.ptr(self._flat), _lib.ptr(tape), _lib.ptr(grad_out), _lib.ptr(self._flat_grad),
-                                      _lib.ptr(self._gradws[key]), 1 if training else 0, _lib.stream()), "endo_net16_bwd")
+        _lib.check(api("bwd")(hnd, _lib.ptr(self._flat), _lib.ptr(tape), _lib.ptr(grad_out), _lib.ptr(self._flat_grad),
+                              _lib.ptr(self._gradws[key]), 1 if training else 0, _lib.stream()), "endo_net16_bwd")
 
     def forward_pair(self, x1, x2):
         """``(self(x1), self(x2))`` -- the two forward passes of a training step (reference train.py:276-277) -- as ONE

@@ -45,13 +45,15 @@ def mask_mul(a, mask):
 
 class TrainingStep(object):
     def __init__(self, model, optimizer, height, width, sfl_weight=20.0, dcl_weight=0.1, epsilon=1.0e-8, pair_forward=True,
-                 fused_head=True, bf16_storage=False):
+                 fused_head=True, bf16_storage=False, fp16_storage=False):
         self.model = model
         # the network over bf16 level buffers (FCDenseNet.forward_bf16_storage: activations and inter-layer gradients stored as
         # bf16, bf16 matrix cores, fp32 accumulation / statistics / parameter gradients; BASELINE configs[2]); the two frames are two
         # sample groups of one call (each with its own BatchNorm statistics, as the reference's two calls, train.py:276-277); losses,
         # clipping and SGD stay fp32
-        self.bf16_storage = bool(bf16_storage)
+        # fp16_storage: the same family over IEEE half (FCDenseNet.forward_fp16_storage; BASELINE configs[4]'s storage half)
+        self.half_storage = bool(fp16_storage)
+        self.bf16_storage = bool(bf16_storage) or self.half_storage
         if self.bf16_storage and not (fused_head and pair_forward):
             raise ValueError("bf16_storage runs through the fused loss head")
         self.epsilon = float(epsilon)
@@ -127,7 +129,7 @@ class TrainingStep(object):
             _lib.check(lib.endo_mask_mul(_lib.ptr(c1), _lib.ptr(b), _lib.ptr(x[:n]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
             _lib.check(lib.endo_mask_mul(_lib.ptr(c2), _lib.ptr(b), _lib.ptr(x[n:]), n, ch, h * w, _lib.stream()), "endo_mask_mul")
             if self.bf16_storage:
-                pred, tape = self.model._run_forward16(x, 2)       # both frames as two sample groups of one call
+                pred, tape = self.model._run_forward16(x, 2, self.half_storage)       # both frames as two sample groups of one call
             else:
                 pred, tape = self.model._run_forward(x, 2)          # (2N, 1, H, W): frame 1's predictions first
             need = int(lib.endo_loss_head_workspace_floats(n, h, w))
@@ -149,7 +151,7 @@ class TrainingStep(object):
     def _fused_backward(self, x, tape, grad_pred):
         with torch.no_grad():
             if self.bf16_storage:
-                self.model._run_backward16(tuple(x.shape), tape, grad_pred, self.model.training, 2)
+                self.model._run_backward16(tuple(x.shape), tape, grad_pred, self.model.training, 2, self.half_storage)
             else:
                 self.model._run_backward(x, tape, grad_pred, self.model.training, 2)
 

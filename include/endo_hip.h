@@ -394,6 +394,22 @@ int64_t endo_net16_bwd_workspace_bytes(const endo_net16* net);
 /* 1 (default): endo_net16_bwd runs the weight gradients on a side stream of its own, forked from and joined back into the caller's
  * stream by events before it returns; 0: everything in line on the caller's stream */
 int endo_net16_set_wgrad_overlap(endo_net16* net, int on);
+/* The same family over IEEE HALF storage (BASELINE configs[4]: "mixed fp16 storage / fp32 accum"): identical signatures and buffer
+ * layouts (csrc/net16h.hip compiles the bf16 sources with another element type), v_mfma_f32_16x16x32_f16, and a power-of-two gradient
+ * scale chosen per backward call from max |grad_out| (per-pixel gradients of a mean loss are far below half's smallest normal):
+ * stored gradients carry it, parameter gradients leave without it.  endo_f16_pack_nhwc / unpack_nhwc: the layout helpers for half. */
+int endo_net16h_create(endo_net16** out, int n_per_group, int h, int w, int groups);
+void endo_net16h_destroy(endo_net16* net);
+int64_t endo_net16h_tape_bytes(const endo_net16* net);
+int endo_net16h_fwd(endo_net16* net, const float* params, float* bn_running, const float* x, float* out, void* tape, int training,
+                    void* stream);
+int64_t endo_net16h_bwd_workspace_bytes(const endo_net16* net);
+int endo_net16h_set_wgrad_overlap(endo_net16* net, int on);
+int64_t endo_net16h_offset(const endo_net16* net, int what, int index);
+int endo_net16h_bwd(endo_net16* net, const float* params, const void* tape, const float* grad_out, float* grads, void* ws, int training,
+                    void* stream);
+int endo_f16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, int t, int blk, int oc0, void* stream);
+int endo_f16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream);
 /* byte offsets into the tape (what 0: final pre-activation fp32; 1: (mean, rstd) of BatchNorm `index` in module order; 2: max-pool
  * codes of transition down `index` ([n][h / 2][w / 2][cout] bytes); 3: level buffer `index`) or the backward workspace (4: gradient
  * buffer of level `index`); 5: channels of level buffer `index`.  Level buffers: [n][t / 32][h][w][32] bf16, channels [0, S) the

@@ -129,6 +129,11 @@ def bf16_ste(t):
     return t + (t.detach().to(torch.bfloat16).to(t.dtype) - t.detach())
 
 
+def fp16_ste(t):
+    """``bf16_ste`` for IEEE half storage (endo_net16h_fwd)."""
+    return t + (t.detach().to(torch.float16).to(t.dtype) - t.detach())
+
+
 def _q(quant, t):
     return t if quant is None else quant(t)
 

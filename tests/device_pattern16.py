@@ -30,8 +30,13 @@ def bn_layers():
     return out
 
 
-def level_buffer(lib, hnd, buf, what, level, n, h, w):
+def level_buffer(lib, hnd, buf, what, level, n, h, w, half=False):
     """fp32 [n][t][h >> level][w >> level] copy of a level buffer of the tape (what 3) or the gradient workspace (what 4)."""
+    if half:
+        class _H(object):          # the half build's entry points under the bf16 names used below
+            endo_net16_offset = lib.endo_net16h_offset
+            endo_bf16_unpack_nhwc = lib.endo_f16_unpack_nhwc
+        lib = _H
     t = int(lib.endo_net16_offset(hnd, 5, level))
     hh, ww = h >> level, w >> level
     out = torch.empty((n, t, hh, ww), dtype=torch.float32, device=buf.device)
@@ -41,16 +46,17 @@ def level_buffer(lib, hnd, buf, what, level, n, h, w):
     return out.cpu()
 
 
-def pattern_from_tape(model, tape, n, h, w):
+def pattern_from_tape(model, tape, n, h, w, half=False):
     lib = ea._lib.load()
-    hnd, _, _ = model._handle16(n, h, w, 1)
+    hnd, _, _ = model._handle16(n, h, w, 1, half)
+    offset = lib.endo_net16h_offset if half else lib.endo_net16_offset
     params = dict(model.named_parameters())
     raw = tape.detach().cpu().numpy()
-    levels = [level_buffer(lib, hnd, tape, 3, lvl, n, h, w) for lvl in range(6)]
+    levels = [level_buffer(lib, hnd, tape, 3, lvl, n, h, w, half) for lvl in range(6)]
     pat = {}
     for index, (prefix, lvl, chans) in enumerate(bn_layers()):
         cnt = len(chans)
-        off = int(lib.endo_net16_offset(hnd, 1, index))
+        off = int(offset(hnd, 1, index))
         saved = torch.from_numpy(raw[off:off + 8 * cnt].view(np.float32).copy()).view(cnt, 2)          # indexed by reference channel
         mean, rstd = saved[:, 0], saved[:, 1]
         gamma = params[prefix + ".weight"].detach().cpu().float()
@@ -63,10 +69,10 @@ def pattern_from_tape(model, tape, n, h, w):
     for lvl in range(5):
         c = skip(lvl)
         hh, ww = h >> (lvl + 1), w >> (lvl + 1)
-        off = int(lib.endo_net16_offset(hnd, 2, lvl))
+        off = int(offset(hnd, 2, lvl))
         codes = torch.from_numpy(raw[off:off + n * c * hh * ww].copy()).view(n, hh, ww, c).permute(0, 3, 1, 2).contiguous()
         pat["pool::transDownBlocks.%d" % lvl] = codes
-    off = int(lib.endo_net16_offset(hnd, 0, 0))
+    off = int(offset(hnd, 0, 0))
     pre = torch.from_numpy(raw[off:off + 4 * n * h * w].view(np.float32).copy()).view(n, 1, h, w)
     pat["sign"] = torch.sign(pre)
     return pat
@@ -78,4 +84,4 @@ def pattern_of(output, model, n, h, w):
         nxt = [fn for fn, _ in node.next_functions if fn is not None]
         node = nxt[0] if nxt else None
     assert node is not None and node.tape is not None, "no forward tape behind this tensor"
-    return pattern_from_tape(model, node.tape, n, h, w)
+    return pattern_from_tape(model, node.tape, n, h, w, bool(getattr(node, "half", False)))

@@ -7,6 +7,6 @@ import test_gpu_bf16 as t
 mode = sys.argv[1] if len(sys.argv) > 1 else "eval"
 shape = tuple(int(v) for v in sys.argv[2:5]) if len(sys.argv) > 4 else (2, 256, 320)
 try:
-    t.test_bf16_storage_backward(shape, mode)
+    t.test_bf16_storage_backward(shape, mode, sys.argv[5] if len(sys.argv) > 5 else "bf16")
 except AssertionError as e:
     print("assert:", str(e)[:300])

@@ -142,8 +142,12 @@ def test_bf16_conv_dense_layer_timing():
 BF16_STORAGE_FWD_TOL = 2e-2          # depth against the fp64 oracle, max error / max depth; measured 6e-3 .. 1e-2 (printed by the test)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 128, 160), (2, 256, 320)])
-def test_bf16_storage_forward(shape):
+FP16_STORAGE_FWD_TOL = 3e-3          # the same family over IEEE half (11 significant bits): measured 8e-4 .. 1.3e-3
+
+
+@pytest.mark.parametrize("shape,storage", [((2, 64, 96), "bf16"), ((1, 128, 160), "bf16"), ((2, 256, 320), "bf16"), ((1, 128, 160), "fp16"),
+                                           ((2, 256, 320), "fp16")], ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
+def test_bf16_storage_forward(shape, storage):
     """FCDenseNet57.forward_bf16_storage (endo_net16_fwd; reference models.py:171-187) against the fp64 oracle and against the fp32
     HIP path on the same parameters and input: training mode (batch statistics; the running statistics after the call against the
     fp32 path's) and eval mode (running statistics).  A different function from the fp32 path -- activations carry 8 significant
@@ -165,7 +169,7 @@ def test_bf16_storage_forward(shape):
         getattr(ref32, mode)(); getattr(bf, mode)()
         with torch.no_grad():
             y32 = ref32(x.to(dev()))
-            y16 = bf.forward_bf16_storage(x.to(dev()))
+            y16 = (bf.forward_fp16_storage if storage == "fp16" else bf.forward_bf16_storage)(x.to(dev()))
         torch.cuda.synchronize()
         st64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in state.items()}
         if mode == "eval":          # the oracle's running statistics after one training-mode call, as both models have them now
@@ -176,9 +180,9 @@ def test_bf16_storage_forward(shape):
         e16 = float((y16.double().cpu() - y64).abs().max() / y64.abs().max())
         e32 = float((y32.double().cpu() - y64).abs().max() / y64.abs().max())
         rel_l2 = float((y16.double().cpu() - y64).norm() / y64.norm())
-        print("bf16-storage forward %s %s: max err / max depth %.2e (fp32 path %.1e), relative L2 %.2e" % (shape, mode, e16, e32, rel_l2))
+        print("%s-storage forward %s %s: max err / max depth %.2e (fp32 path %.1e), relative L2 %.2e" % (storage, shape, mode, e16, e32, rel_l2))
         assert torch.isfinite(y16).all()
-        assert e16 <= BF16_STORAGE_FWD_TOL, (mode, e16)
+        assert e16 <= (FP16_STORAGE_FWD_TOL if storage == "fp16" else BF16_STORAGE_FWD_TOL), (mode, e16)
         assert rel_l2 <= 2e-2, (mode, rel_l2)
         if mode == "train":
             sd32, sd16 = ref32.state_dict(), bf.state_dict()
@@ -233,10 +237,11 @@ def _grads_by_name(model):
     return {k: p.grad.detach().clone() for k, p in model.named_parameters()}
 
 
-@pytest.mark.parametrize("shape,mode", [((2, 64, 96), "train"), ((1, 128, 160), "train"), ((2, 64, 96), "eval"), ((1, 128, 160), "eval"),
-                                        ((2, 256, 320), "train")],          # the last: the benchmark's frame size
+@pytest.mark.parametrize("shape,mode,storage", [((2, 64, 96), "train", "bf16"), ((1, 128, 160), "train", "bf16"), ((2, 64, 96), "eval", "bf16"),
+                                                ((1, 128, 160), "eval", "bf16"), ((2, 256, 320), "train", "bf16"),          # the benchmark's frame size
+                                                ((1, 128, 160), "train", "fp16"), ((1, 128, 160), "eval", "fp16"), ((2, 256, 320), "train", "fp16")],
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
-def test_bf16_storage_backward(shape, mode):
+def test_bf16_storage_backward(shape, mode, storage):
     """Parameter gradients of FCDenseNet57.forward_bf16_storage (endo_net16_bwd) against the fp64 oracle evaluated (a) with the SAME
     roundings in its forward direction (oracle.network.forward(quant=bf16_ste): input, stored convolution outputs, staged
     relu(bn(x)) and matrix-core weights rounded to bf16, identity backward) and (b) on the ReLU / max-pool / sign pattern the HIP
@@ -255,13 +260,18 @@ def test_bf16_storage_backward(shape, mode):
     m.load_state_dict(state)
     m = m.to(dev())
     getattr(m, mode)()
-    y = m.forward_bf16_storage(x.to(dev()))
+    # storage "fp16": the same family over IEEE half (forward_fp16_storage, endo_net16h_*; BASELINE configs[4]'s storage half); the output
+    # gradient is scaled down to the per-pixel size a mean loss produces (1e-6), which half cannot hold without the backward's own scale
+    half = storage == "fp16"
+    if half:
+        g = g * 1.0e-6
+    y = (m.forward_fp16_storage if half else m.forward_bf16_storage)(x.to(dev()))
     pattern = pattern_of(y, m, n, h, w)
     y.backward(g.to(dev()))
     torch.cuda.synchronize()
     # the oracle, on that pattern
     st64 = {k: (v.double().requires_grad_(k in onet.trainable_names()) if v.is_floating_point() else v.clone()) for k, v in state.items()}
-    y64 = onet.forward(st64, x.double(), training=(mode == "train"), quant=onet.bf16_ste, pattern=pattern)
+    y64 = onet.forward(st64, x.double(), training=(mode == "train"), quant=onet.fp16_ste if half else onet.bf16_ste, pattern=pattern)
     y64.backward(g.double())
     want = {k: st64[k].grad for k in onet.trainable_names()}
     got = {k: v.double().cpu() for k, v in _grads_by_name(m).items()}
@@ -285,7 +295,7 @@ def test_bf16_storage_backward(shape, mode):
         den = sum(float((want[k] ** 2).sum()) for k in want if k.endswith(kind))
         print("      kind %-20s relative L2 %.2e" % (kind, (num / max(den, 1e-300)) ** 0.5))
     worst, worst_name = rows[0][0], rows[0][1]
-    print("bf16-storage backward %s %s: forward vs the bf16-rounding oracle %.2e; worst tensor %s max err / max |g| = %.2e; all parameters relative L2 %.2e" % (
+    print(storage + "-storage backward %s %s: forward vs the rounding oracle %.2e; worst tensor %s max err / max |g| = %.2e; all parameters relative L2 %.2e" % (
         shape, mode, e_fwd, worst_name, worst, (l2_num / l2_den) ** 0.5))
     assert e_fwd <= 8e-3, e_fwd
     for err, k, _, _ in rows:
