@@ -34,5 +34,7 @@ python3 $R/tools/pmc_traffic.py /tmp/pf2/f_results.db /tmp/pw2/w_results.db $O/$
 cd $R
 cp $O/${TAG}_pmc_traffic_config2.json $O/${TAG}_kernel_stats_config2.json $R/profiles/
 python bench.py --config 2 --no-cpu-baseline > $O/${TAG}_bench_config2.json 2> $O/bench2.err
+python bench.py --config 4 --no-cpu-baseline > $O/${TAG}_bench_config4.json 2> $O/bench4.err
+python bench.py --config 3 --no-cpu-baseline > $O/${TAG}_bench_config3.json 2> $O/bench3.err
 tail -1 $O/${TAG}_bench.json | cut -c1-900
 ls -la $O
