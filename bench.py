@@ -350,6 +350,7 @@ def main():
     it = 0
     serial_steps = max(args.warmup - 1, 0)
     model.set_kernel_option(5, 0)                                      # ENDO_OPT_WGRAD_OVERLAP off: kernels one at a time
+    model.set_wgrad_overlap16(False)                                   # the same for the 16-bit-storage family's handles
     lib.endo_prof_enable(all_mask if serial_steps > 0 else 0)
     for _ in range(serial_steps):
         scheduler.batch_step(batch_iteration=it)
@@ -359,6 +360,7 @@ def main():
     fam_warm = {f: prof_read(lib, f) for f in MFMA_FAMILIES} if serial_steps > 0 else None
     lib.endo_prof_enable(0)
     model.set_kernel_option(5, 1)
+    model.set_wgrad_overlap16(True)
     for _ in range(args.warmup - serial_steps):
         scheduler.batch_step(batch_iteration=it)
         step_fn(batch)
@@ -526,7 +528,6 @@ def main():
                   "mfma_tflops_for_reference": achieved})
         result["conv_roofline_frac_whole_step"] = None
         if bf16_storage:
-            r["concurrent"] = False          # one stream: kernels run one at a time
             r["algorithmic_bytes_note"] = ("bf16 tensors: dense forward 2 B x (Cin + 12) per pixel; data gradient 2 B x 12 + per input "
                                            "channel the forward value (2 B) and the gradient read and written (4 B); weight gradient "
                                            "2 B x (Cin + 12) per pixel")
