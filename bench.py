@@ -531,8 +531,12 @@ def main():
             r["algorithmic_bytes_note"] = ("bf16 tensors: dense forward 2 B x (Cin + 12) per pixel; data gradient 2 B x 12 + per input "
                                            "channel the forward value (2 B) and the gradient read and written (4 B); weight gradient "
                                            "2 B x (Cin + 12) per pixel")
-            result["roofline_serial"]["unit"] = "TFLOP/s (bf16 matrix cores; these kernels are HBM-bound, see roofline)"
-            result["roofline_serial"]["frac"] = None
+            # stand-alone: the same family with the weight gradients in line (warm-up steps), as HBM GB/s of algorithmic bytes
+            sgbs = fam_warm[dominant][3] / fam_warm[dominant][0] / 1e6 if fam_warm is not None and fam_warm[dominant][0] > 0 else None
+            result["roofline_serial"].update({"bound": "hbm", "mfma_tflops_for_reference": result["roofline_serial"]["achieved"],
+                                              "achieved": sgbs, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                              "frac": sgbs / HBM_PEAK_GBS if sgbs else None})
+            result["roofline_serial"].pop("families_tflops", None)
         else:
             result["roofline_serial"] = None
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only
