@@ -386,3 +386,40 @@ def test_bf16_storage_pair_as_two_groups():
     print("two groups vs two calls: worst weight / BatchNorm tensor %s %.2e, worst bias %s %.2e" % (worst_w[1], worst_w[0], worst_b[1], worst_b[0]))
     assert worst_w[0] <= 3e-2, worst_w          # measured 1.2e-2 (a level-5 tensor: 6 pixels per sample at this size)
     assert worst_b[0] <= 6e-2, worst_b
+
+
+@pytest.mark.parametrize("storage,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
+def test_16bit_training_step_against_oracle(storage, tol):
+    """One TrainingStep of the 16-bit-storage modes (both frames as two sample groups, fused loss head, clipping + SGD; what bench.py
+    --config 2 / 4 times) against the CPU oracle's training iteration (reference train.py:272-328) on the same batch: loss, its two terms
+    and the gradient norm.  Bounds of the modes, not of fp32 rounding: measured 1.5e-4 / 1.5e-5 (loss) and 8e-3 / 3e-3 (gradient norm)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet, train_step as ostep
+    n, h, w = 1, 64, 96
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(7), 8))
+    state0 = {k: v.clone() for k, v in state.items()}
+    batch = ea.synthetic.make_batch(n, h, w, seed=3, sparse_points=300)
+    ref = ostep.train_iteration(state, {}, batch, 1.0e-3)          # updates `state` in place
+    m = ea.FCDenseNet57(1)
+    m.load_state_dict(state0)
+    m = m.to(dev()).train()
+    step = ea.train_step.TrainingStep(m, ea.optim.FusedClipSGD(m, lr=1.0e-3), h, w, bf16_storage=(storage == "bf16"), fp16_storage=(storage == "fp16"))
+    out = step({k: v.to(dev()) for k, v in batch.items()}, lr=1.0e-3)
+    torch.cuda.synchronize()
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    print("%s-storage training step: loss %.6f (oracle %.6f), gradient norm %.4f (oracle %.4f)" % (storage, out["loss"], float(ref["loss"]),
+                                                                                                   float(out["grad_norm"]), float(ref["grad_norm"])))
+    assert not out["skipped"]
+    assert rel(out["loss"], ref["loss"]) <= tol
+    assert rel(out["dcl"], ref["dcl"]) <= 5 * tol and rel(out["sfl"], ref["sfl"]) <= tol
+    assert rel(out["grad_norm"], ref["grad_norm"]) <= 5 * tol
+    # the parameters moved: compare the largest tensors' updates with the oracle's (direction and size)
+    after = m.state_dict()
+    num = den = 0.0
+    for k in onet.trainable_names():
+        d_hip = (after[k].double().cpu() - state0[k].double())
+        d_ref = (state[k].double() - state0[k].double())
+        num += float(((d_hip - d_ref) ** 2).sum()); den += float((d_ref ** 2).sum())
+    print("   parameter update vs the oracle's: relative L2 %.2e" % ((num / den) ** 0.5))
+    assert (num / den) ** 0.5 <= (0.35 if storage == "bf16" else 0.15)          # off-pattern: a few ReLU bits differ (tests/test_gpu_parity.py)
