@@ -679,7 +679,10 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (PH >= 0 ? 1 : (p.cout + 16 * Q - 1) / (16 * Q)), p.n);
     const size_t smem = S::bytes(p.bn_cap);
-    static size_t configured = 0;
+    static size_t configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& configured = configured_by_device[dev & 15];
     if (smem > 48 * 1024 && smem > configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_dma_kernel<KS, KC, Q, IN, EPI, WX, R, NBUF, MINW, VEC, XF, EXP, PH, BF>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));

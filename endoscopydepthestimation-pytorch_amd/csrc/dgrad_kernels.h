@@ -229,7 +229,10 @@ inline int launch_dgrad_dense(ConvParams p, hipStream_t stream) {
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     const size_t smem = D::bytes(p.cout);
-    static size_t configured = 0;
+    static size_t configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& configured = configured_by_device[dev & 15];
     if (smem > 48 * 1024 && smem > configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_dense_kernel<WX, R>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(smem)));

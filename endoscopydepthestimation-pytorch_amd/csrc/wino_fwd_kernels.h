@@ -362,7 +362,10 @@ inline int launch_wino_fwd(ConvParams p, hipStream_t stream) {
     p.bn_cap = ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     const size_t smem = G::bytes(p.bn_cap);
-    static size_t configured = 0;
+    static size_t configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& configured = configured_by_device[dev & 15];
     if (smem > 48 * 1024 && smem > configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino_fwd_kernel<R, KC, MINW, NS, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(smem)));
