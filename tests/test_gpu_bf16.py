@@ -423,3 +423,33 @@ def test_16bit_training_step_against_oracle(storage, tol):
         num += float(((d_hip - d_ref) ** 2).sum()); den += float((d_ref ** 2).sum())
     print("   parameter update vs the oracle's: relative L2 %.2e" % ((num / den) ** 0.5))
     assert (num / den) ** 0.5 <= (0.35 if storage == "bf16" else 0.15)          # off-pattern: a few ReLU bits differ (tests/test_gpu_parity.py)
+
+
+def test_fp16_gradient_scale_is_invisible():
+    """Half storage: endo_net16h_bwd picks a power-of-two gradient scale from max |grad_output| and divides it out of the parameter
+    gradients.  Output gradients of 1e-9, 1 and 1e3 times the same tensor must give parameter gradients in the same ratios (without the
+    scale the first underflows to zero in half and the last overflows); bf16 storage has the range and needs no scale."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w = 1, 128, 160
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(41)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)).to(dev())
+    g = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)).to(dev())
+    grads = {}
+    for s in (1.0, 1.0e-9, 1.0e3):
+        m = ea.FCDenseNet57(1)
+        m.load_state_dict(state)
+        m = m.to(dev()).train()
+        y = m.forward_fp16_storage(x)
+        y.backward(g * s)
+        torch.cuda.synchronize()
+        grads[s] = {k: v.double() / s for k, v in _grads_by_name(m).items()}
+    ref = grads[1.0]
+    floor = 1e-3 * max(float(v.abs().max()) for v in ref.values())
+    for s in (1.0e-9, 1.0e3):
+        worst = max((float((grads[s][k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), floor), k) for k in ref)
+        print("fp16 storage, output gradient x %.0e: worst parameter-gradient tensor %s differs by %.2e of its largest entry" % (s, worst[1], worst[0]))
+        assert all(torch.isfinite(v).all() for v in grads[s].values())
+        assert worst[0] <= 2e-2, worst
