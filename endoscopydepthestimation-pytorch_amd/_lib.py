@@ -93,6 +93,8 @@ SIGNATURES = {
     "endo_jpeg_decode_crop": (_I, [_P, _L, ctypes.c_double, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
     "endo_point_brightness": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P]),
     "endo_prof_enable": (_I, [_I]),
+    "endo_prof_sample": (_I, [_I]),
+    "endo_prof_seen": (_I, [_I, ctypes.POINTER(_L)]),
     "endo_prof_read": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_L),
                             ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "endo_prof_family_name": (ctypes.c_char_p, [_I]),

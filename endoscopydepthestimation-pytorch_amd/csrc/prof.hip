@@ -16,10 +16,13 @@ struct ProfSlot {
 static std::mutex g_prof_mutex;
 static std::deque<ProfSlot> g_prof_slots;
 static unsigned g_prof_mask = 0;   // bit f set = time family f
+static int g_prof_period = 1;      // time one launch in g_prof_period of a family (endo_prof_sample)
+static int64_t g_prof_seen[ENDO_PROF_FAMILIES] = {};      // launches of an enabled family since endo_prof_enable, timed or not
 
 ProfScope::ProfScope(int family_, hipStream_t stream_, double flops, double bytes) : family(family_), stream(stream_), slot(nullptr) {
     if (!((g_prof_mask >> family_) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof_mutex);
+    if (family_ >= 0 && family_ < ENDO_PROF_FAMILIES && (g_prof_seen[family_]++ % g_prof_period) != 0) return;
     ProfSlot s;
     s.family = family_;
     s.flops = flops;
@@ -65,7 +68,22 @@ extern "C" const char* endo_error_string(int code) {
 extern "C" int endo_prof_enable(int family_mask) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     prof_clear();
+    for (auto& n : g_prof_seen) n = 0;
     g_prof_mask = static_cast<unsigned>(family_mask);
+    return 0;
+}
+
+extern "C" int endo_prof_sample(int period) {
+    if (period < 1) return ENDO_E_BADARG;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_period = period;
+    return 0;
+}
+
+extern "C" int endo_prof_seen(int family, int64_t* launches) {
+    if (family < 0 || family >= ENDO_PROF_FAMILIES || !launches) return ENDO_E_BADARG;
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    *launches = g_prof_seen[family];
     return 0;
 }
 

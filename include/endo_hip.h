@@ -38,7 +38,7 @@ extern "C" {
  * 3: round 3 -- kernel-form / precision options move from the process to the network handle: endo_net_set_option /
  * endo_net_get_option REPLACE endo_set_option and endo_set_wgrad_overlap (removed; no environment defaults any more);
  * adds endo_warp_consistency and endo_warp_fallback_blocks. */
-#define ENDO_ABI_VERSION 3
+#define ENDO_ABI_VERSION 4
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
 const char* endo_error_string(int code);
@@ -351,9 +351,15 @@ int endo_point_brightness(const uint8_t* imgs, int frames, int height, int width
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f
  * (0 = off, -1 = all); calling it also discards previously recorded events.  endo_prof_read
- * synchronises on the recorded events and returns totals (ms, launches, algorithmic flops/bytes). */
+ * synchronises on the recorded events and returns totals (ms, launches, algorithmic flops/bytes) of the TIMED launches.
+ * endo_prof_sample(period): time one launch in `period` of each enabled family (default 1 = every launch) -- two events around a
+ * launch on the caller's stream serialise it with its neighbours, and a family of 44 launches per step then costs the step 3 %; a
+ * period coprime with the family's launches per step visits every launch of the step in rotation.  endo_prof_seen: launches of
+ * an enabled family since endo_prof_enable, timed or not. */
 #define ENDO_PROF_FAMILIES 16
 int endo_prof_enable(int family_mask);
+int endo_prof_sample(int period);
+int endo_prof_seen(int family, int64_t* launches);
 int endo_prof_read(int family, double* total_ms, int64_t* launches, double* total_flops, double* total_bytes);
 const char* endo_prof_family_name(int family);
 
