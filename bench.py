@@ -227,7 +227,7 @@ def dispatches_per_step(config=1):
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_id import csrc_sha256
-    suffix = "_kernel_stats.json" if config in (1, 3, 5, 6) else "_kernel_stats_config%d.json" % config
+    suffix = "_kernel_stats.json" if config in (1, 3, 6) else "_kernel_stats_config%d.json" % (2 if config == 4 else config)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
         return {"value": None, "source": "no profiles/*" + suffix}
@@ -239,8 +239,10 @@ def dispatches_per_step(config=1):
         return {"value": None, "source": "unreadable: " + name}
     if (doc.get("source") or {}).get("csrc_sha256") != csrc_sha256():
         return {"value": None, "source": "stale: %s belongs to other kernel sources -- regenerate it with tools/final_profiles.sh" % name}
+    profiled = config in (1, 2)          # the trace is of configs[1] / configs[2]; the other configs launch the same kernels at other sizes
     return {"value": doc["dispatches_per_step"], "library_kernels": doc["library_kernel_dispatches_per_step"],
-            "kernel_time_ms_per_step": doc["kernel_time_ms_per_step"], "source": name}
+            "kernel_time_ms_per_step": doc["kernel_time_ms_per_step"] if profiled else None,
+            "source": name if profiled else name + " (the same launches; that trace's sizes)"}
 
 
 def pmc_traffic(family, config=1):
