@@ -49,57 +49,69 @@ __global__ void __launch_bounds__(1024) s16_grad_scale_kernel(const float* __res
 }
 
 // ---- final 1 x 1 + |.| backward (reference models.py:167, 186): du[c] = g * sign(pre) * w[c] for all 192 channels (first writer of the
-// level-0 gradient buffer); grad_w[c] += sum g * sign(pre) * u[c]; grad_b += sum g * sign(pre).  8 lanes per pixel, 24 channels each.
+// level-0 gradient buffer); grad_w[c] += sum g * sign(pre) * u[c]; grad_b += sum g * sign(pre).  A lane owns one 16-byte unit (8 channels)
+// of a pixel record and walks the 6 channel blocks: a wave's access is 16 pixels x 64 bytes = 1 KiB contiguous per block, read and write.
+// (8 lanes per pixel with 24 channels each -- three 16-byte pieces in different blocks per lane -- ran at 2.4 TB/s.)
 __global__ void __launch_bounds__(256) bf16_final_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                              const uint16_t* __restrict__ u, uint16_t* __restrict__ du, int64_t ns, int plane,
                                                              const float* __restrict__ w, int rot, int rot_n, float* __restrict__ grad_w,
                                                              float* __restrict__ grad_b, double* __restrict__ gsum, const float* __restrict__ gscale) {
-    __shared__ float s_part[4][8][25];
+    constexpr int kBlocks = 192 / 32;
+    __shared__ float s_part[4][4][kBlocks * 8 + 1];
     const int n = blockIdx.y;
-    const int sub = threadIdx.x & 7;
-    float wv[24], gw[24];
+    const int part = threadIdx.x & 3;
+    float wv[kBlocks][8], gw[kBlocks][8];
     float gb = 0.f;
     const float S = gscale ? gscale[0] : 1.f;          // what is written to the gradient buffer carries S; the parameter gradients here do not
 #pragma unroll
-    for (int k = 0; k < 24; ++k) { wv[k] = w[rot_index(sub * 24 + k, rot, rot_n)]; gw[k] = 0.f; }
-    for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; px < plane; px += (gridDim.x * blockDim.x) >> 3) {
+    for (int cb = 0; cb < kBlocks; ++cb)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { wv[cb][k] = S * w[rot_index(cb * 32 + part * 8 + k, rot, rot_n)]; gw[cb][k] = 0.f; }
+    for (int px = (blockIdx.x * blockDim.x + threadIdx.x) >> 2; px < plane; px += (gridDim.x * blockDim.x) >> 2) {
         const float z = pre[static_cast<int64_t>(n) * plane + px];
         const float gs = gout[static_cast<int64_t>(n) * plane + px] * (z > 0.f ? 1.f : (z < 0.f ? -1.f : 0.f));
-        gb += gs;
+        if (part == 0) gb += gs;
+        u32x4_t v[kBlocks];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int c0 = sub * 24 + 8 * j;
-            const int64_t off = n * ns + (static_cast<int64_t>(c0 >> 5) * plane + px) * 32 + (c0 & 31);
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(u + off);
+        for (int cb = 0; cb < kBlocks; ++cb)
+            v[cb] = *reinterpret_cast<const u32x4_t*>(u + n * ns + (static_cast<int64_t>(cb) * plane + px) * 32 + part * 8);
+#pragma unroll
+        for (int cb = 0; cb < kBlocks; ++cb) {
             u32x4_t o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                gw[8 * j + 2 * k] = fmaf(gs, s16_lo(v[k]), gw[8 * j + 2 * k]);
-                gw[8 * j + 2 * k + 1] = fmaf(gs, s16_hi(v[k]), gw[8 * j + 2 * k + 1]);
-                o[k] = pack_s16x2(gs * S * wv[8 * j + 2 * k], gs * S * wv[8 * j + 2 * k + 1]);
+                gw[cb][2 * k] = fmaf(gs, s16_lo(v[cb][k]), gw[cb][2 * k]);
+                gw[cb][2 * k + 1] = fmaf(gs, s16_hi(v[cb][k]), gw[cb][2 * k + 1]);
+                o[k] = pack_s16x2(gs * wv[cb][2 * k], gs * wv[cb][2 * k + 1]);
             }
-            *reinterpret_cast<u32x4_t*>(du + off) = o;
+            *reinterpret_cast<u32x4_t*>(du + n * ns + (static_cast<int64_t>(cb) * plane + px) * 32 + part * 8) = o;
         }
     }
-    // lanes with the same sub: 8 per wave (lane bits 3..5), then the 4 waves through LDS
+    // lanes with the same part: 16 per wave (lane bits 2..5), then the 4 waves through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
-        gw[k] += __shfl_xor(gw[k], 8, 64); gw[k] += __shfl_xor(gw[k], 16, 64); gw[k] += __shfl_xor(gw[k], 32, 64);
-    }
-    gb += __shfl_xor(gb, 8, 64); gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
-    if (lane < 8) {
+    for (int cb = 0; cb < kBlocks; ++cb)
 #pragma unroll
-        for (int k = 0; k < 24; ++k) s_part[wave][sub][k] = gw[k];
-        s_part[wave][sub][24] = gb;
+        for (int k = 0; k < 8; ++k) {
+            float t = gw[cb][k];
+            t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64); t += __shfl_xor(t, 16, 64); t += __shfl_xor(t, 32, 64);
+            gw[cb][k] = t;
+        }
+    gb += __shfl_xor(gb, 4, 64); gb += __shfl_xor(gb, 8, 64); gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+    if (lane < 4) {
+#pragma unroll
+        for (int cb = 0; cb < kBlocks; ++cb)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_part[wave][part][cb * 8 + k] = gw[cb][k];
+        s_part[wave][part][kBlocks * 8] = gb;
     }
     __syncthreads();
-    const float gb_block = s_part[0][0][24] + s_part[1][0][24] + s_part[2][0][24] + s_part[3][0][24];
+    const float gb_block = s_part[0][0][kBlocks * 8] + s_part[1][0][kBlocks * 8] + s_part[2][0][kBlocks * 8] + s_part[3][0][kBlocks * 8];
     if (threadIdx.x < 192) {
-        const int s = threadIdx.x / 24, k = threadIdx.x - 24 * s;
-        atomicAdd(grad_w + rot_index(threadIdx.x, rot, rot_n), s_part[0][s][k] + s_part[1][s][k] + s_part[2][s][k] + s_part[3][s][k]);
+        const int c = threadIdx.x, e = (c >> 5) * 8 + (c & 7), pt = (c & 31) >> 3;
+        atomicAdd(grad_w + rot_index(c, rot, rot_n), s_part[0][pt][e] + s_part[1][pt][e] + s_part[2][pt][e] + s_part[3][pt][e]);
         // sum over pixels of what this kernel writes into channel c of the gradient buffer (see bf16_prep_dy_kernel)
-        atomicAdd(gsum + 2 * threadIdx.x, static_cast<double>(w[rot_index(threadIdx.x, rot, rot_n)]) * static_cast<double>(gb_block) * static_cast<double>(S));
+        atomicAdd(gsum + 2 * c, static_cast<double>(w[rot_index(c, rot, rot_n)]) * static_cast<double>(gb_block) * static_cast<double>(S));
     }
     if (threadIdx.x == 192) atomicAdd(grad_b, gb_block);
 }

@@ -597,7 +597,10 @@ inline int launch_conv(ConvParams p, hipStream_t stream) {
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
     dim3 grid(p.tiles_x * tiles_y, (p.cout + 16 * Q - 1) / (16 * Q), p.n);
     constexpr size_t smem = conv_smem_bytes<KS, KC, Q, WX, R>();
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured && smem > 48 * 1024) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<KS, KC, Q, IN, EPI, WX, R>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));

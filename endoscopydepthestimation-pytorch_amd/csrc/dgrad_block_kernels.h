@@ -414,7 +414,10 @@ inline int launch_dgrad_block(DgradBlockParams p, hipStream_t stream) {
     using G = DgradBlockGeom<NL, WX, R, GP, VEC>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured && G::kBytes > 48 * 1024) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block_kernel<NL, WX, R, GP, EXP, PIPE, VEC, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
@@ -667,7 +670,10 @@ inline int launch_dgrad_block8(DgradBlockParams p, hipStream_t stream) {
     using G = DgradBlock8Geom<NL>;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_block8_kernel<NL, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));

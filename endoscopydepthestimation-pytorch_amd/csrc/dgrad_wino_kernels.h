@@ -340,7 +340,10 @@ inline int launch_dgrad_wino8(DgradBlockParams p, const float* const (&u)[4], hi
     using G = DgradWino8Geom<NL>;
     p.tiles_x = p.w / G::kTileX;
     const int tiles_y = p.h / G::kTileY;
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(dgrad_wino8_kernel<NL, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));

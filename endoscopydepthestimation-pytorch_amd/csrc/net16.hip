@@ -801,7 +801,7 @@ extern "C" int N16(bwd)(endo_net16* net, const float* params, const void* tape_,
 #endif
     {
         const auto& lv = net->lv[0];
-        int bx = static_cast<int>((lv.plane * 8 + 255) / 256);
+        int bx = static_cast<int>((lv.plane * 4 + 255) / 256);          // 4 lanes per pixel
         bx = bx > 512 ? 512 : bx;
         bf16_final_bwd_kernel<<<dim3(bx, net->n), 256, 0, stream>>>(grad_out, reinterpret_cast<const float*>(c.tape + net->pre_off), c.act(0), c.dbuf(0),
                                                                     lv.plane * lv.t, static_cast<int>(lv.plane), params + tb.final_.w, tb.final_.rot,

@@ -199,7 +199,10 @@ inline int launch_wgrad1x1_dma(const WgradParams& p, hipStream_t stream) {
     int splits = 512 / (tiles_co * tiles_ci);          // 2 blocks per CU (LDS)
     if (splits < 1) splits = 1;
     if (splits > chunks_total) splits = chunks_total;
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad1x1_dma_kernel<BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(kP1Bytes)));

@@ -288,7 +288,10 @@ inline int launch_wgrad(const WgradParams& p, hipStream_t stream) {
     if (groups > tiles_total) groups = tiles_total;
     dim3 grid(ci_chunks, groups, co_sets);
     constexpr size_t smem = wgrad_smem_bytes<KS, Q>();
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured && smem > 48 * 1024) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_mfma_kernel<KS, Q, IN, DY>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));

@@ -259,7 +259,10 @@ inline int launch_wgrad_taps(WgradParams p, hipStream_t stream) {
     if (groups < 1) groups = 1;
     if (groups > tiles_total) groups = tiles_total;
     if (groups >= 16) groups &= ~7;            // multiple of 8: enables the XCD-local block order
-    static bool configured = false;
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& configured = configured_by_device[dev & 15];
     if (!configured && G::kBytes > 48 * 1024) {
         ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_taps_kernel<COUT, IN, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(G::kBytes)));
