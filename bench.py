@@ -219,26 +219,44 @@ def cpu_baseline(cfg):
             "ms_per_step": full["ms_per_step"], "timed_iterations": full["iterations"], "batch": cfg["batch"], "batch1_by_threads": sweep}
 
 
-def dispatches_per_step(config=1):
-    """Kernel dispatches per training step, from the newest rocprofv3 kernel-trace summary under profiles/ (tools/summarize_rocprof.py
-    writes `*_kernel_stats.json` next to the table) -- counted by the profiler, not estimated, and tied to the kernel sources by their
-    hash: a summary of another revision is refused (None + the reason).  In-process counting was tried and dropped: this stack's
-    CUDAGraph.debug_dump writes nothing and torch.profiler sees 175 of the ~600 dispatches (tests/diag/dispatch_count_probe.py)."""
+def _summary_of_this_tree(suffix):
+    """The profiles/*<suffix> summary measured on the kernel sources this process runs (their sha256, tools/source_id.py): (doc, name),
+    or (None, reason).  Summaries of other revisions stay in profiles/ as history, so the choice is by hash, not by file name."""
     import glob
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from source_id import csrc_sha256
-    suffix = "_kernel_stats.json" if config in (1, 3, 6) else "_kernel_stats_config%d.json" % (2 if config == 4 else config)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
     if not files:
-        return {"value": None, "source": "no profiles/*" + suffix}
-    name = "profiles/" + os.path.basename(files[-1])
-    try:
-        with open(files[-1]) as fh:
-            doc = json.load(fh)
-    except (OSError, ValueError):
-        return {"value": None, "source": "unreadable: " + name}
-    if (doc.get("source") or {}).get("csrc_sha256") != csrc_sha256():
-        return {"value": None, "source": "stale: %s belongs to other kernel sources -- regenerate it with tools/final_profiles.sh" % name}
+        return None, "no profiles/*" + suffix
+    running = csrc_sha256()
+    last_seen = None
+    for path in reversed(files):
+        name = "profiles/" + os.path.basename(path)
+        try:
+            with open(path) as fh:
+                doc = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        measured_on = (doc.get("source") or {}).get("csrc_sha256")
+        if measured_on == running:
+            return doc, name
+        if last_seen is None:
+            last_seen = (name, measured_on)
+    if last_seen is None:
+        return None, "unreadable: profiles/*" + suffix
+    return None, "stale: %s was measured on kernel sources %s, this tree is %s -- regenerate it with tools/final_profiles.sh" % (
+        last_seen[0], (last_seen[1] or "of an unrecorded revision")[:12], running[:12])
+
+
+def dispatches_per_step(config=1):
+    """Kernel dispatches per training step, from the rocprofv3 kernel-trace summary under profiles/ that was taken on this tree's kernel sources (tools/summarize_rocprof.py
+    writes `*_kernel_stats.json` next to the table) -- counted by the profiler, not estimated, and tied to the kernel sources by their
+    hash: a summary of another revision is refused (None + the reason).  In-process counting was tried and dropped: this stack's
+    CUDAGraph.debug_dump writes nothing and torch.profiler sees 175 of the ~600 dispatches (tests/diag/dispatch_count_probe.py)."""
+    suffix = "_kernel_stats.json" if config in (1, 3, 6) else "_kernel_stats_config%d.json" % (2 if config == 4 else config)
+    doc, name = _summary_of_this_tree(suffix)
+    if doc is None:
+        return {"value": None, "source": name}
     profiled = config in (1, 2)          # the trace is of configs[1] / configs[2]; the other configs launch the same kernels at other sizes
     return {"value": doc["dispatches_per_step"], "library_kernels": doc["library_kernel_dispatches_per_step"],
             "kernel_time_ms_per_step": doc["kernel_time_ms_per_step"] if profiled else None,
@@ -246,30 +264,15 @@ def dispatches_per_step(config=1):
 
 
 def pmc_traffic(family, config=1):
-    """HBM bytes per step of `family`, from the newest committed rocprofv3 --pmc summary under profiles/ (a PMC pass
+    """HBM bytes per step of `family`, from the committed rocprofv3 --pmc summary under profiles/ taken on this tree's kernel sources (a PMC pass
     serialises the kernels, so it cannot be taken inside the timed run; tools/pmc_traffic.py makes the file from the same
     bench.py command; `*_pmc_traffic.json` for configs[1], `*_pmc_traffic_config<k>.json` otherwise).  The file records the
     sha256 of the kernel sources it was measured on (tools/source_id.py): when that is not the tree this process runs, the
     traffic is reported as None with the reason instead of stale bytes.  Returns (bytes per step or None, source / reason)."""
-    import glob
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from source_id import csrc_sha256
     suffix = "_pmc_traffic.json" if config == 1 else "_pmc_traffic_config%d.json" % config
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*" + suffix)))
-    if not files:
-        return None, "no profiles/*%s" % suffix
-    path = files[-1]
-    name = "profiles/" + os.path.basename(path)
-    try:
-        with open(path) as fh:
-            doc = json.load(fh)
-    except (OSError, ValueError):
-        return None, "unreadable: " + name
-    measured_on = (doc.get("source") or {}).get("csrc_sha256")
-    running = csrc_sha256()
-    if measured_on != running:
-        return None, "stale: %s was measured on kernel sources %s, this tree is %s -- regenerate it with tools/final_profiles.sh" % (
-            name, (measured_on or "of an unrecorded revision")[:12], running[:12])
+    doc, name = _summary_of_this_tree(suffix)
+    if doc is None:
+        return None, name
     entry = doc.get("families", {}).get(family)
     if not entry:
         return None, "%s has no family %s" % (name, family)
