@@ -193,12 +193,12 @@ __device__ __forceinline__ int bf_slot(int row, int x, int part) { return ((row 
 // tile order, statistics flushed once per block) was built and measured: no faster at equal occupancy and 60 registers over the
 // 128-register budget of two 8-wave blocks per CU (profiles/r03_o_bf16_conv_variants.txt); not kept.
 // EXP: diagnostic masks of tools/bf16_conv_variants (1 = no matrix phase, 2 = no activation loads, 4 = no BatchNorm arithmetic and LDS stage writes); 0 in the product
-template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0>
+template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0, int TY = kBfTileY>
 __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu(WPE))) bf16_conv_kernel(const Conv16Params p) {
     constexpr int kThreads = 64 * WAVES;
-    constexpr int R = kBfTileY / WAVES;
+    constexpr int R = TY / WAVES;          // TY = tile rows (16; 8 for the 4-wave data-gradient blocks that share a CU with a weight-gradient block)
     constexpr int kHalo = KS / 2;
-    constexpr int kRows = kBfTileY + 2 * kHalo, kCols = kBfTileX + 2 * kHalo;
+    constexpr int kRows = TY + 2 * kHalo, kCols = kBfTileX + 2 * kHalo;
     constexpr int kPix = kRows * kCols;
     constexpr int kUnits = kPix * 4;                                   // 16-byte units of a chunk
     constexpr int kIter = (kUnits + kThreads - 1) / kThreads;
@@ -215,7 +215,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
-    const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX, tiles_y = (p.h + kBfTileY - 1) / kBfTileY;
+    const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX, tiles_y = (p.h + TY - 1) / TY;
     const int tiles_img = tiles_x * tiles_y;
     const int co_base = blockIdx.y * NT * 16;
     const int nchunks = (p.cin + kBfKC - 1) / kBfKC;
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
 
     __syncthreads();          // s_bn
     const int n = blockIdx.z;
-    const int y0 = (blockIdx.x / tiles_x) * kBfTileY, x0 = (blockIdx.x % tiles_x) * kBfTileX;
+    const int y0 = (blockIdx.x / tiles_x) * TY, x0 = (blockIdx.x % tiles_x) * kBfTileX;
     tile_offsets(y0, x0, u_off);
     issue_loads(0, n, u_off);
     {
@@ -641,28 +641,28 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
     }
 }
 
-template <int KS, int NT, int WAVES>
+template <int KS, int NT, int WAVES, int TY = kBfTileY>
 inline size_t bf16_conv_smem(int cin) {
     constexpr int kHalo = KS / 2;
-    constexpr int kPix = (kBfTileY + 2 * kHalo) * (kBfTileX + 2 * kHalo);
+    constexpr int kPix = (TY + 2 * kHalo) * (kBfTileX + 2 * kHalo);
     const int cpad = (cin + kBfKC - 1) / kBfKC * kBfKC;
     const size_t bn = sizeof(float) * 2 * (cpad > NT * 16 ? cpad : NT * 16), red = sizeof(float) * WAVES * NT * 16 * 2;
     return static_cast<size_t>(kPix) * 64 + static_cast<size_t>(KS * KS * NT) * 16 * 64 + bn + red;
 }
 
-template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0>
+template <int KS, int NT, int EPI = 0, int WAVES = 8, int WPE = 4, int EXP = 0, int UNPOOL = 0, int TY = kBfTileY>
 inline int launch_bf16_conv(const Conv16Params& p_, hipStream_t stream) {
     Conv16Params p = p_;
     if (p.in_blk <= 0) p.in_blk = p.in_t;
     if (p.out_blk <= 0) p.out_blk = p.out_t;
     constexpr bool QUADS = EPI == kEpiDgradBn && UNPOOL == 0;
     if ((p.in_blk & 7) || (p.out_blk & 3) || (p.ic0 & (QUADS ? 3 : 7)) || (p.oc0 & 3) || p.in_t % p.in_blk || p.out_t % p.out_blk) return ENDO_E_BADARG;
-    const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kBfTileY - 1) / kBfTileY);
+    const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + TY - 1) / TY);
     const int ngroups = (p.cout + NT * 16 - 1) / (NT * 16);
-    const size_t smem = bf16_conv_smem<KS, NT, WAVES>(p.cin);
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    const size_t smem = bf16_conv_smem<KS, NT, WAVES, TY>(p.cin);
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL, TY>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    static_cast<int>(smem)));
-    bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL><<<dim3(tiles, ngroups, p.n), 64 * WAVES, smem, stream>>>(p);
+    bf16_conv_kernel<KS, NT, EPI, WAVES, WPE, EXP, UNPOOL, TY><<<dim3(tiles, ngroups, p.n), 64 * WAVES, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

@@ -663,7 +663,7 @@ int dense_bwd16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const C
     p.oc0 = c0; p.cout = k16Growth * j; p.co_off = c0; p.grp0 = c0 / 48; p.wgroups = (cv.cin + 47) / 48;
     {
         ProfScope prof(kProfDgradDense, c.stream, 2.0 * px * p.cout * cv.cout * 9, px * (6.0 * p.cout + 2.0 * cv.cout));
-        rc = launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2>(p, c.stream);
+        rc = launch_bf16_conv<3, 3, kEpiDgradBn, 4, 1, 0, 0, 8>(p, c.stream);          // 4-wave blocks over 8-row tiles: one fits a CU beside a weight-gradient block
     }
     if (rc) return rc;
     return bn_finalize16(c, b, cv, level, c0, k16Growth * j);

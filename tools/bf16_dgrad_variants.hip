@@ -1,5 +1,5 @@
 // What a new-map data-gradient pass of the bf16-storage family is made of (development tool, not part of the product): times
-// bf16_conv_kernel<3, 3, kEpiDgradBn, 8, 2> -- the per-layer data gradient with respect to a dense block's new maps -- with parts of it
+// bf16_conv_kernel<3, 3, kEpiDgradBn, 4, 1, 0, 0, 8> -- the per-layer data gradient with respect to a dense block's new maps -- with parts of it
 // switched off (tools/make_conv_diag.py adds the masks to a copy of the kernel header).
 //   python tools/make_conv_diag.py
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/bf16_dgrad_variants.hip -o tools/bin/bf16_dgrad_variants
@@ -63,7 +63,8 @@ int main(int argc, char** argv) {
     p.out_sums = sums; p.co_off = c0; p.grp0 = c0 / 48; p.wgroups = wgroups; p.sr_salt = 12345u;
 
     std::vector<Variant> vs;
-#define V(name, exp) vs.push_back({name, [&](hipStream_t s) { return launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2, exp>(p, s); }})
+#define V(name, exp) vs.push_back({name, [&](hipStream_t s) { return launch_bf16_conv<3, 3, kEpiDgradBn, 4, 1, exp, 0, 8>(p, s); }})
+    vs.push_back({"8-wave blocks over 16-row tiles (until r03_ad)", [&](hipStream_t s) { return launch_bf16_conv<3, 3, kEpiDgradBn, 8, 2, 0>(p, s); }});
     V("product", 0);
     V("no matrix phase", 1);
     V("no input-tile loads", 2);
