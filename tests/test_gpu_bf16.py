@@ -453,3 +453,40 @@ def test_fp16_gradient_scale_is_invisible():
         print("fp16 storage, output gradient x %.0e: worst parameter-gradient tensor %s differs by %.2e of its largest entry" % (s, worst[1], worst[0]))
         assert all(torch.isfinite(v).all() for v in grads[s].values())
         assert worst[0] <= 2e-2, worst
+
+
+@pytest.mark.parametrize("storage,tol,min_cos", [("bf16", 2e-2, 0.85), ("fp16", 4e-3, 0.98)])
+def test_16bit_training_step_at_512x640_tracks_fp32(storage, tol, min_cos):
+    """BASELINE configs[3]'s shape (512 x 640, network_downsampling 64) through the 16-bit-storage modes: 40 x 20 tiles at level 0, the
+    8-row tiles of the new-map data-gradient blocks down to a 16 x 20 level.  No oracle at this size: the check is against this library's
+    own fp32 training step on the same model and batch (itself pinned to the oracle at 512 x 640 in tests/test_gpu_parity.py), on the
+    oracle's synthetic state: the loss and its terms (measured 8.3e-3 / 1.9e-3 relative) and the DIRECTION of the parameter gradient
+    (cosine 0.910 / 0.996).  Not its norm: off the forward pass's own ReLU pattern, and with predictions that differ in the third digit,
+    the norm of this loss's gradient is carried by a few badly conditioned terms of the loss head (22.6 / 51.0 against 60.8 here; the fp32
+    norm itself goes from 1.1 to 1080 across the sizes of tests/diag/bf16_vs_fp32_state_sizes.py) -- the kernels' own gradient accuracy is
+    what the on-pattern tests above pin.  (bench.py's Kaiming-initialised model is a throughput workload, not a numerics one: its fp32
+    loss moves from 3.10 to 2.24 when the input images alone are rounded to bf16, tests/diag/kaiming_conditioning.py.)"""
+    import sys, os, copy
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w = 2, 512, 640
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(7), 8))
+    m32 = ea.FCDenseNet57(1)
+    m32.load_state_dict(state)
+    m16 = copy.deepcopy(m32)
+    m32, m16 = m32.to(dev()).train(), m16.to(dev()).train()
+    batch = {k: v.to(dev()) for k, v in ea.synthetic.make_batch(n, h, w, seed=11).items()}
+    ref = ea.train_step.TrainingStep(m32, ea.optim.FusedClipSGD(m32, lr=1.0e-3), h, w)(batch, lr=1.0e-3)
+    out = ea.train_step.TrainingStep(m16, ea.optim.FusedClipSGD(m16, lr=1.0e-3), h, w, bf16_storage=(storage == "bf16"),
+                                     fp16_storage=(storage == "fp16"))(batch, lr=1.0e-3)
+    torch.cuda.synchronize()
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    g16, g32 = m16._flat_grad.double(), m32._flat_grad.double()          # (clipped: a positive multiple of the gradient)
+    cos = float((g16 * g32).sum() / (g16.norm() * g32.norm()))
+    print("%s storage at 512 x 640: loss %.6f (fp32 %.6f, rel %.1e), sfl rel %.1e, dcl rel %.1e, gradient cosine %.4f, norm %.4f (fp32 %.4f)" % (
+        storage, out["loss"], ref["loss"], rel(out["loss"], ref["loss"]), rel(out["sfl"], ref["sfl"]), rel(out["dcl"], ref["dcl"]), cos,
+        float(out["grad_norm"]), float(ref["grad_norm"])))
+    assert not out["skipped"] and not ref["skipped"]
+    assert rel(out["loss"], ref["loss"]) <= tol
+    assert rel(out["sfl"], ref["sfl"]) <= tol and rel(out["dcl"], ref["dcl"]) <= tol
+    assert cos >= min_cos
