@@ -490,3 +490,32 @@ def test_16bit_training_step_at_512x640_tracks_fp32(storage, tol, min_cos):
     assert rel(out["loss"], ref["loss"]) <= tol
     assert rel(out["sfl"], ref["sfl"]) <= tol and rel(out["dcl"], ref["dcl"]) <= tol
     assert cos >= min_cos
+
+
+def test_prof_sampling_times_one_launch_in_n():
+    """endo_prof_sample(period): with a family enabled, every launch is counted (endo_prof_seen) and one in `period` is timed
+    (endo_prof_read's launch count), starting with the first; period 1 times them all.  What bench.py's 16-bit lines rely on."""
+    lib = ea._lib.load()
+    m = ea.FCDenseNet57(1).to(dev()).eval()
+    x = torch.rand(1, 3, 64, 96, device=dev())
+    fam = 0                                           # dense-layer 3 x 3 forward: 44 launches per forward pass
+    counts = {}
+    try:
+        for period in (1, 7):
+            assert lib.endo_prof_sample(period) == 0
+            lib.endo_prof_enable(1 << fam)
+            with torch.no_grad():
+                m.forward_bf16_storage(x)
+            torch.cuda.synchronize()
+            ms, timed, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
+            assert lib.endo_prof_read(fam, ctypes.byref(ms), ctypes.byref(timed), ctypes.byref(fl), ctypes.byref(by)) == 0
+            seen = ctypes.c_int64()
+            assert lib.endo_prof_seen(fam, ctypes.byref(seen)) == 0
+            counts[period] = (seen.value, timed.value, ms.value)
+        assert lib.endo_prof_sample(0) != 0               # a period below 1 is refused
+    finally:
+        lib.endo_prof_enable(0)
+        lib.endo_prof_sample(1)
+    print("launches seen / timed:", counts)
+    assert counts[1][0] == counts[1][1] > 0 and counts[1][2] > 0.0
+    assert counts[7][0] == counts[1][0] and counts[7][1] == (counts[7][0] + 6) // 7 and counts[7][2] > 0.0
