@@ -27,7 +27,9 @@ inline namespace ENDO16_NS {
 
 constexpr int kDbLayers = 4;
 constexpr int kDbPitch = 112;                        // bytes per staged pixel
-constexpr int kDbRows = kBfTileY + 2, kDbCols = kBfTileX + 2;
+constexpr int kDbWaves = 4;                           // 4-wave blocks over 8-row tiles: one wave per SIMD, so a block fits a CU beside a weight-gradient block
+constexpr int kDbTileY = 2 * kDbWaves, kDbThreads = 64 * kDbWaves;
+constexpr int kDbRows = kDbTileY + 2, kDbCols = kBfTileX + 2;
 constexpr int kDbWBytes = 9 * 3 * 16 * 64;           // one layer's weights of a 48-row group
 
 struct DgradBlock16Params {
@@ -49,25 +51,25 @@ struct DgradBlock16Params {
     int64_t gs_saved, gs_sums;
 };
 
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) bf16_dgrad_block_kernel(const DgradBlock16Params p) {
+__global__ void __launch_bounds__(kDbThreads) __attribute__((amdgpu_waves_per_eu(2))) bf16_dgrad_block_kernel(const DgradBlock16Params p) {
     constexpr int R = 2, NT = 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_db[];
-    unsigned char* s_g = smem_db;                                             // [18][34][7 slots][16 B]
-    unsigned char* s_w = s_g + kDbRows * kDbCols * kDbPitch;                  // [2][tap][nt][16 rows][4 slots][16 B]
-    float* s_bn = reinterpret_cast<float*>(s_w + 2 * kDbWBytes);              // [4 layers][48][2] (scale, shift)
-    float* s_red = s_bn + kDbLayers * 48 * 2;                                 // [2][8 waves][48][2]
+    unsigned char* s_g = smem_db;                                             // [10][34][7 slots][16 B]
+    unsigned char* s_w = s_g + kDbRows * kDbCols * kDbPitch;                  // [tap][nt][16 rows][4 slots][16 B]: ONE layer (a second buffer would not fit beside the weight gradient's 74 KB)
+    float* s_bn = reinterpret_cast<float*>(s_w + kDbWBytes);                  // [4 layers][48][2] (scale, shift)
+    float* s_red = s_bn + kDbLayers * 48 * 2;                                 // [2][waves][48][2]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lk = lane >> 4;
     const int tiles_x = (p.w + kBfTileX - 1) / kBfTileX;
-    const int y0 = (blockIdx.x / tiles_x) * kBfTileY, x0 = (blockIdx.x % tiles_x) * kBfTileX;
+    const int y0 = (blockIdx.x / tiles_x) * kDbTileY, x0 = (blockIdx.x % tiles_x) * kBfTileX;
     const int n = blockIdx.z;
     const int co_base = blockIdx.y * 48;
     const int64_t plane = static_cast<int64_t>(p.h) * p.w;
     const int grp = p.group_n > 0 ? n / p.group_n : 0;
 
-    for (int e = tid; e < kDbLayers * 48; e += 512) {
+    for (int e = tid; e < kDbLayers * 48; e += kDbThreads) {
         const int j = e / 48, c = e - 48 * j;
         const int ci = co_base + c;
         const int pc = ci < p.rot_n ? (ci + p.rot < p.rot_n ? ci + p.rot : ci + p.rot - p.rot_n) : ci;
@@ -79,11 +81,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
     {
         const uint16_t* g_n = p.g + n * p.ns;
         // all of a thread's loads first, then its LDS writes (a load -> store loop would pay the memory latency once per unit)
-        constexpr int kGUnits = kDbRows * kDbCols * 6, kGIter = (kGUnits + 511) / 512;
+        constexpr int kGUnits = kDbRows * kDbCols * 6, kGIter = (kGUnits + kDbThreads - 1) / kDbThreads;
         u32x4_t gv[kGIter];
 #pragma unroll
         for (int i = 0; i < kGIter; ++i) {
-            const int u = tid + i * 512;
+            const int u = tid + i * kDbThreads;
             const int px = u / 6, unit = u - 6 * px;
             const int ry = px / kDbCols, rx = px - ry * kDbCols;
             const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
@@ -95,25 +97,25 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
         }
 #pragma unroll
         for (int i = 0; i < kGIter; ++i) {
-            const int u = tid + i * 512;
+            const int u = tid + i * kDbThreads;
             const int px = u / 6, unit = u - 6 * px;
             if (u < kGUnits) *reinterpret_cast<u32x4_t*>(s_g + px * kDbPitch + unit * 16) = gv[i];
         }
     }
     // weights of a layer: the group's 27 KB are stored in global memory as the LDS image ([tap][nt][16 rows][4 slots], slot = k / 8
-    // XOR (row >> 1) & 3: bf16_all_weights_kernel) and copied by LDS-DMA, 1 KB per wave instruction, 27 of them dealt to the 8 waves
+    // XOR (row >> 1) & 3: bf16_all_weights_kernel) and copied by LDS-DMA, 1 KB per wave instruction, 27 of them dealt to the waves
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    auto dma_w = [&](int j, int buf) {
+    auto dma_w = [&](int j) {
         const unsigned char* src = reinterpret_cast<const unsigned char*>(p.wgt[j]) + static_cast<int64_t>(blockIdx.y) * kDbWBytes + lane * 16;
-        unsigned char* dst = s_w + buf * kDbWBytes;
+        unsigned char* dst = s_w;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int chunk = wave + 8 * k;
+        for (int k = 0; k < (kDbWBytes / 1024 + kDbWaves - 1) / kDbWaves; ++k) {
+            const int chunk = wave + kDbWaves * k;
             if (chunk < kDbWBytes / 1024) __builtin_amdgcn_global_load_lds((gptr_t)(src + chunk * 1024), (lptr_t)(dst + chunk * 1024), 16, 0, 0);
         }
     };
-    dma_w(0, 0);
+    dma_w(0);
 
     // ---- the lane's outputs: rows R wave + r, columns 16 hh + li, channels co_base + 16 t + 4 lk .. + 3; forward values read once ----
     const uint16_t* x_n = p.x + n * p.ns;
@@ -154,14 +156,13 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
         __builtin_amdgcn_s_waitcnt(0x0070);          // this wave's DMA of layer j's weights (vmcnt 0) and its LDS writes
         __syncthreads();          // weights of layer j (and, the first time, the tile and the BN table) are in LDS; s_red[(j + 1) & 1] is free
         if (j > 0 && tid < 96) {          // the sums of layer j - 1, written before the barrier
-            const float* red = s_red + ((j - 1) & 1) * 8 * 96;
+            const float* red = s_red + ((j - 1) & 1) * kDbWaves * 96;
             double tsum = 0.0;
-            for (int wv = 0; wv < 8; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
+            for (int wv = 0; wv < kDbWaves; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
             atomicAdd(p.sums[j - 1] + grp * p.gs_sums + 2 * co_base + tid, tsum);
         }
-        if (j + 1 < kDbLayers) dma_w(j + 1, (j + 1) & 1);
         const int u0 = j < 2 ? 0 : 2;
-        const unsigned char* wj = s_w + (j & 1) * kDbWBytes;
+        const unsigned char* wj = s_w;
         f32x4_t acc[R][2][NT];
 #pragma unroll
         for (int r = 0; r < R; ++r)
@@ -188,6 +189,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
                         for (int t = 0; t < NT; ++t) acc[r][hh][t] = S16_MFMA(a[t], b, acc[r][hh][t], 0, 0, 0);
                     }
             }
+        // every wave has read layer j's weights: the next layer's arrive while this one's BatchNorm / ReLU backward runs
+        __syncthreads();
+        if (j + 1 < kDbLayers) dma_w(j + 1);
         // ---- layer j's BatchNorm / ReLU backward on its share ----
         float s1[NT][4], s2[NT][4];
 #pragma unroll
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
                     }
                 }
         }
-        float* red = s_red + (j & 1) * 8 * 96;
+        float* red = s_red + (j & 1) * kDbWaves * 96;
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -226,9 +230,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
     }
     __syncthreads();
     if (tid < 96) {
-        const float* red = s_red + ((kDbLayers - 1) & 1) * 8 * 96;
+        const float* red = s_red + ((kDbLayers - 1) & 1) * kDbWaves * 96;
         double tsum = 0.0;
-        for (int wv = 0; wv < 8; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
+        for (int wv = 0; wv < kDbWaves; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
         atomicAdd(p.sums[kDbLayers - 1] + grp * p.gs_sums + 2 * co_base + tid, tsum);
     }
     // ---- one read-modify-write of the gradient buffer: all reads, then the sums and the writes ----
@@ -257,16 +261,16 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) b
 }
 
 inline size_t bf16_dgrad_block_smem() {
-    return static_cast<size_t>(kDbRows) * kDbCols * kDbPitch + 2 * kDbWBytes + sizeof(float) * (kDbLayers * 48 * 2 + 2 * 8 * 96);
+    return static_cast<size_t>(kDbRows) * kDbCols * kDbPitch + kDbWBytes + sizeof(float) * (kDbLayers * 48 * 2 + 2 * kDbWaves * 96);
 }
 
 // c0 a multiple of 48 (every dense block of FC-DenseNet57: 48 k base channels), gc0 a multiple of 8
 inline int launch_bf16_dgrad_block(const DgradBlock16Params& p, hipStream_t stream) {
     if (p.c0 <= 0 || (p.c0 % 48) || (p.gc0 & 7) || (p.blk & 7)) return ENDO_E_BADARG;
-    const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kBfTileY - 1) / kBfTileY);
+    const int tiles = ((p.w + kBfTileX - 1) / kBfTileX) * ((p.h + kDbTileY - 1) / kDbTileY);
     const size_t smem = bf16_dgrad_block_smem();
     ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_dgrad_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-    bf16_dgrad_block_kernel<<<dim3(tiles, p.c0 / 48, p.n), 512, smem, stream>>>(p);
+    bf16_dgrad_block_kernel<<<dim3(tiles, p.c0 / 48, p.n), kDbThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
