@@ -189,7 +189,12 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __r
 // weight gradient
 // ---------------------------------------------------------------------------------------------
 constexpr int kWgRows = 4, kWgCols = 32;                 // pixels of a tile
-constexpr int kWgCi = 192;                               // input channels per block (grid.y covers the rest)
+// input channels per block = 64 T (grid.y covers the rest): T 16-channel tiles per wave.  3 x 3: T = 1 -- 9 accumulator tiles per wave instead
+// of 27 and a third of the LDS; a tile's activations are then ONE batch of four 16-byte units per thread, and the registers this frees hold
+// the NEXT tile's loads (G window and activation batch) across the matrix phase: the walk over the tiles no longer waits for memory twice
+// per tile with nothing else to do
+constexpr int kWgT3 = 1, kWgT1 = 3;
+constexpr int bf16_wgrad_tiles_per_wave(int ks) { return ks == 3 ? kWgT3 : kWgT1; }
 constexpr int kWgPitchA = kWgRows * 64 + 16;             // bytes between channels of the staged a tile
 constexpr int kWgPitchG3 = (kWgRows + 2) * 3 * 64 + 16;  // 3 x 3: [16 cout][6 rows][3 shifted copies][32 px]
 constexpr int kWgCo1 = 144;                              // 1 x 1: couts per block (9 fragments of 16)
@@ -219,11 +224,12 @@ struct Wgrad16Params {
 };
 
 // KS = 3: grid (blocks, ci groups of 192, cout groups of 16); KS = 1: grid (blocks, ci groups of 192, cout groups of 144)
-template <int KS>
+template <int KS, int T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) bf16_wgrad_kernel(const Wgrad16Params p) {
+    constexpr int kWgCi = 64 * T;
     constexpr int kGBytes = KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_wg[];
-    unsigned char* s_a = smem_wg;                                       // [192][4 rows][32 px] bf16, pitch kWgPitchA
+    unsigned char* s_a = smem_wg;                                       // [64 T][4 rows][32 px] bf16, pitch kWgPitchA
     unsigned char* s_g = s_a + kWgCi * kWgPitchA;
     float* s_bn = reinterpret_cast<float*>(s_g + kGBytes);              // [2 groups][192][2] (scale, shift)
 
@@ -252,14 +258,118 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         s_bn[2 * e] = sc; s_bn[2 * e + 1] = sh;
     }
 
-    f32x4_t acc[9][3];
+    f32x4_t acc[9][T];
 #pragma unroll
     for (int f = 0; f < 9; ++f)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) acc[f][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < T; ++t) acc[f][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int tiles_x = (p.w + kWgCols - 1) / kWgCols, tiles_y = (p.h + kWgRows - 1) / kWgRows;
     const int total = tiles_x * tiles_y * p.n;
+    if constexpr (KS == 3 && T == 1) {
+        // ---- pipelined walk: tile i + 1's G window and activation batch are loaded while tile i is in its matrix phase ----
+        constexpr int kGItems = (kWgRows + 2) * (kWgCols + 2) * 4, kGIter = (kGItems + 255) / 256;
+        const int quads = (cout_g + 3) >> 2;
+        u32x2_t gv[kGIter];
+        u32x4_t av[4];
+        unsigned aok = 0;
+        auto tile_geom = [&](int tile, int& n, int& y0, int& x0) {
+            n = tile / (tiles_x * tiles_y);
+            const int rem = tile - n * tiles_x * tiles_y;
+            y0 = (rem / tiles_x) * kWgRows; x0 = (rem % tiles_x) * kWgCols;
+        };
+        auto issue = [&](int tile) {
+            int n, y0, x0;
+            tile_geom(tile, n, y0, x0);
+            const bool live = tile < total;
+#pragma unroll
+            for (int i = 0; i < kGIter; ++i) {
+                const int it = tid + i * 256;
+                const int q = it % quads, px = it / quads;
+                const int ry = px / (kWgCols + 2), rx = px - ry * (kWgCols + 2);          // tile pixel (ry - 1, rx - 1)
+                const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+                gv[i] = u32x2_t{0u, 0u};
+                if (live && it < (kWgRows + 2) * (kWgCols + 2) * quads && gy >= 0 && gy < p.h && gx >= 0 && gx < p.w)
+                    gv[i] = *reinterpret_cast<const u32x2_t*>(p.g + n * p.g_ns + blk_off(p.gc0 + co0 + 4 * q, static_cast<int64_t>(gy) * p.w + gx, g_plane, p.g_blk));
+            }
+            aok = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {          // unit k = (it >> 9) * 4 + (it & 3) of pixel (it >> 2) & 127, it = i * 256 + tid: 8 units of 8 channels
+                const int it = i * 256 + tid;
+                const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
+                const int gy = y0 + (px >> 5), gx = x0 + (px & 31);
+                av[i] = u32x4_t{0u, 0u, 0u, 0u};
+                if (live && k < units_c && gx < p.w && gy < p.h) {
+                    aok |= 1u << i;
+                    const int sy = p.ups ? gy >> 1 : gy, sx = p.ups ? gx >> 1 : gx;
+                    av[i] = *reinterpret_cast<const u32x4_t*>(p.a + n * p.a_ns + blk_off(p.ac0 + ci0 + 8 * k, static_cast<int64_t>(sy) * p.a_w + sx, a_plane, p.a_blk));
+                }
+            }
+        };
+        issue(blockIdx.x);
+        for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
+            const int n = tile / (tiles_x * tiles_y);
+            const float* bn_g = s_bn + (p.group_n > 0 ? n / p.group_n : 0) * 2 * kWgCi;
+            __syncthreads();          // the previous tile's fragment reads (and, the first time, s_bn)
+#pragma unroll
+            for (int i = 0; i < kGIter; ++i) {
+                const int it = tid + i * 256;
+                if (it >= (kWgRows + 2) * (kWgCols + 2) * quads) continue;
+                const int q = it % quads, px = it / quads;
+                const int ry = px / (kWgCols + 2), rx = px - ry * (kWgCols + 2);
+                const u32x2_t v = gv[i];
+                const uint16_t e[4] = {static_cast<uint16_t>(v[0] & 0xffffu), static_cast<uint16_t>(v[0] >> 16), static_cast<uint16_t>(v[1] & 0xffffu),
+                                       static_cast<uint16_t>(v[1] >> 16)};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int x = rx - 1 + kx - 1;          // copy kx holds G[x - kx + 1] at x
+                    if (x < 0 || x >= kWgCols) continue;
+#pragma unroll
+                    for (int i2 = 0; i2 < 4; ++i2)
+                        *reinterpret_cast<uint16_t*>(s_g + (4 * q + i2) * kWgPitchG3 + (ry * 3 + kx) * 64 + x * 2) = e[i2];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int it = i * 256 + tid;
+                const int k = (it >> 9) * 4 + (it & 3), px = (it >> 2) & 127;
+                if (k >= units_c) continue;
+                const int ry = px >> 5, rx = px & 31;
+                const u32x4_t v = av[i];
+                const bool ok = (aok >> i) & 1u;
+                float z[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { z[2 * j] = s16_lo(v[j]); z[2 * j + 1] = s16_hi(v[j]); }
+                if (p.saved) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4_t q = *reinterpret_cast<const f32x4_t*>(bn_g + 2 * (8 * k + 2 * j));
+                        z[2 * j] = ok ? fmaxf(fmaf(z[2 * j], q[0], q[1]), 0.f) : 0.f;
+                        z[2 * j + 1] = ok ? fmaxf(fmaf(z[2 * j + 1], q[2], q[3]), 0.f) : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned pk = pack_s16x2(z[2 * j], z[2 * j + 1]);
+                    *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk & 0xffffu);
+                    *reinterpret_cast<uint16_t*>(s_a + (8 * k + 2 * j + 1) * kWgPitchA + ry * 64 + rx * 2) = static_cast<uint16_t>(pk >> 16);
+                }
+            }
+            issue(tile + gridDim.x);          // flies under the barrier and the matrix phase
+            __syncthreads();
+            if (wave < ntiles_ci) {
+#pragma unroll
+                for (int row = 0; row < kWgRows; ++row) {
+                    const s16x8_t b = *reinterpret_cast<const s16x8_t*>(s_a + (16 * wave + li) * kWgPitchA + row * 64 + lk * 16);
+#pragma unroll
+                    for (int f = 0; f < 9; ++f) {
+                        const s16x8_t a = *reinterpret_cast<const s16x8_t*>(s_g + li * kWgPitchG3 + ((row - f / 3 + 2) * 3 + f % 3) * 64 + lk * 16);
+                        acc[f][0] = S16_MFMA(a, b, acc[f][0], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else
     for (int tile = blockIdx.x; tile < total; tile += gridDim.x) {
         const int n = tile / (tiles_x * tiles_y);
         const int rem = tile - n * tiles_x * tiles_y;
@@ -375,19 +485,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
         }
         __syncthreads();
         // ---- this wave's ci tiles 3 wave .. 3 wave + 2, one k-step per tile row ----
-        if (3 * wave < ntiles_ci) {
+        if (T * wave < ntiles_ci) {
 #pragma unroll
             for (int row = 0; row < kWgRows; ++row) {
-                s16x8_t b[3];
+                s16x8_t b[T];
 #pragma unroll
-                for (int t = 0; t < 3; ++t) b[t] = *reinterpret_cast<const s16x8_t*>(s_a + (16 * (3 * wave + t) + li) * kWgPitchA + row * 64 + lk * 16);
+                for (int t = 0; t < T; ++t) b[t] = *reinterpret_cast<const s16x8_t*>(s_a + (16 * (T * wave + t) + li) * kWgPitchA + row * 64 + lk * 16);
 #pragma unroll
                 for (int f = 0; f < 9; ++f) {
                     s16x8_t a;
                     if constexpr (KS == 3) a = *reinterpret_cast<const s16x8_t*>(s_g + li * kWgPitchG3 + ((row - f / 3 + 2) * 3 + f % 3) * 64 + lk * 16);
                     else a = *reinterpret_cast<const s16x8_t*>(s_g + (16 * f + li) * kWgPitchA + row * 64 + lk * 16);
 #pragma unroll
-                    for (int t = 0; t < 3; ++t) acc[f][t] = S16_MFMA(a, b[t], acc[f][t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) acc[f][t] = S16_MFMA(a, b[t], acc[f][t], 0, 0, 0);
                 }
             }
         }
@@ -397,9 +507,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) b
 #pragma unroll
     for (int f = 0; f < 9; ++f)
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const int ci = ci0 + 16 * (3 * wave + t) + li;
-            if (3 * wave + t >= ntiles_ci || ci >= p.ci_pad) continue;
+        for (int t = 0; t < T; ++t) {
+            const int ci = ci0 + 16 * (T * wave + t) + li;
+            if (T * wave + t >= ntiles_ci || ci >= p.ci_pad) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[(static_cast<int64_t>(f) * 16 + 4 * lk + i) * p.ci_pad + ci] = acc[f][t][i];
         }
@@ -434,12 +544,14 @@ __global__ void __launch_bounds__(256) bf16_wgrad_reduce_kernel(const float* __r
 
 template <int KS>
 inline size_t bf16_wgrad_smem() {
+    constexpr int kWgCi = 64 * bf16_wgrad_tiles_per_wave(KS);
     return static_cast<size_t>(kWgCi) * kWgPitchA + (KS == 3 ? 16 * kWgPitchG3 : kWgCo1 * kWgPitchA) + sizeof(float) * 2 * 2 * kWgCi;
 }
 
 // blocks of the walk over tiles, the partial buffer a launch needs (floats) and the launch itself
 inline int bf16_wgrad_blocks(const Wgrad16Params& p, int ks) {
     const int tiles = ((p.w + kWgCols - 1) / kWgCols) * ((p.h + kWgRows - 1) / kWgRows) * p.n;
+    const int kWgCi = 64 * bf16_wgrad_tiles_per_wave(ks);
     const int ci_groups = (p.cin + kWgCi - 1) / kWgCi, co_groups = ks == 3 ? (p.cout + 15) / 16 : (p.cout + kWgCo1 - 1) / kWgCo1;
     int blocks = (ks == 3 ? 512 : 256) / (ci_groups * co_groups);
     // (fewer, longer-running blocks at the coarse levels -- at least 8 tiles each -- halve the reduction but leave most CUs idle:
@@ -459,10 +571,11 @@ inline int launch_bf16_wgrad(Wgrad16Params p, float* dw, hipStream_t stream) {
     if (p.group_n > 0 && p.n > 2 * p.group_n) return ENDO_E_BADARG;          // two BatchNorm tables in LDS
     p.ci_pad = (p.cin + 15) / 16 * 16;
     const int blocks = bf16_wgrad_blocks(p, KS);
+    constexpr int T = bf16_wgrad_tiles_per_wave(KS), kWgCi = 64 * T;
     const int ci_groups = (p.cin + kWgCi - 1) / kWgCi, co_groups = KS == 3 ? (p.cout + 15) / 16 : (p.cout + kWgCo1 - 1) / kWgCo1;
     const size_t smem = bf16_wgrad_smem<KS>();
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_wgrad_kernel<KS>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
-    bf16_wgrad_kernel<KS><<<dim3(blocks, ci_groups, co_groups), 256, smem, stream>>>(p);
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_wgrad_kernel<KS, T>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+    bf16_wgrad_kernel<KS, T><<<dim3(blocks, ci_groups, co_groups), 256, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     const int64_t per_block = static_cast<int64_t>(co_groups) * 9 * 16 * p.ci_pad;
     bf16_wgrad_reduce_kernel<<<dim3(static_cast<int>((per_block + 255) / 256), (blocks + 63) / 64), 256, 0, stream>>>(p.partial, blocks, co_groups, p.ci_pad, p.cin, p.cout, KS, p.rot,
