@@ -554,10 +554,11 @@ def main():
                                            "2 B x (Cin + 12) per pixel")
             # stand-alone: the same family with the weight gradients in line (warm-up steps), as HBM GB/s of algorithmic bytes
             sgbs = fam_warm[dominant][3] / fam_warm[dominant][0] / 1e6 if fam_warm is not None and fam_warm[dominant][0] > 0 else None
-            result["roofline_serial"].update({"bound": "hbm", "mfma_tflops_for_reference": result["roofline_serial"]["achieved"],
-                                              "achieved": sgbs, "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                              "frac": sgbs / HBM_PEAK_GBS if sgbs else None})
-            result["roofline_serial"].pop("families_tflops", None)
+            if result["roofline_serial"] is not None:          # None with --warmup 0 / 1: no stand-alone timing was taken
+                result["roofline_serial"].update({"bound": "hbm", "mfma_tflops_for_reference": result["roofline_serial"]["achieved"],
+                                                  "achieved": sgbs, "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                  "frac": sgbs / HBM_PEAK_GBS if sgbs else None})
+                result["roofline_serial"].pop("families_tflops", None)
         else:
             result["roofline_serial"] = None
     if not args.no_cpu_baseline and world == 1:          # rank 0 at N = 1 only

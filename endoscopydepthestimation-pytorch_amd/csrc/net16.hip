@@ -312,6 +312,7 @@ struct endo_net16 {
     int64_t ws_zero_begin, ws_zero_end;   // everything but the level-0 gradient buffer starts at zero
     int64_t ws_w16d;                      // bytes
     int64_t ws_partial;                   // bytes
+    int64_t ws_partial_floats;            // capacity of the partial buffer (launch_bf16_wgrad checks every launch against it)
     int64_t ws_gscale;                    // bytes: {S, 1 / S} of the stored gradients (half storage)
     int64_t ws_bytes;
     // the weight gradients read only finished tensors (forward activations, a prepared gradient range) and nothing waits for them but
@@ -361,13 +362,19 @@ extern "C" int N16(create)(endo_net16** out, int n_per_group, int h, int w, int 
             const int64_t f = bf16_wgrad_partial_floats(cin, cout, ks, bf16_wgrad_blocks(q, ks));
             need = f > need ? f : need;
         };
+        // EVERY weight-gradient launch of the backward pass: blocks x co_groups x 144 x ci_pad is not monotonic in cin (the block count
+        // drops when cin crosses a multiple of 64), so the widest layer of a level is not its largest partial buffer
         wg(0, 4, k16First, 3);
         for (int l = 0; l < k16Levels; ++l) {
-            wg(l, c16_skip(l) + k16New + k16Growth * 3, k16Growth, 3);       // widest dense layer of the level
-            wg(l, c16_skip(l), c16_skip(l), 1);                              // transition down
-            wg(l, k16New, k16New, 3);                                        // transition up
+            for (int j = 0; j < k16Layers; ++j) {
+                wg(l, tb.down_conv[l][j].cin, k16Growth, 3);
+                wg(l, tb.up_conv[k16Levels - 1 - l][j].cin, k16Growth, 3);
+            }
+            wg(l, tb.td_conv[l].cin, tb.td_conv[l].cout, 1);                 // transition down
+            wg(l, k16New, k16New, 3);                                        // transition up (output grid of level l)
         }
-        wg(k16Levels, 288 + k16Growth * 3, k16Growth, 3);
+        for (int j = 0; j < k16Layers; ++j) wg(k16Levels, tb.bott_conv[j].cin, k16Growth, 3);
+        net->ws_partial_floats = need;
         net->ws_partial = o; o += align(need * 4);
         net->ws_gscale = o; o += 256;
         net->ws_bytes = o;
@@ -619,7 +626,7 @@ void fill_wgrad_a(const Ctx16& c, Wgrad16Params& p, int level, int ac0, int cin,
     if (b) { p.saved = c.saved(*b); p.gamma = c.params + b->g; p.beta = c.params + b->b; }
     p.rot = cv.rot; p.rot_n = cv.rot_n;
     p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved;
-    p.partial = c.partial(); p.gscale = c.gscale();
+    p.partial = c.partial(); p.partial_cap = c.net->ws_partial_floats; p.gscale = c.gscale();
 }
 
 // the data gradient of a BN -> ReLU -> conv layer: a convolution over the gradient of its outputs with the kEpiDgradBn epilogue
@@ -793,10 +800,18 @@ extern "C" int N16(bwd)(endo_net16* net, const float* params, const void* tape_,
         bf16_all_weights_kernel<<<1024, 256, 0, stream>>>(t, params, reinterpret_cast<uint16_t*>(c.ws + net->ws_w16d));
         ENDO_LAUNCH_CHECK();
     }
+    // everything that may fork the side stream runs inside `body`: the join below is reached on every exit path, so an error return never
+    // leaves the side stream un-joined with the caller's
+    auto body = [&]() -> int {
     int rc;
 #ifdef ENDO16_HALF
-    s16_grad_scale_kernel<<<1, 1024, 0, stream>>>(grad_out, static_cast<int64_t>(net->n) * net->lv[0].plane,
-                                                  reinterpret_cast<float*>(c.ws + net->ws_gscale));
+    ENDO_CHECK(hipMemsetAsync(c.ws + net->ws_gscale, 0, 16, stream));
+    {
+        const int64_t count = static_cast<int64_t>(net->n) * net->lv[0].plane;
+        int gb = static_cast<int>((count + 8191) / 8192);
+        gb = gb > 256 ? 256 : gb;
+        s16_grad_scale_kernel<<<gb, 1024, 0, stream>>>(grad_out, count, reinterpret_cast<float*>(c.ws + net->ws_gscale));
+    }
     ENDO_LAUNCH_CHECK();
 #endif
     {
@@ -832,16 +847,19 @@ extern "C" int N16(bwd)(endo_net16* net, const float* params, const void* tape_,
         p.a = reinterpret_cast<const uint16_t*>(c.tape + net->in_off); p.a_ns = lv.plane * 8; p.a_blk = 8; p.a_h = lv.h; p.a_w = lv.w; p.ac0 = 0; p.cin = 4;
         p.cin_w = 3;
         p.g = c.dbuf(0); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = 0; p.cout = k16First;
-        p.partial = c.partial(); p.gscale = c.gscale();
+        p.partial = c.partial(); p.partial_cap = c.net->ws_partial_floats; p.gscale = c.gscale();
         hipStream_t side;
         rc = c.fork_wgrad(side);
         if (rc) return rc;
         rc = launch_bf16_wgrad<3>(p, grads + tb.first.w, side);
         if (rc) return rc;
     }
+    return 0;
+    };
+    const int rc_body = body();
     if (net->wstream && net->use_wstream) {          // join: the caller's stream continues only after every weight gradient has landed
         ENDO_CHECK(hipEventRecord(net->ev_join, net->wstream));
         ENDO_CHECK(hipStreamWaitEvent(stream, net->ev_join, 0));
     }
-    return 0;
+    return rc_body;
 }

@@ -8,7 +8,7 @@ work=/tmp/variant_$name
 rm -rf $work; mkdir -p $work
 cd $root/endoscopydepthestimation-pytorch_amd/csrc
 objs=""
-for f in geometry losses optimizer prof scatter head jpeg filter dgrad_wino3 net16 net; do
+for f in geometry losses optimizer prof scatter head jpeg filter dgrad_wino3 net16 net16h net; do
     fx=""; [ $f = dgrad_wino3 ] && fx="-fno-slp-vectorize"
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -fPIC $extra $fx -c $f.hip -o $work/$f.o &
     objs="$objs $work/$f.o"

@@ -22,15 +22,65 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from source_id import source_id          # noqa: E402 -- ties the file to the kernel sources it was measured on (bench.py checks it)
 
-FAMILIES = [
-    # (the bf16-storage family's kernels, bench.py --config 2: bf16_dgrad_block_kernel and bf16_conv_kernel<3, 3, 2, ...> serve only the
-    # dense layers' data gradients; bf16_wgrad_kernel<3> also the five transition-up and the first convolution -- 6 of 50 launches)
-    ("dgrad_dense", re.compile(r"dgrad_block8?_kernel|dgrad_wino8_kernel|dgrad_wino3_kernel|dgrad_dense_kernel|conv_dma_kernel<3, \d+, 1, 0, 2,|"
-                               r"bf16_dgrad_block_kernel|bf16_conv_kernel<3, 3, 2,")),
-    ("conv3x3_dense_fwd", re.compile(r"wino_fwd_kernel|conv_dma_kernel<3, \d+, 1, 1, 0,|finalize_partial_kernel|bf16_conv_kernel<3, 1, 0,")),
-    ("wgrad_dense", re.compile(r"wgrad_nsplit_kernel|wgrad_nsplit_reduce_kernel|wgrad_taps_kernel<12, 1>|wgrad_mfma_kernel<3, 1, 1, 0>|"
-                               r"bf16_wgrad_kernel<3>|bf16_wgrad_reduce_kernel")),
-]
+# A kernel belongs to a family by its BASE name plus, where one base name serves several layer kinds, the template arguments that
+# say which (round 3 matched on a textual prefix of the template list: when `wgrad_taps_kernel<12, 1>` grew a third argument the family
+# silently lost 112 launches).  classify() must return a family for every convolution-like kernel -- "other" is an explicit answer --
+# and main() fails when one of them is unknown.
+def split_name(name):
+    """'void endo::b16::conv_kernel<3, 1, 0>(endo::P)' -> ('conv_kernel', ['3', '1', '0'])"""
+    name = name.split("(")[0].strip()
+    if name.startswith("void "):
+        name = name[5:]
+    args = []
+    if "<" in name:
+        name, rest = name.split("<", 1)
+        args = [a.strip() for a in rest.rstrip(">").split(",")]
+    return name.split("::")[-1], args
+
+
+CONV_LIKE = re.compile(r"wgrad|dgrad|conv|wino")
+
+
+def classify(name):
+    """family of bench.py's profiling scopes, 'other' for convolution-like kernels outside the three dense-layer families, None for
+    kernels that are not convolution-like; raises on a convolution-like kernel this table does not know."""
+    base, a = split_name(name)
+    if not CONV_LIKE.search(base):
+        return None
+    if base in ("wgrad_nsplit_kernel", "wgrad_nsplit_reduce_kernel", "wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_wino_finish_kernel"):
+        return "wgrad_dense"
+    if base == "wgrad_taps_kernel":                       # <COUT, IN_MODE, BF>: IN_MODE 1 = BN + ReLU input (dense layer), 0 = raw (first conv), 2 = x2 gather (transition up)
+        return "wgrad_dense" if a[1] == "1" else "other"
+    if base == "wgrad_mfma_kernel":                       # <KS, IN_MODE, ...>: the register-staged fallback
+        return "wgrad_dense" if a[0] == "3" and a[1] == "1" else "other"
+    if base in ("dgrad_block_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_dense_kernel"):
+        return "dgrad_dense"
+    if base == "wino_fwd_kernel" or base == "finalize_partial_kernel":
+        return "conv3x3_dense_fwd"
+    if base in ("conv_dma_kernel", "conv_mfma_kernel"):   # <KS, KC, Q, IN_MODE, EPI, ...>
+        if a[0] == "3" and a[2] == "1" and a[3] == "1" and a[4] == "0":
+            return "conv3x3_dense_fwd"
+        if a[0] == "3" and a[2] == "1" and a[3] == "0" and a[4] == "2":
+            return "dgrad_dense"
+        return "other"
+    # the 16-bit-storage family (bench.py --config 2 / 4)
+    if base == "bf16_dgrad_block_kernel":
+        return "dgrad_dense"
+    if base == "bf16_conv_kernel":                        # <KS, NT, EPI, ...>
+        if a[0] == "3" and a[1] == "3" and a[2] == "2":
+            return "dgrad_dense"
+        if a[0] == "3" and a[1] == "1" and a[2] == "0":
+            return "conv3x3_dense_fwd"
+        return "other"
+    if base == "bf16_wgrad_kernel":                       # <KS, T>: KS 3 also serves the five transition-up layers and the first convolution (6 of 50 launches)
+        return "wgrad_dense" if a[0] == "3" else "other"
+    if base == "bf16_wgrad_reduce_kernel":                # one per bf16_wgrad_kernel launch, 3x3 and 1x1 alike (5 of 55 are the 1x1's: ~1 % of the family's bytes)
+        return "wgrad_dense"
+    if base in ("wgrad1x1_dma_kernel", "wgrad1x1_mfma_kernel", "tu_wgrad_subpix_kernel", "tu_wgrad_subpix_reduce_kernel", "wino_fwd_weights_kernel",
+                "dgrad_wino_weights_kernel", "tu_subpix_dgrad_weights_kernel", "wgrad_wino_weights_kernel", "td_bwd_prep_kernel",
+                "td_dgrad_gemm_kernel", "td_wgrad_gemm_kernel", "td_wgrad_reduce_kernel"):
+        return "other"
+    raise SystemExit("pmc_traffic: convolution-like kernel %r belongs to no family -- extend classify()" % name)
 
 
 def per_kernel(db, counter):
@@ -42,14 +92,16 @@ def per_kernel(db, counter):
 
 def families_from_kernels(kernels, steps):
     fams = {}
-    for fam, rx in FAMILIES:
-        sel = [v for k, v in kernels.items() if rx.search(k)]
-        if sel:
-            fetch = sum(v["fetch_bytes_per_launch"] * v["launches"] for v in sel)
-            write = sum(v["write_bytes_per_launch"] * v["launches"] for v in sel)
-            fams[fam] = {"kernel_dispatches_per_step": sum(v["launches"] for v in sel) / steps,
-                         "fetch_bytes_per_step": fetch / steps, "write_bytes_per_step": write / steps,
-                         "traffic_bytes_per_step": (fetch + write) / steps}
+    for name, v in kernels.items():
+        fam = classify(name)
+        if fam is None or fam == "other":
+            continue
+        f = fams.setdefault(fam, {"kernel_dispatches_per_step": 0.0, "fetch_bytes_per_step": 0.0, "write_bytes_per_step": 0.0})
+        f["kernel_dispatches_per_step"] += v["launches"] / steps
+        f["fetch_bytes_per_step"] += v["fetch_bytes_per_launch"] * v["launches"] / steps
+        f["write_bytes_per_step"] += v["write_bytes_per_launch"] * v["launches"] / steps
+    for f in fams.values():
+        f["traffic_bytes_per_step"] = f["fetch_bytes_per_step"] + f["write_bytes_per_step"]
     return fams
 
 
@@ -73,7 +125,7 @@ def main():
             continue
         nf, f = fetch.get(name, (0, 0.0))
         nw, w = write.get(name, (0, 0.0))
-        out["kernels"][name[:110]] = {"launches": max(nf, nw), "fetch_bytes_per_launch": 2048.0 * f / max(nf, 1),
+        out["kernels"][name[:160]] = {"launches": max(nf, nw), "fetch_bytes_per_launch": 2048.0 * f / max(nf, 1),
                                       "write_bytes_per_launch": 1024.0 * w / max(nw, 1)}
     out["families"] = families_from_kernels(out["kernels"], steps)
     with open(sys.argv[3], "w") as fh:
