@@ -387,11 +387,18 @@ def main():
     lib.endo_prof_enable(mask)
     t0 = time.perf_counter()
     skipped = 0
+    # every step's losses, guard flag and gradient norm are read on the host (the reference's loss.item(), train.py:317) -- one step
+    # late: the guard itself is decided on the device (StepOutput, train_step.py), so the read of step k - 1 happens while step k is
+    # queued and the GPU does not idle at the loss
+    pending = None
     for _ in range(args.steps):
         scheduler.batch_step(batch_iteration=it)
         out = step_fn(batch)
-        skipped += int(out["skipped"])
+        if pending is not None:
+            skipped += int(pending["skipped"])
+        pending = out
         it += 1
+    skipped += int(pending["skipped"]) if pending is not None else 0
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0                             # this rank's own steps (before waiting for the others)
     barrier()

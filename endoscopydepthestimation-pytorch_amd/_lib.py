@@ -83,7 +83,7 @@ SIGNATURES = {
     "endo_net_tape_offset": (_L, [_P, _I, _I]),
     "endo_net_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "endo_net_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "endo_sgd_clip_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
+    "endo_sgd_clip_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _P]),
     "endo_sparse_scatter": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, _P]),
     "endo_relative_poses": (_I, [_P, _I, ctypes.c_double, _P, _P, _P, _P, _P]),
     "endo_point_cloud": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),

@@ -68,10 +68,61 @@ __device__ __forceinline__ bf16x4_bits pack_bf16x4(float a, float b, float c, fl
 // eight consecutive k values of a lane for v_mfma_f32_16x16x32_bf16 (gfx950: twice the k of the x16 form in the same 16-18 cycles,
 // tools/mfma_rate_probe)
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4_acc __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bf16x8_t pack_bf16x8(float a, float b, float c, float d, float e, float f, float g, float h) {
     typedef float f32x8_t __attribute__((ext_vector_type(8)));
     return __builtin_convertvector(f32x8_t{a, b, c, d, e, f, g, h}, bf16x8_t);
+}
+
+// ---- fp32 products on the bf16 matrix cores: the three-term split ("bf16x3") ---------------------------------------------------------
+// fp32 matrix instructions run on the vector FMA lanes of this part (157 TFLOP/s, shared with every VALU instruction of the kernel:
+// DESIGN.md 4.12); v_mfma_f32_16x16x32_bf16 is a separate unit with 16x the rate.  An fp32 value is EXACTLY the sum of three bf16 terms
+//     v = hi + mid + lo,   hi = bf16(v),  mid = bf16(v - hi),  lo = bf16(v - hi - mid)
+// (round to nearest even: each residual is at most half an ulp of the term before, so the three terms carry 8 + 9 + 9 >= 24 significant
+// bits; the subtractions are exact in fp32), and a product of two bf16 values is exact in fp32.  So
+//     a * b = ah bh + (ah bm + am bh) + (am bm + ah bl + al bh) + [am bl + al bm + al bl],
+// where the bracket is at most 2^-23 |a b| (|am| <= 2^-8 |a|, |bl| <= 2^-16 |b|), typically 2^-26 |a b| -- relative to ONE product,
+// while the rounding fp32 itself commits when it adds a product to its accumulator is 2^-24 of the (much larger) running sum.
+// The kernels issue the six leading products as six bf16 MFMAs into the same fp32 accumulator, smallest first: fp32
+// operands, exact products, fp32 accumulation -- at 6 / 16 of the fp32 matrix instructions' issue time and off the vector lanes.
+// Splitting costs ~5.5 VALU instructions per element and is done once per fragment that then feeds many MFMAs.
+typedef unsigned u32x4_bits __attribute__((ext_vector_type(4)));
+
+struct Bf16x8Split {
+    bf16x8_t hi, mid, lo;
+};
+
+// two values -> one dword of each term; ra / rb are scratch
+__device__ __forceinline__ void split_bf16x3_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{ra, rb}, bf16x2_t));
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{sa, sb}, bf16x2_t));
+}
+
+__device__ __forceinline__ Bf16x8Split split_bf16x8(float a, float b, float c, float d, float e, float f, float g, float h) {
+    unsigned hi[4], mid[4], lo[4];
+    split_bf16x3_pair(a, b, hi[0], mid[0], lo[0]);
+    split_bf16x3_pair(c, d, hi[1], mid[1], lo[1]);
+    split_bf16x3_pair(e, f, hi[2], mid[2], lo[2]);
+    split_bf16x3_pair(g, h, hi[3], mid[3], lo[3]);
+    return Bf16x8Split{__builtin_bit_cast(bf16x8_t, u32x4_bits{hi[0], hi[1], hi[2], hi[3]}), __builtin_bit_cast(bf16x8_t, u32x4_bits{mid[0], mid[1], mid[2], mid[3]}),
+                       __builtin_bit_cast(bf16x8_t, u32x4_bits{lo[0], lo[1], lo[2], lo[3]})};
+}
+
+// acc += a * b over the 32 k of the fragments, six products, smallest first
+__device__ __forceinline__ f32x4_acc mfma_bf16x3(const Bf16x8Split& a, const Bf16x8Split& b, f32x4_acc acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.mid, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.mid, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.mid, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, acc, 0, 0, 0);
+    return acc;
 }
 
 // Block-wide sum of K per-thread partials, one fp64 atomic per value per block.

@@ -28,15 +28,17 @@ __global__ void __launch_bounds__(256) head_add_kernel(float* __restrict__ out, 
     }
 }
 
-// losses[0..2] = total, dcl, sfl as train.py:299-315 forms them (fp32): sfl = w_sfl * 0.5 * (a + b), dcl likewise, total = dcl + sfl;
+// losses[0..2] = total, dcl, sfl as train.py:299-315 forms them (fp32), losses[3] = 1 when the total is NaN / Inf (train.py:317) else 0: sfl = w_sfl * 0.5 * (a + b), dcl likewise, total = dcl + sfl;
 // up[0] = d total / d (each sparse-flow term), up[1] = d total / d (each consistency term)
 __global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl, float c_dcl, float* __restrict__ losses, float* __restrict__ up) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float sfl = c_sfl * (parts[0] + parts[1]);
         const float dcl = c_dcl * (parts[2] + parts[3]);
-        losses[0] = dcl + sfl;
+        const float total = dcl + sfl;
+        losses[0] = total;
         losses[1] = dcl;
         losses[2] = sfl;
+        losses[3] = (isnan(total) || isinf(total)) ? 1.f : 0.f;          // the guard of train.py:317, decided on the device
         up[0] = c_sfl;
         up[1] = c_dcl;
     }

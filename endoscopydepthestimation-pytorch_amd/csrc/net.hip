@@ -555,6 +555,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
 //   ENDO_OPT_WINO_MIN_TILES  a Winograd kernel is used from this many tiles per launch on (default 1024: the levels whose launches fill
 //                            the chip several times; tests set 1 to reach the kernels at small sizes)
+//   ENDO_OPT_MFMA_X3         bit mask of the kernel families (1 wgrad, 2 forward, 4 dgrad) that evaluate fp32 products as three-term bf16 splits (common.h)
 //   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 1;
@@ -563,6 +564,7 @@ static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
     opt[ENDO_OPT_MFMA_BF16] = 0;
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
+    opt[ENDO_OPT_MFMA_X3] = 0;
 }
 static int wino_fwd_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_FWD]; }
 static bool wino_fwd_enabled(const Ctx& c) { return wino_fwd_mode(c) != 0; }
@@ -572,6 +574,8 @@ static bool dgrad_vec_enabled(const Ctx& c) { return c.net->opt[ENDO_OPT_DGRAD_V
 // bit 0: weight gradients, bit 1: forward, bit 2: data gradients of the dense layers (1 = all three)
 static int mfma_bf16_mask(const Ctx& c) { const int v = c.net->opt[ENDO_OPT_MFMA_BF16]; return v == 1 ? 7 : (v >> 1); }
 static bool mfma_bf16_wgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 1) != 0; }
+// operand mode of a dense-layer weight gradient: 0 fp32 MFMA, 1 operands rounded to bf16, 2 fp32 operands as three-term bf16 splits
+static int wgrad_mfma_mode(const Ctx& c) { return mfma_bf16_wgrad(c) ? 1 : ((c.net->opt[ENDO_OPT_MFMA_X3] & 1) ? 2 : 0); }
 static bool mfma_bf16_fwd(const Ctx& c) { return (mfma_bf16_mask(c) & 2) != 0; }
 static bool mfma_bf16_dgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 4) != 0; }
 
@@ -765,7 +769,7 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
-    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, mfma_bf16_wgrad(c));
+    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, wgrad_mfma_mode(c));
     if (wgrad_taps_ok(p)) return mfma_bf16_wgrad(c) ? launch_wgrad_taps<12, IN_BNRELU, 1>(p, c.stream) : launch_wgrad_taps<12, IN_BNRELU>(p, c.stream);
     return launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }

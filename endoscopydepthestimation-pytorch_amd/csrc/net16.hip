@@ -401,7 +401,7 @@ extern "C" int64_t N16(bwd_workspace_bytes)(const endo_net16* net) { return net 
 // Where things are (tests read the forward pass's decisions and the gradient buffers): byte offsets into the tape -- what 0: final
 // pre-activation (fp32), 1: (mean, rstd) of BatchNorm layer `index` in module order (fp32), 2: max-pool codes of transition down
 // `index`, 3: level buffer `index` -- or into the backward workspace -- 4: gradient buffer of level `index`; 5: channels of level
-// buffer `index` (not an offset).  -1 for anything else.
+// buffer `index` (not an offset); 7: bytes between two sample groups' (mean, rstd) tables.  -1 for anything else.
 extern "C" int64_t N16(offset)(const endo_net16* net, int what, int index) {
     if (!net || index < 0) return -1;
     const Table16& tb = table16();
@@ -413,6 +413,7 @@ extern "C" int64_t N16(offset)(const endo_net16* net, int what, int index) {
         case 4: return index <= k16Levels ? net->ws_d[index] : -1;
         case 5: return index <= k16Levels ? net->lv[index].t : -1;
         case 6: return index <= k16Levels ? net->ws_pq[index] : -1;          // workspace: deferred BatchNorm terms of the level, fp32 [P[t]][Q[t]] per group
+        case 7: return net->gs_saved * 4;          // not an offset: bytes from one sample group's saved (mean, rstd) table to the next
         default: return -1;
     }
 }

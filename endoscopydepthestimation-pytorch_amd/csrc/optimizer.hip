@@ -16,8 +16,14 @@ __global__ void __launch_bounds__(256) sq_norm_kernel(const float* __restrict__ 
 
 __global__ void __launch_bounds__(256) sgd_clip_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                                                        double* norm, int64_t count, float lr, float mu, float max_norm,
-                                                       float scale, int first) {
+                                                       float scale, int first, const float* __restrict__ skip_flag) {
     const float total = static_cast<float>(sqrt(norm[0]));
+    // the non-finite-loss guard (train.py:317-322), taken on the device: a non-zero flag (any rank's, after the bucket's all-reduce)
+    // leaves parameters and momentum untouched -- what the reference's zero_grad() + step() does with torch >= 2.0
+    if (skip_flag && skip_flag[0] != 0.f) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) norm[1] = static_cast<double>(total);
+        return;
+    }
     float coef = max_norm / (total + 1.0e-6f);
     coef = coef > 1.0f ? 1.0f : coef;
     if (blockIdx.x == 0 && threadIdx.x == 0) norm[1] = static_cast<double>(total);
@@ -35,7 +41,7 @@ __global__ void __launch_bounds__(256) sgd_clip_kernel(float* __restrict__ p, fl
 using namespace endo;
 
 extern "C" int endo_sgd_clip_step(float* params, float* grads, float* momentum, double* norm_out, int64_t count, float lr, float mu,
-                                  float max_norm, float grad_scale, int first_step, void* stream_) {
+                                  float max_norm, float grad_scale, int first_step, const float* skip_flag, void* stream_) {
     if (!params || !grads || !momentum || !norm_out || count <= 0) return ENDO_E_BADARG;
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfOptimizer, stream, 0.0, 4.0 * 6.0 * static_cast<double>(count));
@@ -43,7 +49,7 @@ extern "C" int endo_sgd_clip_step(float* params, float* grads, float* momentum, 
     int blocks = static_cast<int>((count + 256 * 8 - 1) / (256 * 8));
     blocks = blocks > 1024 ? 1024 : blocks;
     sq_norm_kernel<<<blocks, 256, 0, stream>>>(grads, norm_out, count, grad_scale);
-    sgd_clip_kernel<<<blocks, 256, 0, stream>>>(params, grads, momentum, norm_out, count, lr, mu, max_norm, grad_scale, first_step);
+    sgd_clip_kernel<<<blocks, 256, 0, stream>>>(params, grads, momentum, norm_out, count, lr, mu, max_norm, grad_scale, first_step, skip_flag);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

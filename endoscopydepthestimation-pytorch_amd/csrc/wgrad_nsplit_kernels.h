@@ -35,7 +35,8 @@ constexpr int kNsMG = 7;
 constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
 
 // EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x loads, 2 = no dY DMA, 4 = no barrier
-// BF: 1 = bf16 MFMA operands (fp32 accumulation, fp32 memory): the 4 k-steps of a float4 become one v_mfma_f32_16x16x16_bf16
+// BF: 1 = bf16 MFMA operands (fp32 accumulation, fp32 memory): the 8 k-steps of a lane's two float4s become one v_mfma_f32_16x16x32_bf16;
+// 2 = fp32 operands as three bf16 terms each, six such MFMAs (fp32-accurate: common.h split_bf16x8)
 template <int NG, int EXP = 0, int BF = 0>
 __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradParams p, float* __restrict__ partial,
                                                                     int chunks_per_block) {
@@ -205,7 +206,32 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
         if (chunk + 2 < c_end) issue(buf == 0 ? 2 : buf - 1, slot_c);          // the buffer computed last iteration
 
         const float* s_dy = smem + buf * kNsBuf;
-        if constexpr (BF != 0) {
+        if constexpr (BF == 2) {
+            // fp32 products on the bf16 matrix cores (common.h, split_bf16x8): both operands split into three bf16 terms, six MFMAs per
+            // (row group, channel group) in place of the eight fp32 ones -- 96 instead of 256 matrix-pipe cycles, off the vector lanes
+            Bf16x8Split bq[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                bq[g] = split_bf16x8(bv[g][0][0], bv[g][0][1], bv[g][0][2], bv[g][0][3], bv[g][1][0], bv[g][1][1], bv[g][1][2], bv[g][1][3]);
+#pragma unroll
+            for (int m = 0; m < kNsMG; ++m) {
+                const float* ap = s_dy + aoff[m];
+                const Bf16x8Split aq = split_bf16x8(ap[0], ap[1], ap[2], ap[3], ap[16], ap[17], ap[18], ap[19]);
+                // smallest products first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.lo, bq[g].hi, acc[g][m], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.hi, bq[g].lo, acc[g][m], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.mid, bq[g].mid, acc[g][m], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.mid, bq[g].hi, acc[g][m], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.hi, bq[g].mid, acc[g][m], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq.hi, bq[g].hi, acc[g][m], 0, 0, 0);
+            }
+        } else if constexpr (BF != 0) {
             // the lane's 8 pixels of the chunk (two float4s) are the k = 8 lk + i of ONE v_mfma_f32_16x16x32_bf16 per (row group, channel group)
             bf16x8_t bq[NG];
 #pragma unroll
@@ -321,13 +347,19 @@ inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int pass
     return 0;
 }
 
-// scratch: kNsScratchFloats floats
-inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream, bool bf16_operands = false) {
+// scratch: kNsScratchFloats floats.  mfma_mode: 0 = fp32 matrix instructions, 1 = operands ROUNDED to bf16 (the mixed-precision mode of
+// DESIGN.md 4.10), 2 = fp32 operands split into three bf16 terms, six bf16 MFMAs (common.h: fp32-accurate products on the bf16 cores)
+inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t stream, int mfma_mode = 0) {
     const int groups = (p.cin + 15) / 16;
     const int passes = (groups + 11) / 12;                       // at most 3 groups per wave
     const int per_pass = (groups + passes - 1) / passes;
     const int ng = (per_pass + 3) / 4;
-    if (bf16_operands) {
+    if (mfma_mode == 2) {
+        if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 2>(p, scratch, passes, stream);
+        if (ng == 2) return launch_wgrad_nsplit_ng<2, 0, 2>(p, scratch, passes, stream);
+        return launch_wgrad_nsplit_ng<3, 0, 2>(p, scratch, passes, stream);
+    }
+    if (mfma_mode == 1) {
         if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 1>(p, scratch, passes, stream);
         if (ng == 2) return launch_wgrad_nsplit_ng<2, 0, 1>(p, scratch, passes, stream);
         return launch_wgrad_nsplit_ng<3, 0, 1>(p, scratch, passes, stream);

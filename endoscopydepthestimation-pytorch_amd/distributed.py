@@ -1,8 +1,8 @@
 """Data parallelism: one process per GPU, persistent replicas, ONE all-reduce of the flat gradient
 bucket per step (RCCL over xGMI via torch.distributed backend "nccl"), replacing the per-forward
 broadcast / scatter / gather / reduce_add of ``torch.nn.DataParallel`` (reference train.py:197;
-SURVEY.md 2.2 rows C1-C3).  Also the 1-element MAX all-reduce that makes every rank take the same
-branch of the non-finite-loss guard (train.py:317-322).  Backend-agnostic: the CPU tests drive it
+SURVEY.md 2.2 rows C1-C3).  The bucket's trailing float carries the non-finite-loss flag, so the same
+collective makes every rank take the same branch of the guard (train.py:317-322).  Backend-agnostic: the CPU tests drive it
 with gloo.
 """
 
@@ -49,23 +49,38 @@ def shard_range(total, rank, world):
 
 
 class GradientBucket(object):
-    """The flat fp32 gradient buffer of a model replica, reduced with a single collective."""
+    """The flat fp32 gradient buffer of a model replica, reduced with a single collective.  ``bucket_fn`` (optional) returns the
+    buffer WITH its trailing guard slot (``FCDenseNet.flat_gradient_bucket``): the step's non-finite-loss flag then rides in the same
+    all-reduce -- its sum over ranks is non-zero exactly when some rank's loss was NaN / Inf, so every rank takes the same branch of
+    train.py:317-322 without a second collective and without the host in the loop."""
 
-    def __init__(self, flat_grad_fn):
+    def __init__(self, flat_grad_fn, bucket_fn=None):
         self._flat_grad_fn = flat_grad_fn
+        self._bucket_fn = bucket_fn
 
-    def all_reduce(self):
-        """Sum the bucket over ranks.  Returns the factor (1/world) the optimizer must apply --
-        it is folded into the fused clip+SGD kernel instead of costing a pass of its own."""
+    def all_reduce(self, flag=None):
+        """Sum the bucket over ranks.  Returns the factor (1/world) the optimizer must apply -- it is folded into the fused clip+SGD
+        kernel instead of costing a pass of its own -- or, when ``flag`` (1-element fp32 device tensor, this rank's guard flag) is
+        given, ``(factor, flag after consensus)``: a 1-element view the optimizer kernel reads."""
         world = world_size()
-        if world > 1:
-            dist.all_reduce(self._flat_grad_fn(), op=dist.ReduceOp.SUM)
-        return 1.0 / world
+        if flag is None:
+            if world > 1:
+                dist.all_reduce(self._flat_grad_fn(), op=dist.ReduceOp.SUM)
+            return 1.0 / world
+        if world <= 1:
+            return 1.0, flag
+        if self._bucket_fn is None:
+            raise RuntimeError("GradientBucket: the guard flag needs the bucket with its trailing slot (bucket_fn)")
+        bucket = self._bucket_fn()
+        bucket[-1:].copy_(flag.reshape(1))
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+        return 1.0 / world, bucket[-1:]
 
 
 def agree_nonfinite(flag_tensor):
     """flag_tensor: 1-element tensor, 1 where this rank's loss is NaN/Inf.  MAX over ranks so the
-    guard of train.py:317-322 is taken by all ranks or none."""
+    guard of train.py:317-322 is taken by all ranks or none.  (TrainingStep no longer calls it: the flag travels in the gradient
+    bucket, GradientBucket.all_reduce(flag); kept for callers that drive the modules themselves.)"""
     if world_size() > 1:
         dist.all_reduce(flag_tensor, op=dist.ReduceOp.MAX)
     return flag_tensor

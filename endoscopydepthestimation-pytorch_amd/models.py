@@ -172,6 +172,7 @@ class FCDenseNet(nn.Module):
 
         self._flat = None          # flat parameter storage (all 210 tensors)
         self._flat_grad = None
+        self._flat_grad_full = None
         self._flat_bn = None       # running_mean/var of the 49 BN layers
         self._nbt = None
         self._handles = {}
@@ -200,6 +201,7 @@ class FCDenseNet(nn.Module):
             off += n
         self._flat, self._offsets, self._params = flat, offsets, params
         self._flat_grad = None
+        self._flat_grad_full = None
         bns = self._bn_modules()
         width = sum(2 * m.num_features for m in bns)
         flat_bn = torch.empty(width, dtype=torch.float32, device=device)
@@ -245,11 +247,19 @@ class FCDenseNet(nn.Module):
         self._attach_grads(create)
         return self._flat_grad
 
+    def flat_gradient_bucket(self):
+        """The buffer a data-parallel step all-reduces: the flat gradients plus one trailing float, the step's non-finite-loss flag."""
+        self._attach_grads(True)
+        return self._flat_grad_full
+
     def _attach_grads(self, create=True):
         if self._flat_grad is None or self._flat_grad.device != self._flat.device:
             if not create:
                 return
-            self._flat_grad = torch.zeros_like(self._flat)
+            # one extra float behind the gradients: the non-finite-loss flag of the step, so that the ONE all-reduce of the bucket also
+            # carries the guard's consensus (train_step.TrainingStep, distributed.GradientBucket)
+            self._flat_grad_full = torch.zeros(self._flat.numel() + 1, dtype=torch.float32, device=self._flat.device)
+            self._flat_grad = self._flat_grad_full[:self._flat.numel()]
             for p, off in zip(self._params, self._offsets):
                 p.grad = self._flat_grad[off:off + p.numel()].view(p.shape)
             return
@@ -282,7 +292,7 @@ class FCDenseNet(nn.Module):
 
     # kernel-form / precision options (include/endo_hip.h ENDO_OPT_*) belong to THIS module object -- like everything else about a
     # reference module (train.py:191): they apply to every native handle it owns, present and future, and to no other model
-    _OPTION_DEFAULTS = {0: 1, 1: 1, 2: 1, 3: 1024, 4: 0, 5: 1}
+    _OPTION_DEFAULTS = {0: 1, 1: 1, 2: 1, 3: 1024, 4: 0, 5: 1, 6: 0}
 
     def set_kernel_option(self, option_id, value):
         """Returns the previous value."""
@@ -319,7 +329,7 @@ class FCDenseNet(nn.Module):
         state = dict(self.__dict__)
         for key in ("_handles", "_gradws"):
             state[key] = {}
-        for key in ("_flat_grad", "_anchor"):
+        for key in ("_flat_grad", "_flat_grad_full", "_anchor"):
             state[key] = None
         return state
 

@@ -37,17 +37,22 @@ class FusedClipSGD(Optimizer):
             self._norm = torch.zeros(2, dtype=torch.float64, device=params.device)
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
-        """grad_scale: 1/world_size after a summed all-reduce.  Returns the pre-clip gradient norm
-        as a 0-dim fp64 device tensor of its own (no host sync; later steps do not overwrite it)."""
+    def step(self, grad_scale=1.0, skip_flag=None):
+        """grad_scale: 1/world_size after a summed all-reduce.  skip_flag: None, or a 1-element fp32 device tensor -- when it is
+        non-zero the kernels leave parameters and momentum untouched (the non-finite-loss guard of reference train.py:317-322,
+        decided on the device so that the host never waits for the loss before the backward pass).  Returns the pre-clip gradient
+        norm as a 0-dim fp64 device tensor of its own (no host sync; later steps do not overwrite it)."""
         lib = _lib.load()
         group = self.param_groups[0]
         params = self.model.flat_parameters()
         grads = self.model.flat_gradients()
         self._ensure_state()
+        # (first_step: the momentum buffer starts as zeros, so mu * buf + g IS g on the first step; the flag is kept for callers of the
+        # C entry point that hand over an uninitialised buffer)
         _lib.check(lib.endo_sgd_clip_step(_lib.ptr(params), _lib.ptr(grads), _lib.ptr(self._momentum), _lib.ptr(self._norm),
                                           params.numel(), float(group['lr']), float(group['momentum']), float(group['max_norm']),
-                                          float(grad_scale), 1 if self._steps == 0 else 0, _lib.stream()), "endo_sgd_clip_step")
+                                          float(grad_scale), 0, _lib.ptr(skip_flag) if skip_flag is not None else None,
+                                          _lib.stream()), "endo_sgd_clip_step")
         self._steps += 1
         return self._norm[1].clone()
 

@@ -3,11 +3,10 @@ train.py:272-328, built from the drop-in modules of ``models`` / ``losses`` and 
 
   colours * boundary -> two network forwards (BN statistics per call, train.py:276-277) -> depth
   scaling -> flow-from-depth both ways -> boundary masking -> sparse-flow loss -> depth warping
-  both ways -> depth-consistency loss -> weighted sum -> non-finite guard (agreed across ranks)
-  -> backward -> ONE gradient all-reduce -> fused clip_grad_norm_(10) + SGD(0.9).
+  both ways -> depth-consistency loss -> weighted sum (+ the non-finite flag, on the device) -> backward
+  -> ONE all-reduce of gradients + flag -> fused clip_grad_norm_(10) + SGD(0.9), skipped by the kernel when
+  any rank's loss was NaN / Inf.
 """
-
-import math
 
 import torch
 
@@ -72,7 +71,7 @@ class TrainingStep(object):
         self.flow_from_depth_layer = models.FlowfromDepthLayer()
         self.sparse_flow_loss_function = losses.SparseMaskedL1Loss()
         self.depth_consistency_loss_function = losses.NormalizedDistanceLoss(height=height, width=width)
-        self.bucket = distributed.GradientBucket(model.flat_gradients)
+        self.bucket = distributed.GradientBucket(model.flat_gradients, getattr(model, "flat_gradient_bucket", None))
         # persistent replicas must start from the same state (nn.DataParallel re-broadcasts on every forward, train.py:197)
         distributed.sync_parameters(model, optimizer)
 
@@ -135,7 +134,7 @@ class TrainingStep(object):
             need = int(lib.endo_loss_head_workspace_floats(n, h, w))
             if self._head_ws is None or self._head_ws.numel() < need or self._head_ws.device != pred.device:
                 self._head_ws = torch.empty(need, dtype=torch.float32, device=pred.device)
-            losses_t = torch.empty(3, dtype=torch.float32, device=pred.device)
+            losses_t = torch.empty(4, dtype=torch.float32, device=pred.device)          # total, dcl, sfl, guard flag
             grad_pred = torch.empty_like(pred)
             f = lambda key: _lib.ptr(_lib.dev_f32(batch[key], key))
             pose = lambda key, cols: _lib.ptr(_lib.dev_f32(batch[key], key).reshape(n, cols))
@@ -156,38 +155,106 @@ class TrainingStep(object):
                 self.model._run_backward(x, tape, grad_pred, self.model.training, 2)
 
     def __call__(self, batch, lr=None):
+        """One iteration.  Nothing in it waits for the host: the non-finite-loss guard (train.py:317-322) is a flag the loss head writes on
+        the device, summed over ranks inside the gradient all-reduce and read by the optimizer kernel, which then leaves parameters and
+        momentum untouched -- the reference's guarded branch also runs backward() and a step() that changes nothing.  Returns a
+        ``StepOutput``: a mapping with the keys "loss", "dcl", "sfl", "grad_norm", "skipped" whose first access makes the one
+        device-to-host read of the step (the reference's ``loss.item()``, train.py:317) -- a training loop that reads the PREVIOUS
+        iteration's output after launching the current one never idles the GPU."""
         if lr is not None:
             for group in self.optimizer.param_groups:
                 group["lr"] = lr
-        if self.fused_head:
-            # the previous iteration's gradients were consumed by its optimizer step: clear the flat buffer now, ahead of the
-            # host synchronisation below, so that the first backward kernel follows the guard without a memset in between
-            self.optimizer.zero_grad()
-            losses_t, x, tape, pred, grad_pred = self._fused_iteration(batch)
-            host = losses_t.tolist()                  # the reference syncs here too (train.py:317)
-            value = host[0]
-            bad = math.isnan(value) or math.isinf(value)
-            if distributed.world_size() > 1:
-                flag = torch.tensor([1.0 if bad else 0.0], device=pred.device)
-                bad = bool(distributed.agree_nonfinite(flag).item() > 0)
-            if bad:
-                return {"loss": value, "dcl": float("nan"), "sfl": float("nan"), "skipped": True}
-            self._fused_backward(x, tape, grad_pred)
-            scale = self.bucket.all_reduce()
-            norm = self.optimizer.step(grad_scale=scale)
-            return {"loss": value, "dcl": losses_t[1], "sfl": losses_t[2], "grad_norm": norm, "skipped": False}
-        loss, dcl, sfl, _ = self.losses(batch)
-        value = loss.item()                       # the reference syncs here too (train.py:317)
-        bad = math.isnan(value) or math.isinf(value)
-        if distributed.world_size() > 1:
-            flag = torch.tensor([1.0 if bad else 0.0], device=loss.device)
-            bad = bool(distributed.agree_nonfinite(flag).item() > 0)
-        if bad:
-            # train.py:317-322 -- with torch >= 2.0 the guarded branch leaves parameters untouched
-            self.optimizer.zero_grad()
-            return {"loss": value, "dcl": float("nan"), "sfl": float("nan"), "skipped": True}
         self.optimizer.zero_grad()
-        loss.backward()
-        scale = self.bucket.all_reduce()
-        norm = self.optimizer.step(grad_scale=scale)
-        return {"loss": value, "dcl": dcl, "sfl": sfl, "grad_norm": norm, "skipped": False}
+        if self.fused_head:
+            losses_t, x, tape, pred, grad_pred = self._fused_iteration(batch)
+            self._fused_backward(x, tape, grad_pred)
+        else:
+            loss, dcl, sfl, _ = self.losses(batch)
+            with torch.no_grad():
+                bad = (~torch.isfinite(loss.detach())).to(torch.float32).reshape(1)
+                losses_t = torch.cat([loss.detach().reshape(1), dcl.detach().reshape(1), sfl.detach().reshape(1), bad]).to(torch.float32)
+            loss.backward()
+        scale, flag = self.bucket.all_reduce(losses_t[3:4])
+        norm = self.optimizer.step(grad_scale=scale, skip_flag=flag)
+        return StepOutput(losses_t, flag, norm, self._readback_slot(losses_t.device))
+
+    def _readback_slot(self, device):
+        """A set of pinned host buffers + an event out of a small ring: the numbers of a step are copied out asynchronously right
+        behind the optimizer kernel, so that reading step k - 1 after launching step k waits for step k - 1 only."""
+        if device.type != "cuda":
+            return None
+        ring = self.__dict__.setdefault("_readback_ring", [])
+        if len(ring) < 8:
+            ring.append(_ReadbackSlot())
+            return ring[-1]
+        self._readback_next = (self.__dict__.get("_readback_next", -1) + 1) % len(ring)
+        slot = ring[self._readback_next]
+        slot.release()          # an output issued 8 steps ago and never read takes its values now (its copy finished long ago)
+        return slot
+
+
+class _ReadbackSlot(object):
+    def __init__(self):
+        self.losses = torch.empty(4, dtype=torch.float32).pin_memory()
+        self.flag = torch.empty(1, dtype=torch.float32).pin_memory()
+        self.norm = torch.empty(1, dtype=torch.float64).pin_memory()
+        self.event = torch.cuda.Event()
+        self.owner = None
+
+    def release(self):
+        owner = self.owner() if self.owner is not None else None
+        if owner is not None:
+            owner._read()
+        self.owner = None
+
+
+class StepOutput(object):
+    """What one TrainingStep call produced: [total, dcl, sfl] losses, the guard flag after the ranks' consensus and the pre-clip
+    gradient norm, copied to pinned host buffers asynchronously right behind the step's last kernel (three copies of a few bytes, no
+    kernel).  Read like the dict older versions returned; the first read waits for THOSE copies, not for whatever was queued after
+    them.  "loss" is a float; "dcl" / "sfl" / "grad_norm" are 0-dim host tensors (NaN for a skipped step's terms, as before);
+    "skipped" is a bool."""
+
+    def __init__(self, losses, flag, norm, slot):
+        import weakref
+        self._host = None
+        self._slot = slot
+        if slot is None:          # host tensors (CPU tests of the glue)
+            self._vals = (losses, flag, norm)
+        else:
+            slot.losses.copy_(losses, non_blocking=True)
+            slot.flag.copy_(flag.reshape(1), non_blocking=True)
+            slot.norm.copy_(norm.reshape(1), non_blocking=True)
+            slot.event.record()
+            slot.owner = weakref.ref(self)
+
+    def _read(self):
+        if self._host is None:
+            if self._slot is not None:
+                self._slot.event.synchronize()
+                losses, flag, norm = self._slot.losses.tolist(), self._slot.flag.tolist(), self._slot.norm.tolist()
+                self._slot.owner = None
+                self._slot = None
+            else:
+                losses, flag, norm = (t.reshape(-1).tolist() for t in self._vals)
+                self._vals = None
+            skipped = flag[0] != 0.0
+            nan = float("nan")
+            self._host = {"loss": losses[0], "dcl": torch.tensor(nan if skipped else losses[1]), "sfl": torch.tensor(nan if skipped else losses[2]),
+                          "grad_norm": torch.tensor(norm[0], dtype=torch.float64), "skipped": skipped}
+        return self._host
+
+    def __getitem__(self, key):
+        return self._read()[key]
+
+    def __contains__(self, key):
+        return key in ("loss", "dcl", "sfl", "grad_norm", "skipped")
+
+    def keys(self):
+        return self._read().keys()
+
+    def items(self):
+        return self._read().items()
+
+    def __repr__(self):
+        return "StepOutput(%r)" % (self._read(),)

@@ -37,8 +37,11 @@ extern "C" {
  * endo_jpeg_*, endo_point_brightness).
  * 3: round 3 -- kernel-form / precision options move from the process to the network handle: endo_net_set_option /
  * endo_net_get_option REPLACE endo_set_option and endo_set_wgrad_overlap (removed; no environment defaults any more);
- * adds endo_warp_consistency and endo_warp_fallback_blocks. */
-#define ENDO_ABI_VERSION 4
+ * adds endo_warp_consistency and endo_warp_fallback_blocks.
+ * 4: round 3 -- the 16-bit-storage family (endo_net16_*, endo_net16h_*, endo_bf16_*, endo_f16_*).
+ * 5: round 4 -- the non-finite-loss guard moves onto the device: endo_loss_head writes a FOURTH float (the flag),
+ * endo_sgd_clip_step takes a `skip_flag` device pointer; endo_net16_offset what = 7. */
+#define ENDO_ABI_VERSION 5
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
 const char* endo_error_string(int code);
@@ -137,10 +140,12 @@ int endo_scale_inv_bwd(const float* grad_loss, const float* pred, const float* g
  * masking, sparse-flow loss, depth warping both ways, depth-consistency loss, weighted sum) AND its backward down to
  * d loss / d prediction, composed from the entry points above (same kernels, same arithmetic; the modules remain for callers
  * that want the pieces).  pred_*: n x 1 x H x W network outputs; the other inputs are the batch tensors of train.py:245-270
- * (sparse flows n x 2 x H x W; t n x 3, R / K n x 9).  losses: 3 fp32 on the device = total, depth-consistency, sparse-flow
- * (weights applied: w * 0.5 * (term_1 + term_2)).  grad_pred_*: n x 1 x H x W, written.  workspace: 16-byte aligned,
- * endo_loss_head_workspace_floats(n, h, w) floats.  The caller reads losses[0] for the non-finite guard (train.py:317) and
- * then feeds grad_pred_* to endo_net_bwd.
+ * (sparse flows n x 2 x H x W; t n x 3, R / K n x 9).  losses: FOUR fp32 on the device = total, depth-consistency, sparse-flow
+ * (weights applied: w * 0.5 * (term_1 + term_2)) and the guard flag of train.py:317 (1.0 when the total is NaN / Inf, else 0.0).
+ * grad_pred_*: n x 1 x H x W, written.  workspace: 16-byte aligned, endo_loss_head_workspace_floats(n, h, w) floats.  The caller
+ * feeds grad_pred_* to endo_net_bwd without waiting for the host and hands &losses[3] (or its all-reduced sum) to
+ * endo_sgd_clip_step as `skip_flag`: the reference's guarded branch also runs backward() and then a step() that changes nothing
+ * (train.py:318-321).
  * ------------------------------------------------------------------------------------------- */
 int64_t endo_loss_head_workspace_floats(int n, int h, int w);
 int endo_loss_head(const float* pred_1, const float* pred_2, const float* boundaries,
@@ -212,6 +217,11 @@ int endo_net_groups(const endo_net* net);
  *                            (v_mfma_f32_16x16x16_bf16; fp32 accumulation, fp32 tensors in memory) -- the mixed-precision mode of
  *                            BASELINE configs[2], with its own tolerance; default 0 = fp32 operands.
  *                            Development values 2 * mask (mask bit 0 weight gradients, 1 forward, 2 data gradients) select families
+ *   ENDO_OPT_MFMA_X3         the SAME function as fp32 operands, on the bf16 matrix cores: a bit mask (1 weight gradients, 2 forward, 4 data
+ *                            gradients) of the dense layers' kernel families that evaluate their fp32 products as three-term bf16 splits
+ *                            (v = hi + mid + lo exactly; six exact bf16 products per fp32 product, fp32 accumulation; csrc/common.h
+ *                            split_bf16x8) -- fp32 operands and fp32-level accuracy (held to the fp32 bounds by the parity tests) at
+ *                            6 / 16 of the fp32 matrix instructions' issue time.  Ignored where ENDO_OPT_MFMA_BF16 selects rounded operands.
  *   ENDO_OPT_WGRAD_OVERLAP   endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient
  *                            chain and joined before it returns: 1 (default); 0 puts them back in line on the
  *                            caller's stream (clean per-kernel timings) */
@@ -221,7 +231,8 @@ int endo_net_groups(const endo_net* net);
 #define ENDO_OPT_WINO_MIN_TILES 3
 #define ENDO_OPT_MFMA_BF16 4
 #define ENDO_OPT_WGRAD_OVERLAP 5
-#define ENDO_OPT_COUNT 6
+#define ENDO_OPT_MFMA_X3 6
+#define ENDO_OPT_COUNT 7
 int endo_net_set_option(endo_net* net, int option_id, int value);
 int endo_net_get_option(const endo_net* net, int option_id);
 int64_t endo_net_group_stride(const endo_net* net);
@@ -267,10 +278,12 @@ int64_t endo_net_tape_offset(const endo_net* net, int what, int index);
  * grads are scaled in place by grad_scale (1/world after the all-reduce) and then by the clip
  * coefficient min(1, max_norm / (norm + 1e-6)); momentum buf = mu * buf + g; p -= lr * buf.
  * first_step != 0: buf = g.  norm_out: 2 fp64 [sum of squares, pre-clip global L2 norm], written by the call.
+ * skip_flag: null, or one fp32 on the device -- when it is non-zero (the non-finite-loss guard of train.py:317-322, endo_loss_head's
+ * losses[3], summed over ranks by the gradient all-reduce) parameters and momentum are left untouched; norm_out is still written.
  * ------------------------------------------------------------------------------------------- */
 int endo_sgd_clip_step(float* params, float* grads, float* momentum, double* norm_out,
                        int64_t count, float lr, float mu, float max_norm, float grad_scale,
-                       int first_step, void* stream);
+                       int first_step, const float* skip_flag, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Sparse SfM scatter -- reference utils.py:460-612 (get_torch_training_data) for a batch of pairs of ONE
@@ -418,7 +431,7 @@ int endo_f16_pack_nhwc(const float* x, void* out, int n, int c, int h, int w, in
 int endo_f16_unpack_nhwc(const void* in, float* x, int n, int c, int h, int w, int t, int blk, int ic0, void* stream);
 /* byte offsets into the tape (what 0: final pre-activation fp32; 1: (mean, rstd) of BatchNorm `index` in module order; 2: max-pool
  * codes of transition down `index` ([n][h / 2][w / 2][cout] bytes); 3: level buffer `index`) or the backward workspace (4: gradient
- * buffer of level `index`); 5: channels of level buffer `index`.  Level buffers: [n][t / 32][h][w][32] bf16, channels [0, S) the
+ * buffer of level `index`); 5: channels of level buffer `index`; 7: bytes between two sample groups' (mean, rstd) tables.  Level buffers: [n][t / 32][h][w][32] bf16, channels [0, S) the
  * down path, [S, S + 48) the transition-up output, [S + 48, S + 96) the up block's maps (S = 96 + 48 level; bottleneck: 288 + 48). */
 int64_t endo_net16_offset(const endo_net16* net, int what, int index);
 int endo_net16_bwd(endo_net16* net, const float* params, const void* tape, const float* grad_out, float* grads, void* ws, int training,

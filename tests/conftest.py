@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "bench: timing prints without assertions on speed (run by hand with -m bench on a GPU box; not part of -m gpu)")
 
 
 @pytest.fixture(scope="session")

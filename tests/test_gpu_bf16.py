@@ -93,60 +93,16 @@ def test_bf16_conv_against_fp64(case, blk):
     assert float((s - want).abs().max() / want.abs().max()) <= 1e-5
 
 
-def test_bf16_conv_dense_layer_timing():
-    """Not a pass / fail performance gate: prints the time of the widest dense layer of the network (level 0, Cin = 180 -> 12, 16
-    samples of 256 x 320) in the bf16-storage brick next to the fp32 Winograd kernel's 470 us (profiles/r03_j_kernel_stats_by_grid.txt),
-    and checks the result against fp64 on a sub-block."""
-    lib = ea._lib.load()
-    n, h, w, t, ic0, cin, cout, oc0 = 16, 256, 320, 192, 0, 180, 12, 180
-    g = torch.Generator(device=dev()).manual_seed(3)
-    blk = 32                                       # the level buffers' layout: [n][t / 32][h][w][32]
-    xin = (torch.rand(n * h * w * t, device=dev(), generator=g) * 2 - 1).to(torch.bfloat16)
-    weight = torch.randn((cout, cin, 3, 3), device=dev(), generator=g) * (2.0 / (cin * 9)) ** 0.5
-    bn = torch.stack([torch.rand(cin, device=dev(), generator=g) + 0.5, torch.rand(cin, device=dev(), generator=g) * 0.2 - 0.1], dim=1).contiguous()
-    bias = torch.zeros(cout, device=dev())
-    wl = torch.empty(int(lib.endo_bf16_conv_weight_elems(cout, cin, 3)), dtype=torch.bfloat16, device=dev())
-    assert lib.endo_bf16_conv_weights(weight.data_ptr(), cout, cin, 3, wl.data_ptr(), None) == 0
-    sums = torch.zeros((cout, 2), dtype=torch.float64, device=dev())
-
-    def run():
-        return lib.endo_bf16_conv(xin.data_ptr(), t, blk, ic0, cin, bn.data_ptr(), wl.data_ptr(), bias.data_ptr(), xin.data_ptr(), t, blk, oc0, cout,
-                                  sums.data_ptr(), n, h, w, 3, 0, None)
-    for _ in range(3):
-        assert run() == 0
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
-    gb = n * h * w * (cin + cout) * 2 / 1e9
-    print("bf16-storage dense layer, level 0, Cin 180 -> 12, 16 x 256 x 320: %.1f us = %.2f TB/s of algorithmic bytes, %.1f TFLOP/s" % (
-        us, gb / us * 1e3, 2.0 * n * h * w * cin * cout * 9 / us / 1e6))
-    # correctness on the first sample's top-left block
-    y = torch.empty((1, cout, h, w), dtype=torch.float32, device=dev())
-    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), y.data_ptr(), 1, cout, h, w, t, blk, oc0, None) == 0
-    xa = torch.empty((1, cin, h, w), dtype=torch.float32, device=dev())
-    assert lib.endo_bf16_unpack_nhwc(xin.data_ptr(), xa.data_ptr(), 1, cin, h, w, t, blk, ic0, None) == 0
-    x0 = xa[:, :, :40, :40].cpu()
-    ref = reference(x0, 0, cin, weight.cpu(), bias.cpu(), bn.cpu(), 3, 0)[0, :, :32, :32]
-    err = float((y[0, :, :32, :32].cpu().double() - ref).abs().max() / ref.abs().max())
-    assert err <= 6e-3, err
-
-
 # ---------------------------------------------------------------------------------------------
 # the whole forward pass over bf16 level buffers
 # ---------------------------------------------------------------------------------------------
-BF16_STORAGE_FWD_TOL = 2e-2          # depth against the fp64 oracle, max error / max depth; measured 6e-3 .. 1e-2 (printed by the test)
+BF16_STORAGE_FWD_TOL = 1.5e-2        # depth against the fp64 oracle, max error / max depth; measured 6.1e-3 .. 9.9e-3 (printed by the test); relative L2 4.7e-3 -> 7e-3
 
 
-FP16_STORAGE_FWD_TOL = 3e-3          # the same family over IEEE half (11 significant bits): measured 8e-4 .. 1.3e-3
+FP16_STORAGE_FWD_TOL = 2e-3          # the same family over IEEE half (11 significant bits): measured 8.2e-4 .. 1.34e-3; relative L2 5.9e-4 -> 9e-4
 
 
-@pytest.mark.parametrize("shape,storage", [((2, 64, 96), "bf16"), ((1, 128, 160), "bf16"), ((2, 256, 320), "bf16"), ((1, 128, 160), "fp16"),
-                                           ((2, 256, 320), "fp16")], ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
+@pytest.mark.parametrize("shape,storage", [((2, 64, 96), "bf16"), ((1, 128, 160), "bf16"), ((1, 128, 160), "fp16")], ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_bf16_storage_forward(shape, storage):
     """FCDenseNet57.forward_bf16_storage (endo_net16_fwd; reference models.py:171-187) against the fp64 oracle and against the fp32
     HIP path on the same parameters and input: training mode (batch statistics; the running statistics after the call against the
@@ -183,7 +139,7 @@ def test_bf16_storage_forward(shape, storage):
         print("%s-storage forward %s %s: max err / max depth %.2e (fp32 path %.1e), relative L2 %.2e" % (storage, shape, mode, e16, e32, rel_l2))
         assert torch.isfinite(y16).all()
         assert e16 <= (FP16_STORAGE_FWD_TOL if storage == "fp16" else BF16_STORAGE_FWD_TOL), (mode, e16)
-        assert rel_l2 <= 2e-2, (mode, rel_l2)
+        assert rel_l2 <= (9e-4 if storage == "fp16" else 7e-3), (mode, rel_l2)
         if mode == "train":
             sd32, sd16 = ref32.state_dict(), bf.state_dict()
             worst = 0.0
@@ -196,30 +152,6 @@ def test_bf16_storage_forward(shape, storage):
             assert worst <= 5e-2
 
 
-def test_bf16_storage_forward_timing():
-    """Prints (no gate) the forward time of the benchmark batch -- 16 frames of 256 x 320, one call -- over bf16 level buffers next to
-    the fp32 path's grouped pair forward (5.9 ms of a training step, profiles/r03_i_stream_timeline.txt)."""
-    n, h, w = 16, 256, 320
-    m = ea.FCDenseNet57(1)
-    ea.utils.kaiming_weight_zero_bias(m, mode="fan_in", activation_mode="relu", distribution="normal")
-    m = m.to(dev()).train()
-    x = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
-    res = {}
-    for name, fn in (("bf16 storage", lambda: m.forward_bf16_storage(x)), ("fp32", lambda: m.forward_pair(x[:8], x[8:]))):
-        with torch.no_grad():
-            for _ in range(3):
-                fn()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / 10
-    print("forward of 16 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (res["bf16 storage"], res["fp32"]))
-
-
 # ---------------------------------------------------------------------------------------------
 # the backward pass over bf16 level buffers
 # ---------------------------------------------------------------------------------------------
@@ -228,9 +160,15 @@ def test_bf16_storage_forward_timing():
 # parameters in relative L2 5e-3..1.1e-2 (2 x 256 x 320, training mode: 1.03e-2; with round-to-nearest stores it was 7.2e-2 there, DESIGN.md
 # 4.14).  Conv BIASES in training mode are sums over all pixels of gradient maps whose mean BatchNorm has removed: <= 7.7e-2 of the tensor's
 # largest entry; every bias whose gradient is mathematically zero is exactly zero.
-BF16_STORAGE_GRAD_TOL = 5e-2                 # inference mode
-BF16_STORAGE_GRAD_TOL_TRAIN = 1e-1           # training mode
-BF16_STORAGE_BIAS_GRAD_TOL_TRAIN = 1.5e-1
+BF16_STORAGE_GRAD_TOL = 4.8e-2               # inference mode (measured 3.2e-2)
+BF16_STORAGE_GRAD_TOL_TRAIN = 1.0e-1         # training mode (measured 6.76e-2: bottleneck layer 3 weight at 2 x 64 x 96)
+BF16_STORAGE_BIAS_GRAD_TOL_TRAIN = 1.25e-1    # measured 8.4e-2 (1 x 256 x 320, denseBlocksUp.2.layers.1.conv.bias)
+BF16_STORAGE_L2_TOL = 1.8e-2                 # measured 1.23e-2 (2 x 64 x 96), 1.15e-2 (1 x 256 x 320)
+# half storage, the same quantities: weights / BatchNorm 1.01e-2 (training), 3.7e-3 (inference); biases 9.5e-3; relative L2 1.61e-3
+FP16_STORAGE_GRAD_TOL = 5.5e-3
+FP16_STORAGE_GRAD_TOL_TRAIN = 1.5e-2
+FP16_STORAGE_BIAS_GRAD_TOL_TRAIN = 1.45e-2
+FP16_STORAGE_L2_TOL = 2.4e-3
 
 
 def _grads_by_name(model):
@@ -238,8 +176,8 @@ def _grads_by_name(model):
 
 
 @pytest.mark.parametrize("shape,mode,storage", [((2, 64, 96), "train", "bf16"), ((1, 128, 160), "train", "bf16"), ((2, 64, 96), "eval", "bf16"),
-                                                ((1, 128, 160), "eval", "bf16"), ((2, 256, 320), "train", "bf16"),          # the benchmark's frame size
-                                                ((1, 128, 160), "train", "fp16"), ((1, 128, 160), "eval", "fp16"), ((2, 256, 320), "train", "fp16")],
+                                                ((1, 128, 160), "eval", "bf16"), ((1, 128, 160), "train", "fp16"), ((1, 128, 160), "eval", "fp16")],
+                         # (the benchmark's frame size: test_16bit_pair_at_benchmark_batch, test_16bit_backward_partial_buffer_shapes)
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_bf16_storage_backward(shape, mode, storage):
     """Parameter gradients of FCDenseNet57.forward_bf16_storage (endo_net16_bwd) against the fp64 oracle evaluated (a) with the SAME
@@ -297,45 +235,13 @@ def test_bf16_storage_backward(shape, mode, storage):
     worst, worst_name = rows[0][0], rows[0][1]
     print(storage + "-storage backward %s %s: forward vs the rounding oracle %.2e; worst tensor %s max err / max |g| = %.2e; all parameters relative L2 %.2e" % (
         shape, mode, e_fwd, worst_name, worst, (l2_num / l2_den) ** 0.5))
-    assert e_fwd <= 8e-3, e_fwd
+    assert e_fwd <= (1.1e-3 if half else 7.7e-3), e_fwd          # measured 7.0e-4 / 5.15e-3
+    tols = (FP16_STORAGE_BIAS_GRAD_TOL_TRAIN, FP16_STORAGE_GRAD_TOL_TRAIN, FP16_STORAGE_GRAD_TOL) if half else (
+        BF16_STORAGE_BIAS_GRAD_TOL_TRAIN, BF16_STORAGE_GRAD_TOL_TRAIN, BF16_STORAGE_GRAD_TOL)
     for err, k, _, _ in rows:
         loose = mode == "train" and (k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias")
-        assert err <= (BF16_STORAGE_BIAS_GRAD_TOL_TRAIN if loose else (BF16_STORAGE_GRAD_TOL_TRAIN if mode == "train" else BF16_STORAGE_GRAD_TOL)), (k, err)
-    assert (l2_num / l2_den) ** 0.5 <= 2.5e-2
-
-
-def test_bf16_storage_step_timing():
-    """Prints (no gate) forward + backward of the benchmark batch (two calls of 8 frames of 256 x 320, as a training step makes them)
-    over bf16 level buffers next to the fp32 path's grouped pair."""
-    n, h, w = 8, 256, 320
-    m = ea.FCDenseNet57(1)
-    ea.utils.kaiming_weight_zero_bias(m, mode="fan_in", activation_mode="relu", distribution="normal")
-    m = m.to(dev()).train()
-    x1 = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
-    x2 = torch.rand((n, 3, h, w), device=dev()) * 2 - 1
-    g = torch.randn((n, 1, h, w), device=dev())
-
-    def step16():
-        y1 = m.forward_bf16_storage(x1); y2 = m.forward_bf16_storage(x2)
-        torch.autograd.backward([y1, y2], [g, g])
-
-    def step32():
-        y1, y2 = m.forward_pair(x1, x2)
-        torch.autograd.backward([y1, y2], [g, g])
-    res = {}
-    for name, fn in (("bf16 storage", step16), ("fp32", step32)):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        res[name] = e0.elapsed_time(e1) / 5
-    print("network forward + backward, two batches of 8 x 256 x 320, training mode: bf16 storage %.3f ms, fp32 (grouped pair) %.3f ms" % (
-        res["bf16 storage"], res["fp32"]))
+        assert err <= (tols[0] if loose else (tols[1] if mode == "train" else tols[2])), (k, err)
+    assert (l2_num / l2_den) ** 0.5 <= (FP16_STORAGE_L2_TOL if half else BF16_STORAGE_L2_TOL)
 
 
 def test_bf16_storage_pair_as_two_groups():
@@ -384,19 +290,26 @@ def test_bf16_storage_pair_as_two_groups():
     worst_b = max((v, k) for k, v in err.items() if is_bias(k))
     worst_w = max((v, k) for k, v in err.items() if not is_bias(k))
     print("two groups vs two calls: worst weight / BatchNorm tensor %s %.2e, worst bias %s %.2e" % (worst_w[1], worst_w[0], worst_b[1], worst_b[0]))
-    assert worst_w[0] <= 3e-2, worst_w          # measured 1.2e-2 (a level-5 tensor: 6 pixels per sample at this size)
-    assert worst_b[0] <= 6e-2, worst_b
+    assert worst_w[0] <= 1.8e-2, worst_w          # measured 1.18e-2 (a level-5 tensor: 6 pixels per sample at this size)
+    assert worst_b[0] <= 2.7e-2, worst_b          # measured 1.78e-2
 
 
-@pytest.mark.parametrize("storage,tol", [("bf16", 2e-2), ("fp16", 2e-3)])
-def test_16bit_training_step_against_oracle(storage, tol):
+# one training step against the oracle's: measured (printed) loss 1.48e-4 / 1.52e-5, gradient norm 8.3e-3 / 3.0e-3, parameter update relative
+# L2 0.188 / 0.058 (off the pattern: a few ReLU bits differ)
+# (terms: dcl 6.3e-4 / 8.6e-5, sfl 1.8e-4 / 1.2e-5)
+STEP16_BOUNDS = {"bf16": dict(loss=2.3e-4, terms=9.5e-4, norm=1.25e-2, update=0.28), "fp16": dict(loss=3.0e-5, terms=1.3e-4, norm=4.5e-3, update=0.087)}
+
+
+@pytest.mark.parametrize("storage", ["bf16", "fp16"])
+def test_16bit_training_step_against_oracle(storage):
     """One TrainingStep of the 16-bit-storage modes (both frames as two sample groups, fused loss head, clipping + SGD; what bench.py
     --config 2 / 4 times) against the CPU oracle's training iteration (reference train.py:272-328) on the same batch: loss, its two terms
-    and the gradient norm.  Bounds of the modes, not of fp32 rounding: measured 1.5e-4 / 1.5e-5 (loss) and 8e-3 / 3e-3 (gradient norm)."""
+    and the gradient norm.  Bounds of the modes, not of fp32 rounding (STEP16_BOUNDS: 1.5 x the measured values)."""
     import sys, os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from oracle import network as onet, train_step as ostep
     n, h, w = 1, 64, 96
+    b = STEP16_BOUNDS[storage]
     state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(7), 8))
     state0 = {k: v.clone() for k, v in state.items()}
     batch = ea.synthetic.make_batch(n, h, w, seed=3, sparse_points=300)
@@ -408,12 +321,13 @@ def test_16bit_training_step_against_oracle(storage, tol):
     out = step({k: v.to(dev()) for k, v in batch.items()}, lr=1.0e-3)
     torch.cuda.synchronize()
     rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
-    print("%s-storage training step: loss %.6f (oracle %.6f), gradient norm %.4f (oracle %.4f)" % (storage, out["loss"], float(ref["loss"]),
-                                                                                                   float(out["grad_norm"]), float(ref["grad_norm"])))
+    print("%s-storage training step: loss %.6f (oracle %.6f, rel %.2e), dcl rel %.2e, sfl rel %.2e, gradient norm %.4f (oracle %.4f, rel %.2e)" % (
+        storage, out["loss"], float(ref["loss"]), rel(out["loss"], ref["loss"]), rel(out["dcl"], ref["dcl"]), rel(out["sfl"], ref["sfl"]),
+        float(out["grad_norm"]), float(ref["grad_norm"]), rel(out["grad_norm"], ref["grad_norm"])))
     assert not out["skipped"]
-    assert rel(out["loss"], ref["loss"]) <= tol
-    assert rel(out["dcl"], ref["dcl"]) <= 5 * tol and rel(out["sfl"], ref["sfl"]) <= tol
-    assert rel(out["grad_norm"], ref["grad_norm"]) <= 5 * tol
+    assert rel(out["loss"], ref["loss"]) <= b["loss"]
+    assert rel(out["dcl"], ref["dcl"]) <= b["terms"] and rel(out["sfl"], ref["sfl"]) <= b["terms"]
+    assert rel(out["grad_norm"], ref["grad_norm"]) <= b["norm"]
     # the parameters moved: compare the largest tensors' updates with the oracle's (direction and size)
     after = m.state_dict()
     num = den = 0.0
@@ -422,7 +336,7 @@ def test_16bit_training_step_against_oracle(storage, tol):
         d_ref = (state[k].double() - state0[k].double())
         num += float(((d_hip - d_ref) ** 2).sum()); den += float((d_ref ** 2).sum())
     print("   parameter update vs the oracle's: relative L2 %.2e" % ((num / den) ** 0.5))
-    assert (num / den) ** 0.5 <= (0.35 if storage == "bf16" else 0.15)          # off-pattern: a few ReLU bits differ (tests/test_gpu_parity.py)
+    assert (num / den) ** 0.5 <= b["update"]
 
 
 def test_fp16_gradient_scale_is_invisible():
@@ -452,10 +366,10 @@ def test_fp16_gradient_scale_is_invisible():
         worst = max((float((grads[s][k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), floor), k) for k in ref)
         print("fp16 storage, output gradient x %.0e: worst parameter-gradient tensor %s differs by %.2e of its largest entry" % (s, worst[1], worst[0]))
         assert all(torch.isfinite(v).all() for v in grads[s].values())
-        assert worst[0] <= 2e-2, worst
+        assert worst[0] <= 7.7e-3, worst          # measured 5.1e-3
 
 
-@pytest.mark.parametrize("storage,tol,min_cos", [("bf16", 2e-2, 0.85), ("fp16", 4e-3, 0.98)])
+@pytest.mark.parametrize("storage,tol,min_cos", [("bf16", 1.3e-2, 0.866), ("fp16", 3.0e-3, 0.9943)])          # measured 8.6e-3 / 0.9104, 2.0e-3 / 0.9962
 def test_16bit_training_step_at_512x640_tracks_fp32(storage, tol, min_cos):
     """BASELINE configs[3]'s shape (512 x 640, network_downsampling 64) through the 16-bit-storage modes: 40 x 20 tiles at level 0, the
     8-row tiles of the new-map data-gradient blocks down to a 16 x 20 level.  No oracle at this size: the check is against this library's
@@ -519,3 +433,222 @@ def test_prof_sampling_times_one_launch_in_n():
     print("launches seen / timed:", counts)
     assert counts[1][0] == counts[1][1] > 0 and counts[1][2] > 0.0
     assert counts[7][0] == counts[1][0] and counts[7][1] == (counts[7][0] + 6) // 7 and counts[7][2] > 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# the workloads bench.py --config 2 / 4 time (BASELINE configs[2] / [4], per GPU): two sample groups of 8 x 256 x 320
+# ---------------------------------------------------------------------------------------------
+def _oracle_pair_grads(state, xs, cots, patterns, quant):
+    """fp32 oracle (fp64 at this size costs minutes and 40 GB, as in test_full_size_pair_backward_on_pattern), frame by frame, each
+    with its own BatchNorm statistics, the mode's roundings in the forward direction and the pass's own pattern: summed gradients."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    names = onet.trainable_names()
+    total, ys = None, []
+    for x, cot, pat in zip(xs, cots, patterns):
+        st = {k: v.clone() for k, v in state.items()}
+        for nm in names:
+            st[nm].requires_grad_(True)
+        y = onet.forward(st, x, training=True, quant=quant, pattern=pat)
+        grads = torch.autograd.grad((y * cot).sum(), [st[nm] for nm in names])
+        total = list(grads) if total is None else [a + b for a, b in zip(total, grads)]
+        ys.append(y.detach())
+        del y, grads, st
+    return dict(zip(names, total)), ys
+
+
+# measured on the benchmark batch (gpurun_out r4a, printed by the test) -> bound (<= 1.5 x measured):
+#   bf16: forward 4.60e-3 of the largest depth; worst weight / BatchNorm tensor 4.82e-2, worst conv bias 6.34e-2, all parameters relative L2 9.37e-3
+#   fp16: forward 5.47e-4; worst tensor 5.18e-3, worst bias 1.08e-2, relative L2 1.29e-3
+PAIR16_BOUNDS = {"bf16": dict(fwd=6.9e-3, tensor=7.2e-2, bias=9.5e-2, l2=1.4e-2), "fp16": dict(fwd=8.2e-4, tensor=7.8e-3, bias=1.6e-2, l2=1.9e-3)}
+
+
+@pytest.mark.parametrize("storage", ["bf16", "fp16"])
+def test_16bit_pair_at_benchmark_batch(storage):
+    """The launch bench.py --config 2 / 4 times: ONE grouped call over 2 x 8 frames of 256 x 320 (endo_net16_fwd / _bwd with two sample
+    groups: the 512-block weight-gradient tile walk over 16 samples, two BatchNorm tables per block, the 0.85 GB workspace), forward and
+    all 210 parameter gradients against the oracle with the mode's roundings on the pass's own pattern -- as
+    test_full_size_pair_backward_on_pattern does for the fp32 family (reference models.py:171-187, train.py:276-277)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    from device_pattern16 import pattern_from_tape
+    n, h, w = 8, 256, 320
+    half = storage == "fp16"
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(37)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    if half:
+        cots = [c * 1.0e-6 for c in cots]          # the per-pixel size of a mean loss's gradient: only the backward's own scale keeps it in half's range
+    m = ea.FCDenseNet57(1)
+    m.load_state_dict(state)
+    m = m.to(dev()).train()
+    x = torch.cat(xs).to(dev())
+    with torch.no_grad():
+        ys, tape = m._run_forward16(x, 2, half)
+        patterns = pattern_from_tape(m, tape, n, h, w, half, groups=2)
+        m._run_backward16(tuple(x.shape), tape, torch.cat(cots).to(dev()), True, 2, half)
+    torch.cuda.synchronize()
+    got = {k: v.double().cpu() for k, v in _grads_by_name(m).items()}
+    ys = ys.double().cpu()
+    del tape
+    want, yo = _oracle_pair_grads(state, xs, cots, patterns, onet.fp16_ste if half else onet.bf16_ste)
+    b = PAIR16_BOUNDS[storage]
+    e_fwd = max(float((ys[g * n:(g + 1) * n] - yo[g].double()).abs().max() / yo[g].abs().max()) for g in range(2))
+    floor = 1e-3 * max(float(v.abs().max()) for v in want.values())
+    is_bias = lambda k: k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias"
+    rows, l2n, l2d = [], 0.0, 0.0
+    for k, gw in want.items():
+        gw = gw.double()
+        assert torch.isfinite(got[k]).all(), k
+        rows.append((float((got[k] - gw).abs().max()) / max(float(gw.abs().max()), floor), k))
+        l2n += float(((got[k] - gw) ** 2).sum()); l2d += float((gw ** 2).sum())
+    rows.sort(reverse=True)
+    worst_b = max(r for r in rows if is_bias(r[1]))
+    worst_w = max(r for r in rows if not is_bias(r[1]))
+    print("%s storage, 2 x 8 x 256 x 320 in one call: forward %.2e of the largest depth; worst weight / BatchNorm tensor %s %.2e, worst bias %s %.2e; "
+          "all parameters relative L2 %.2e" % (storage, e_fwd, worst_w[1], worst_w[0], worst_b[1], worst_b[0], (l2n / l2d) ** 0.5))
+    assert e_fwd <= b["fwd"], e_fwd
+    assert worst_w[0] <= b["tensor"], worst_w
+    assert worst_b[0] <= b["bias"], worst_b
+    assert (l2n / l2d) ** 0.5 <= b["l2"]
+
+
+@pytest.mark.parametrize("shape,storage", [((1, 256, 320), "bf16"), ((4, 128, 160), "bf16"), ((1, 256, 320), "fp16"), ((4, 128, 160), "fp16")],
+                         ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
+def test_16bit_backward_partial_buffer_shapes(shape, storage):
+    """Shapes at which round 3's workspace sizing (widest layer per level) was SMALLER than the largest weight-gradient partial buffer the
+    backward pass writes: n = 1 at 256 x 320 and n = 4 at 128 x 160 overran it by 73 728 bytes -- in the half family onto the {S, 1 / S}
+    gradient scale, which the reduce kernels then read.  The workspace is sized over every launch now and every launch is checked
+    against it (launch_bf16_wgrad); here the parameter gradients of those shapes against the rounding oracle on the pattern, with the
+    bounds of test_bf16_storage_backward, and an intact guard word behind the workspace."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    from device_pattern16 import pattern_from_tape
+    n, h, w = shape
+    half = storage == "fp16"
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(71), 72))
+    rng = np.random.default_rng(43)
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) * (1.0e-6 if half else 1.0)
+    m = ea.FCDenseNet57(1)
+    m.load_state_dict(state)
+    m = m.to(dev()).train()
+    hnd, _, ws_bytes = m._handle16(n, h, w, 1, half)
+    key = ("fp16" if half else "bf16", n, h, w, 1)
+    m._gradws[key] = torch.full((ws_bytes + 256,), 0x5A, dtype=torch.uint8, device=dev())          # 256 guard bytes behind the workspace
+    with torch.no_grad():
+        y, tape = m._run_forward16(x.to(dev()), 1, half)
+        pattern = pattern_from_tape(m, tape, n, h, w, half)
+        m._run_backward16((n, 3, h, w), tape, g.to(dev()), True, 1, half)
+    torch.cuda.synchronize()
+    assert bool((m._gradws[key][ws_bytes:] == 0x5A).all()), "the backward pass wrote behind its workspace"
+    st64 = {k: (v.double().requires_grad_(k in onet.trainable_names()) if v.is_floating_point() else v.clone()) for k, v in state.items()}
+    y64 = onet.forward(st64, x.double(), training=True, quant=onet.fp16_ste if half else onet.bf16_ste, pattern=pattern)
+    y64.backward(g.double())
+    got = {k: v.double().cpu() for k, v in _grads_by_name(m).items()}
+    floor = 1e-3 * max(float(st64[k].grad.abs().max()) for k in onet.trainable_names())
+    l2n = l2d = 0.0
+    worst = (0.0, "")
+    for k in onet.trainable_names():
+        gw = st64[k].grad
+        assert torch.isfinite(got[k]).all(), k
+        loose = k.endswith("conv.bias") or k.endswith("convTrans.1.bias") or k == "firstconv.bias"
+        err = float((got[k] - gw).abs().max()) / max(float(gw.abs().max()), floor)
+        worst = max(worst, (err, k))
+        assert err <= ((FP16_STORAGE_BIAS_GRAD_TOL_TRAIN if half else BF16_STORAGE_BIAS_GRAD_TOL_TRAIN) if loose else (FP16_STORAGE_GRAD_TOL_TRAIN if half else BF16_STORAGE_GRAD_TOL_TRAIN)), (k, err)
+        l2n += float(((got[k] - gw) ** 2).sum()); l2d += float((gw ** 2).sum())
+    print("%s storage %s: worst tensor %s %.2e, relative L2 %.2e" % (storage, shape, worst[1], worst[0], (l2n / l2d) ** 0.5))
+    assert (l2n / l2d) ** 0.5 <= (FP16_STORAGE_L2_TOL if half else BF16_STORAGE_L2_TOL)          # measured 1.55e-3 / 1.15e-2
+
+
+def test_fp16_storage_step_with_gap_scaled_poses():
+    """BASELINE configs[4] as bench.py --config 4 runs it per GPU: batch 8 x 256 x 320, per-sample frame gaps U{5..30} (poses scaled by
+    gap / 10: reference dataset.py:384-404 with --adjacent_range 5 30) AND fp16 storage -- one TrainingStep against the CPU oracle's
+    training iteration (reference train.py:272-328): loss, its two terms, the gradient norm; the large motion must have sent blocks
+    of the tiled warp kernels down the gather fallback.  The final convolution's bias is shifted by 12 as in the full-size reference
+    fixture (tests/golden/make_golden.py: with 4 the synthetic network's depth comes within 1e-3 of zero at a few pixels, DepthScalingLayer
+    divides by it, and the loss measures those pixels -- 1.8e-2 between this mode and the oracle, 0.47 in the gradient norm, measured in
+    round 4 -- instead of the kernels).  Off the pattern, fp32 oracle without the mode's roundings; bounds = 1.5 x measured."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet, train_step as ostep
+    n, h, w = 8, 256, 320
+    lib = ea._lib.load()
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(83), 84), bias=12.0)
+    state0 = {k: v.clone() for k, v in state.items()}
+    batch = ea.synthetic.make_batch(n, h, w, seed=120, sparse_points=500, gap_scale=(5, 30))
+    m = ea.FCDenseNet57(1)
+    m.load_state_dict(state0)
+    m = m.to(dev()).train()
+    step = ea.train_step.TrainingStep(m, ea.optim.FusedClipSGD(m, lr=1.0e-3), h, w, fp16_storage=True)
+    fwd, bwd = ctypes.c_longlong(), ctypes.c_longlong()
+    assert lib.endo_warp_fallback_blocks(None, None, 1) == 0
+    out = step({k: v.to(dev()) for k, v in batch.items()}, lr=1.0e-3)
+    torch.cuda.synchronize()
+    assert lib.endo_warp_fallback_blocks(ctypes.byref(fwd), ctypes.byref(bwd), 1) == 0
+    ref = ostep.train_iteration(state, {}, batch, 1.0e-3)
+    rel = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-12)
+    print("fp16 storage + gap-scaled poses, 8 x 256 x 320: loss %.7f (oracle %.7f, rel %.1e), dcl rel %.1e, sfl rel %.1e, gradient norm %.5f (oracle %.5f, "
+          "rel %.1e); fallback blocks %d / %d" % (out["loss"], float(ref["loss"]), rel(out["loss"], ref["loss"]), rel(out["dcl"], ref["dcl"]),
+                                                  rel(out["sfl"], ref["sfl"]), float(out["grad_norm"]), float(ref["grad_norm"]),
+                                                  rel(out["grad_norm"], ref["grad_norm"]), fwd.value, bwd.value))
+    assert not out["skipped"] and not ref["skipped"]
+    assert fwd.value > 0 and bwd.value > 0, "the large-motion batch did not exercise the gather fallback of the tiled warp kernels"
+    assert rel(out["loss"], ref["loss"]) <= FP16_GAP_STEP_TOL["loss"]
+    assert rel(out["dcl"], ref["dcl"]) <= FP16_GAP_STEP_TOL["dcl"] and rel(out["sfl"], ref["sfl"]) <= FP16_GAP_STEP_TOL["sfl"]
+    assert rel(out["grad_norm"], ref["grad_norm"]) <= FP16_GAP_STEP_TOL["grad_norm"]
+
+
+# measured (gpurun_out r4b): loss 3.0e-6, dcl 8.8e-6, sfl 2.9e-6, gradient norm 1.2e-3 -> 1.5 x, with a floor of 1e-5 (fp32 rounding of the loss head)
+FP16_GAP_STEP_TOL = {"loss": 1e-5, "dcl": 1.5e-5, "sfl": 1e-5, "grad_norm": 1.8e-3}
+
+
+def test_16bit_modes_descend_like_fp32():
+    """reference train.py:244-328 is a LOOP: 20 iterations on one fixed batch (2 x 128 x 160, the oracle's synthetic state, lr 1e-3 with
+    the clip at 10) through TrainingStep in fp32, bf16 storage and fp16 storage.  No step may be skipped, every loss finite, and the
+    PROGRESS of each mode is measured with one yardstick: the fp32 path's loss (forward only, same batch) of the parameters each mode
+    ends with, against the fp32 loss at the start -- a mode whose gradients pointed elsewhere (cosine 0.91 at 512 x 640) or whose
+    stochastic roundings drifted would gain less than the fp32 run.  (A mode's own loss differs from fp32's by its forward roundings,
+    1.2 % for bf16 at the first iteration: comparing those would measure the forward, not the descent.)"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import network as onet
+    n, h, w, iters = 2, 128, 160, 20
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(7), 8))
+    batch = {k: v.to(dev()) for k, v in ea.synthetic.make_batch(n, h, w, seed=92, sparse_points=800).items()}
+
+    def fp32_loss(model):
+        ruler = ea.train_step.TrainingStep(model, ea.optim.FusedClipSGD(model, lr=0.0), h, w)
+        with torch.no_grad():
+            return float(ruler.losses(batch)[0])          # training-mode forward (batch statistics), no update
+    traj, final32 = {}, {}
+    start32 = None
+    for mode, kw in (("fp32", {}), ("bf16", {"bf16_storage": True}), ("fp16", {"fp16_storage": True})):
+        m = ea.FCDenseNet57(1)
+        m.load_state_dict(state)
+        m = m.to(dev()).train()
+        if start32 is None:
+            start32 = fp32_loss(m)
+            m.load_state_dict(state)          # (the ruler's forward moved the running statistics; they do not enter a training-mode loss)
+        step = ea.train_step.TrainingStep(m, ea.optim.FusedClipSGD(m, lr=1.0e-3), h, w, **kw)
+        outs = [step(batch, lr=1.0e-3) for _ in range(iters)]
+        torch.cuda.synchronize()
+        assert all(not o["skipped"] and np.isfinite(o["loss"]) for o in outs), mode
+        traj[mode] = [o["loss"] for o in outs]
+        final32[mode] = fp32_loss(m)
+        print("%s: own loss %s | fp32 loss of its parameters after %d iterations %.5f (start %.5f)" % (
+            mode, " ".join("%.4f" % v for v in traj[mode][::4]), iters, final32[mode], start32))
+    gain32 = start32 - final32["fp32"]
+    assert gain32 > 0.01 * start32, "the fp32 trajectory itself does not descend: %r" % (traj["fp32"],)
+    for mode in ("bf16", "fp16"):
+        gain = start32 - final32[mode]
+        print("%s storage: fp32-loss gain over %d iterations %.5f = %.3f of the fp32 run's %.5f" % (mode, iters, gain, gain / gain32, gain32))
+        assert abs(gain / gain32 - 1.0) <= DESCENT_TOL[mode], (mode, gain, gain32)
+
+
+# measured (gpurun_out r4b): the fp32 run gains 0.04285 of 1.8623 in 20 iterations; bf16 storage 0.965 of that, fp16 storage 0.996
+DESCENT_TOL = {"bf16": 0.055, "fp16": 0.01}

@@ -503,7 +503,7 @@ BF16_GRAD_TOL = 1e-1      # ... and every parameter gradient, max error / the te
                           # bottleneck and first up block, whose BN normalises over 2 x (2 x 3) ... 2 x (16 x 20) values)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 256, 320)])
+@pytest.mark.parametrize("shape", [(2, 64, 96)])          # (a development mode, bench.py --config 5: the BASELINE workloads are the fp32 and the 16-bit-STORAGE paths)
 def test_bf16_operand_mode_on_pattern(shape):
     """ENDO_OPT_MFMA_BF16 = 1 (the mixed-precision mode behind bench.py --config 5): the dense layers' forward, data-gradient and
     weight-gradient kernels round their MFMA operands to bf16 and accumulate in fp32; tensors in memory, BN statistics, the
@@ -1350,46 +1350,6 @@ def test_warp_consistency_call():
 
 
 BF16_FULL_GRAD_TOL = 1e-1          # measured on MI355X: worst tensor 6.1e-2 (bottleneck.layers.0.conv.weight), median 6.8e-3, depth 9.8e-3
-
-
-def test_bf16_operand_pair_at_benchmark_batch():
-    """The bf16-operand mode at the per-GPU workload bench.py --config 5 times: the grouped pair pass at 2 x 8 x 256 x 320 (16 samples
-    per launch: the n-split weight gradient's bf16 form, the fused bf16 data gradients and the 32x16 forward tiles only these grids
-    select), each frame's depth and the summed parameter gradients against the CPU oracle on the patterns the pass itself took
-    (fp32 oracle, as test_full_size_pair_backward_on_pattern: fp64 at this size costs minutes and 40 GB; its own ~1e-5 is far below
-    the mode's tolerance)."""
-    n, h, w = 8, 256, 320
-    with kernel_options({OPT_MFMA_BF16: 1}):
-        state, model = make_model(58)
-    rng = np.random.default_rng(14)
-    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
-    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
-    model.train()
-    y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
-    patterns = pattern_of(y1, model, n, h, w, groups=2)
-    ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
-    torch.cuda.synchronize()
-    params = dict(model.named_parameters())
-    names = onet.trainable_names()
-    total = None
-    worst_depth = 0.0
-    for x, cot, pat, got in zip(xs, cots, patterns, (y1, y2)):
-        st = {k: v.clone() for k, v in state.items()}
-        for nm in names:
-            st[nm].requires_grad_(True)
-        y = onet.forward(st, x, training=True, pattern=pat)
-        worst_depth = max(worst_depth, rel_err(got, y.detach()))
-        assert_close(got, y.detach(), BF16_FWD_TOL, "bf16 operands at 8x256x320: depth of one frame vs the oracle on the same pattern")
-        grads = torch.autograd.grad((y * cot).sum(), [st[nm] for nm in names])
-        total = list(grads) if total is None else [a + b for a, b in zip(total, grads)]
-        del y, grads, st
-    report = assert_grads_on_pattern(params, dict(zip(names, (t.double() for t in total))), None, BF16_FULL_GRAD_TOL,
-                                     "bf16 operands, 2 x 8x256x320 pair backward")
-    errors = sorted(r[0] for r in report)
-    print("bf16 operands at the benchmark batch: depth err %.2e, gradient errors median %.2e, worst %.2e (%s)" % (
-        worst_depth, errors[len(errors) // 2], errors[-1], max(report)[2]))
-    assert errors[len(errors) // 2] <= 1.5e-2
-    assert errors[-1] > 1e-4, "the bf16 kernels did not run"
 
 
 def test_full_size_pair_backward_on_pattern():

@@ -151,7 +151,7 @@ int main(int argc, char** argv) {
         auto zero = [&](hipStream_t s) { CK(hipMemsetAsync(dw, 0, (size_t)12 * cin * 9 * 4, s)); };
         vs.push_back({"wgrad taps-in-M dma 32x8", [&](hipStream_t s) { zero(s); return launch_wgrad_taps<12, IN_BNRELU>(g, s); }});
         vs.push_back({"wgrad nsplit (library)", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit(g, wscratch, s); }});
-        vs.push_back({"wgrad nsplit, bf16 MFMA operands", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit(g, wscratch, s, true); }});
+        vs.push_back({"wgrad nsplit, bf16 MFMA operands", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit(g, wscratch, s, 1); }});
         vs.push_back({"wgrad nsplit<3> no x loads", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 1>(g, wscratch, passes, s); }});
         vs.push_back({"wgrad nsplit<3> no dY DMA", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 2>(g, wscratch, passes, s); }});
         vs.push_back({"wgrad nsplit<3> no loads at all", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 3>(g, wscratch, passes, s); }});
