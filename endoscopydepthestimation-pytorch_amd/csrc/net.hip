@@ -22,6 +22,7 @@
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
+#include "wgrad_x3_kernels.h"
 #include "wgrad_subpix_kernels.h"
 #include "wino_fwd_kernels.h"
 #include "dgrad_wino_kernels.h"
@@ -769,7 +770,10 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
-    if (wgrad_nsplit_ok(p)) return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, wgrad_mfma_mode(c));
+    if (wgrad_nsplit_ok(p)) {
+        if (wgrad_mfma_mode(c) == 2) return launch_wgrad_x3(p, c.gradws + c.net->wg_scratch_off, c.stream);          // fp32 products as bf16 splits (wgrad_x3_kernels.h)
+        return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, wgrad_mfma_mode(c));
+    }
     if (wgrad_taps_ok(p)) return mfma_bf16_wgrad(c) ? launch_wgrad_taps<12, IN_BNRELU, 1>(p, c.stream) : launch_wgrad_taps<12, IN_BNRELU>(p, c.stream);
     return launch_wgrad<3, 1, IN_BNRELU, DY_PLAIN>(p, c.stream);
 }

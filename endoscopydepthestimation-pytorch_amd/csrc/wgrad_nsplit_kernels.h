@@ -242,6 +242,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
                 const float* ap = s_dy + aoff[m];
                 const bf16x8_t aq = pack_bf16x8(ap[0], ap[1], ap[2], ap[3], ap[16], ap[17], ap[18], ap[19]);
 #pragma unroll
+                for (int rep = 0; rep < (BF == 3 ? 6 : 1); ++rep)          // BF = 3 (tools/x3_bench only): six MFMAs per pair on the ROUNDED operands -- what the matrix work of the x3 form costs without its splits
+#pragma unroll
                 for (int g = 0; g < NG; ++g)
                     if (g < ngw) acc[g][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bq[g], acc[g][m], 0, 0, 0);
             }
@@ -286,6 +288,8 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
 // grid (groups_total * 7, slices): the partial rows of row block (group, m) are one contiguous run of `blocks` x 256 floats; a
 // block of the grid adds its slice of them -- float4 per lane, four rows in flight per thread block pass, a fixed order per
 // (slice, element) -- and adds the slice's sum to the flat gradient (one atomic per element and slice).
+// ORDER: which (co, tap) a GEMM row m stands for -- 0: m = 9 co + tap (wgrad_nsplit_kernel), 1: m = 12 tap + co (wgrad_x3_kernel)
+template <int ORDER = 0>
 __global__ void __launch_bounds__(256) wgrad_nsplit_reduce_kernel(const float* __restrict__ partial, int blocks, int groups_total, int cin,
                                                                   float* __restrict__ dw) {
     __shared__ f32x4 s_part[4][64];
@@ -313,7 +317,7 @@ __global__ void __launch_bounds__(256) wgrad_nsplit_reduce_kernel(const float* _
     const int m = 16 * m7 + 4 * (lane >> 4) + r;
     const int ci = 16 * group + (lane & 15);
     if (m < 108 && ci < cin) {
-        const int co = m / 9, tap = m - co * 9;
+        const int co = ORDER == 0 ? m / 9 : m % 12, tap = ORDER == 0 ? m - co * 9 : m / 12;
         atomicAdd(dw + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, total);
     }
 }
@@ -342,7 +346,7 @@ inline int launch_wgrad_nsplit_ng(const WgradParams& p, float* scratch, int pass
     const int groups_total = (p.cin + 15) / 16;
     wgrad_nsplit_kernel<NG, EXP, BF><<<dim3(blocks, passes), kConvThreads, 0, stream>>>(p, scratch, per);
     ENDO_LAUNCH_CHECK();
-    wgrad_nsplit_reduce_kernel<<<dim3(groups_total * kNsMG, 16), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
+    wgrad_nsplit_reduce_kernel<0><<<dim3(groups_total * kNsMG, 16), 256, 0, stream>>>(scratch, blocks, groups_total, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -358,6 +362,11 @@ inline int launch_wgrad_nsplit(const WgradParams& p, float* scratch, hipStream_t
         if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 2>(p, scratch, passes, stream);
         if (ng == 2) return launch_wgrad_nsplit_ng<2, 0, 2>(p, scratch, passes, stream);
         return launch_wgrad_nsplit_ng<3, 0, 2>(p, scratch, passes, stream);
+    }
+    if (mfma_mode == 3) {          // diagnostic (tools/x3_bench)
+        if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 3>(p, scratch, passes, stream);
+        if (ng == 2) return launch_wgrad_nsplit_ng<2, 0, 3>(p, scratch, passes, stream);
+        return launch_wgrad_nsplit_ng<3, 0, 3>(p, scratch, passes, stream);
     }
     if (mfma_mode == 1) {
         if (ng <= 1) return launch_wgrad_nsplit_ng<1, 0, 1>(p, scratch, passes, stream);

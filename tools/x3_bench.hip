@@ -12,6 +12,7 @@
 
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_taps_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_nsplit_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_x3_kernels.h"
 
 using namespace endo;
 
@@ -90,12 +91,13 @@ int main(int argc, char** argv) {
     double maxref = 0; for (double v : ref) maxref = fmax(maxref, fabs(v));
 
     struct V { const char* name; int mode; };
-    const V vs[] = {{"fp32 MFMA (v_mfma_f32_16x16x4_f32)", 0}, {"operands rounded to bf16 (1 x bf16 MFMA)", 1}, {"three-term split, 6 x bf16 MFMA", 2}};
+    const V vs[] = {{"fp32 MFMA (v_mfma_f32_16x16x4_f32)", 0}, {"operands rounded to bf16 (1 x bf16 MFMA)", 1}, {"three-term split per fragment, 6 x bf16 MFMA", 2}, {"three-term split, G pre-split in LDS (wgrad_x3_kernel)", 3}, {"diagnostic: 6 MFMAs on rounded operands, no split", 5}};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> got((size_t)12 * cin * 9);
     for (const V& v : vs) {
         CK(hipMemset(dw, 0, got.size() * 4));
-        int rc = launch_wgrad_nsplit(g, wscratch, 0, v.mode);
+        auto run = [&](int mode) { return mode == 3 ? launch_wgrad_x3(g, wscratch, 0) : launch_wgrad_nsplit(g, wscratch, 0, mode == 5 ? 3 : mode); };
+        int rc = run(v.mode);
         if (rc) { printf("%s: launch failed %d\n", v.name, rc); continue; }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(got.data(), dw, got.size() * 4, hipMemcpyDeviceToHost));
@@ -106,11 +108,11 @@ int main(int argc, char** argv) {
                 const double d = got[((size_t)co * cin + cis[k]) * 9 + tap] - ref[k * 108 + m];
                 maxerr = fmax(maxerr, fabs(d)); sq += d * d;
             }
-        for (int i = 0; i < 3; ++i) launch_wgrad_nsplit(g, wscratch, 0, v.mode);
+        for (int i = 0; i < 3; ++i) run(v.mode);
         CK(hipDeviceSynchronize());
         const int reps = 20;
         CK(hipEventRecord(e0, 0));
-        for (int i = 0; i < reps; ++i) launch_wgrad_nsplit(g, wscratch, 0, v.mode);
+        for (int i = 0; i < reps; ++i) run(v.mode);
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
