@@ -454,16 +454,17 @@ def main():
 
     warp_ms_per_pair_modules = host_inclusive(warp_both)
     warp_ms_per_pair = host_inclusive(warp_both_fused)
-    # kernel time of the same calls (HIP events on the launch stream around every geometry / loss entry point)
-    lib.endo_prof_enable((1 << FAMILY_GEOMETRY) | (1 << FAMILY_LOSS))
+    # device time of the same call: ONE pair of events around `reps` back-to-back calls on the launch stream (round 3 put events
+    # around every entry point of the composed chain, which serialised its 11 launches and read SLOWER than the host-inclusive
+    # figure); algorithmic bytes as SURVEY.md 8(d) counts them: 160 B per pixel and pair (both directions, forward and backward)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     for _ in range(reps):
         warp_both_fused()
+    ev1.record()
     torch.cuda.synchronize()
-    geo = prof_read(lib, FAMILY_GEOMETRY)
-    los = prof_read(lib, FAMILY_LOSS)
-    lib.endo_prof_enable(0)
-    warp_kernel_ms = (geo[0] + los[0]) / reps
-    warp_bytes = (geo[3] + los[3]) / reps                              # algorithmic bytes of one warp_both() call (the library's own count)
+    warp_kernel_ms = ev0.elapsed_time(ev1) / reps
+    warp_bytes = 160.0 * batch_size * height * width
 
     breakdown = None
     if args.breakdown and rank == 0:
@@ -542,10 +543,11 @@ def main():
         "roofline_depth_warp": {
             "kernel": "depth_warp fwd+bwd (both directions) + depth-consistency loss fwd+bwd", "bound": "hbm",
             "achieved": warp_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": warp_gbs / HBM_PEAK_GBS, "traffic": None,
-            "algorithmic_bytes_per_pair": warp_bytes / batch_size, "kernel_ms_per_pair": warp_kernel_ms / batch_size,
+            "algorithmic_bytes_per_pair": warp_bytes / batch_size,
+            "time_base": "device time of endo_warp_consistency (1 memset + 2 kernels), one event pair around %d back-to-back calls" % reps,
+            "device_ms_per_pair": warp_kernel_ms / batch_size,
             "host_inclusive_ms_per_pair": warp_ms_per_pair,
-            "host_inclusive_ms_per_pair_through_the_modules_and_autograd": warp_ms_per_pair_modules,
-            "note": "latency/launch bound at this size: %.0f KB per launch" % (warp_bytes / max(geo[1] + los[1], 1) * reps / 1e3)},
+            "host_inclusive_ms_per_pair_through_the_modules_and_autograd": warp_ms_per_pair_modules},
     }
     if bf16 or bf16_storage:
         # with bf16 operands the matrix work is ~1/8 of the fp32 kernels' and the dense-layer families are bound by HBM / LDS / VALU:

@@ -612,6 +612,266 @@ __global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Depth warp both ways + depth-consistency loss (losses.py:112-146), forward and backward, as TWO kernels (+ a 1 KB memset and a one-wave finalize):
+// the chain of BASELINE's second metric (endo_warp_consistency, train.py:305-314).  Round 3 composed it from the entry points above:
+// 11 launches, ~100 us per call for 105 MB.  Here gridDim.z = 2 covers the two directions (z = 0: frame 1 warped from frame 2,
+// pose 1-wrt-2; z = 1: the roles swapped):
+//   consistency_fwd_kernel   the tiled warp forward; per pixel the four NormalizedDistanceLoss sums of its sample (block reduction,
+//                            one fp64 atomic per sum and block); it also ZEROES its tile of this direction's own gradient output.
+//   consistency_finalize_kernel  one wave: the 2 x n x 4 sums -> the loss and the per-sample coefficients (d loss / d numerator,
+//                            d loss / d denominator) the backward kernel needs.
+//   consistency_bwd_kernel   per pixel the loss's gradient w.r.t. its own depth and w.r.t. the warped depth, the latter pushed
+//                            straight through the warp backward of the same pixel (taps recomputed, source tile staged as in the
+//                            forward kernel): its own-pixel terms are ONE atomic add into this direction's gradient, the source terms
+//                            go through the LDS tile into the other direction's gradient.
+// Same arithmetic per term as the kernels above; the three contributions of a gradient element arrive by fp32 atomics in any order
+// (the composed path added them in a fixed order: differences at fp32 rounding, test bound 1e-6).
+// ------------------------------------------------------------------------------------------
+struct ConsistencyArgs {
+    const float* depth[2];           // [0] frame 1, [1] frame 2
+    const float* t[2];               // [0] 1-wrt-2, [1] 2-wrt-1
+    const float* R[2];
+    const float* K;
+    const float* mask;
+    float* warped[2];                // direction z: depth[1 - z] warped into frame z
+    float* inter[2];
+    float* grad[2];                  // d loss / d depth[z]
+    double* stats;                   // [2][n][4]  sum m a, sum m, sum m |P - Pw|_1, sum m (a + |b|)   (zeroed by the caller)
+    float* coef;                     // [2][n][2]  (d loss / d numerator, d loss / d denominator) of sample n in direction z
+    float* loss;
+    float c_dcl;                     // dcl_weight * 0.5
+    float eps;
+    int n, h, w, tiles_x;
+    int zero_grads;                  // 1: the forward kernel zeroes grad[]; 0: the caller has initialised them (endo_loss_head: the flow terms)
+};
+
+__device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) consistency_fwd_kernel(const ConsistencyArgs a) {
+    using T = WarpTile<TY, TX>;
+    __shared__ Camera cam;
+    __shared__ int s_box[16];
+    __shared__ float s_d[T::BH * T::BW], s_m[T::BH * T::BW];
+    __shared__ double scratch[4 * 4];
+    const int n = blockIdx.y, z = blockIdx.z;
+    const int h = a.h, w = a.w;
+    const float* __restrict__ d1 = a.depth[z];
+    const float* __restrict__ d2 = a.depth[1 - z];
+    const float* __restrict__ mask = a.mask;
+    load_camera(a.K, a.R[z], a.t[z], n, &cam);
+    const int64_t base = static_cast<int64_t>(n) * h * w;
+    const int tx0 = (blockIdx.x % a.tiles_x) * TX, ty0 = (blockIdx.x / a.tiles_x) * TY;
+    Taps tp[T::kPix];
+    float mpix[T::kPix], dself[T::kPix];
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        tp[k].vw = tp[k].ve = tp[k].vn = tp[k].vs = false;
+        tp[k].x0 = tp[k].y0 = 0;
+        mpix[k] = 0.f; dself[k] = 0.f;
+        if (yy < h && xx < w) {
+            float qx, qy, qz;
+            ray(cam, static_cast<float>(xx), static_cast<float>(yy), qx, qy, qz);
+            const float m = mask[base + static_cast<int64_t>(yy) * w + xx];
+            dself[k] = d1[base + static_cast<int64_t>(yy) * w + xx];
+            const float dm = dself[k] * m;
+            float zt = cam.w[2] + dm * qz;
+            zt = (m > 0.5f) ? zt : a.eps;
+            zt = (zt > 0.0f) ? zt : a.eps;
+            tp[k] = make_taps((cam.w[0] + dm * qx) / zt, (cam.w[1] + dm * qy) / zt, w, h);
+            mpix[k] = m;
+            if ((tp[k].vw || tp[k].ve) && (tp[k].vn || tp[k].vs)) {
+                minx = min(minx, tp[k].x0); maxx = max(maxx, tp[k].x0);
+                miny = min(miny, tp[k].y0); maxy = max(maxy, tp[k].y0);
+            }
+        }
+    }
+    int bx0, by0, bw, bh;
+    block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
+    const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
+    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[0], 1ull);
+    if (staged) {
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const int ry = e / T::BW, rx = e - ry * T::BW;
+            const int sy = by0 + ry, sx = bx0 + rx;
+            float dv = 0.f, mv = 0.f, ss;
+            if (rx < bw && sy >= 0 && sy < h && sx >= 0 && sx < w) dv = depth_in_1(cam, d2, mask, base, w, sx, sy, &mv, &ss);
+            s_d[e] = dv; s_m[e] = mv;
+        }
+        __syncthreads();
+    }
+    const float fx = a.K[9 * n + 0], fy = a.K[9 * n + 4], cx = a.K[9 * n + 2], cy = a.K[9 * n + 5];
+    float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        if (yy >= h || xx >= w) continue;
+        const Taps& q = tp[k];
+        float v[4] = {0.f, 0.f, 0.f, 0.f}, mm[4] = {0.f, 0.f, 0.f, 0.f}, ss;
+        if (staged) {
+            const int o = (q.y0 - by0) * T::BW + (q.x0 - bx0);
+            if (q.vw && q.vn) { v[0] = s_d[o]; mm[0] = s_m[o]; }
+            if (q.ve && q.vn) { v[1] = s_d[o + 1]; mm[1] = s_m[o + 1]; }
+            if (q.vw && q.vs) { v[2] = s_d[o + T::BW]; mm[2] = s_m[o + T::BW]; }
+            if (q.ve && q.vs) { v[3] = s_d[o + T::BW + 1]; mm[3] = s_m[o + T::BW + 1]; }
+        } else {
+            if (q.vw && q.vn) v[0] = depth_in_1(cam, d2, mask, base, w, q.x0, q.y0, &mm[0], &ss);
+            if (q.ve && q.vn) v[1] = depth_in_1(cam, d2, mask, base, w, q.x0 + 1, q.y0, &mm[1], &ss);
+            if (q.vw && q.vs) v[2] = depth_in_1(cam, d2, mask, base, w, q.x0, q.y0 + 1, &mm[2], &ss);
+            if (q.ve && q.vs) v[3] = depth_in_1(cam, d2, mask, base, w, q.x0 + 1, q.y0 + 1, &mm[3], &ss);
+        }
+        float acc, macc;
+        tap_blend(q, v, mm, acc, macc);
+        const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
+        const float mi = (macc * mpix[k] >= 0.9f) ? 1.0f : 0.0f;
+        a.warped[z][o] = acc;
+        a.inter[z][o] = mi;
+        if (a.zero_grads) a.grad[z][o] = 0.f;          // the backward kernel accumulates into it
+        // NormalizedDistanceLoss sums (norm_dist_reduce, losses.hip): a = own depth, b = warped depth
+        const float ax = (static_cast<float>(xx) - cx) / fx, ay = (static_cast<float>(yy) - cy) / fy;
+        const float av = dself[k], b = acc;
+        part[0] += mi * av;
+        part[1] += mi;
+        part[2] += mi * fabsf(ax * av - ax * b) + mi * fabsf(ay * av - ay * b) + mi * fabsf(av - b);
+        part[3] += mi * (av + fabsf(b));
+    }
+    block_sum_atomic<4>(part, a.stats + 4 * (z * a.n + n), scratch);
+}
+
+// loss and the backward pass's per-sample coefficients from the 2 x n x 4 sums.  A kernel of its own, one wave: the "last block of the
+// forward kernel finalises" form needs a device-scope fence in every block, which on this part writes back and invalidates the XCD's L2
+// -- 2560 blocks of it made the forward kernel 222 us instead of ~15 (profiles/r04_warp_consistency_kernel_stats.txt history).
+__global__ void consistency_finalize_kernel(const ConsistencyArgs a) {
+    // lane i < 2 n owns (direction, sample) i: its term and coefficients; a wave reduction adds the terms (n <= 32; larger batches loop)
+    float term = 0.f;
+    for (int i = threadIdx.x; i < 2 * a.n; i += 64) {
+        const double* st = a.stats + 4 * i;
+        const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
+        const float mean_value = s0 / (1.0e-5f + s1);                  // norm_dist_den (losses.hip) with the module's eps
+        const float den = 1.0e-5f * mean_value + s3;
+        term += 2.0f * s2 / den;
+        const float g = a.c_dcl / static_cast<float>(a.n);             // d loss / d (this sample's term)
+        a.coef[2 * i] = 2.0f * g / den;
+        a.coef[2 * i + 1] = -2.0f * g * s2 / (den * den);
+    }
+    term = wave_sum(term);
+    if (threadIdx.x == 0) a.loss[0] = a.c_dcl * (term / static_cast<float>(a.n));
+}
+
+template <int TY, int TX>
+__global__ void __launch_bounds__(256) consistency_bwd_kernel(const ConsistencyArgs a) {
+    using T = WarpTile<TY, TX>;
+    __shared__ Camera cam;
+    __shared__ int s_box[16];
+    __shared__ float s_d[T::BH * T::BW], s_m[T::BH * T::BW], s_g[T::BH * T::BW];
+    const int n = blockIdx.y, z = blockIdx.z;
+    const int h = a.h, w = a.w;
+    const float* __restrict__ d1 = a.depth[z];
+    const float* __restrict__ d2 = a.depth[1 - z];
+    const float* __restrict__ mask = a.mask;
+    float* gd1 = a.grad[z];
+    float* gd2 = a.grad[1 - z];
+    load_camera(a.K, a.R[z], a.t[z], n, &cam);
+    const int64_t base = static_cast<int64_t>(n) * h * w;
+    const float fw = static_cast<float>(w), fh = static_cast<float>(h);
+    const int tx0 = (blockIdx.x % a.tiles_x) * TX, ty0 = (blockIdx.x / a.tiles_x) * TY;
+    const float cnum = a.coef[2 * (z * a.n + n)], cden = a.coef[2 * (z * a.n + n) + 1];
+    const float fx = a.K[9 * n + 0], fy = a.K[9 * n + 4], cx = a.K[9 * n + 2], cy = a.K[9 * n + 5];
+    Taps tp[T::kPix];
+    float qxs[T::kPix], qys[T::kPix], qzs[T::kPix], zts[T::kPix], nxs[T::kPix], nys[T::kPix], mpix[T::kPix], dself[T::kPix];
+    bool opens[T::kPix];
+    int minx = 1 << 30, miny = 1 << 30, maxx = -(1 << 30), maxy = -(1 << 30);
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        tp[k].vw = tp[k].ve = tp[k].vn = tp[k].vs = false;
+        tp[k].x0 = tp[k].y0 = 0;
+        mpix[k] = 0.f; opens[k] = false; dself[k] = 0.f;
+        qxs[k] = qys[k] = qzs[k] = nxs[k] = nys[k] = 0.f; zts[k] = 1.f;
+        if (yy < h && xx < w) {
+            ray(cam, static_cast<float>(xx), static_cast<float>(yy), qxs[k], qys[k], qzs[k]);
+            const float m = mask[base + static_cast<int64_t>(yy) * w + xx];
+            dself[k] = d1[base + static_cast<int64_t>(yy) * w + xx];
+            const float dm = dself[k] * m;
+            const float z2 = cam.w[2] + dm * qzs[k];
+            float zt = (m > 0.5f) ? z2 : a.eps;
+            opens[k] = (m > 0.5f) && (zt > 0.0f);
+            zt = (zt > 0.0f) ? zt : a.eps;
+            zts[k] = zt; mpix[k] = m;
+            nxs[k] = cam.w[0] + dm * qxs[k];
+            nys[k] = cam.w[1] + dm * qys[k];
+            tp[k] = make_taps(nxs[k] / zt, nys[k] / zt, w, h);
+            if ((tp[k].vw || tp[k].ve) && (tp[k].vn || tp[k].vs)) {
+                minx = min(minx, tp[k].x0); maxx = max(maxx, tp[k].x0);
+                miny = min(miny, tp[k].y0); maxy = max(maxy, tp[k].y0);
+            }
+        }
+    }
+    int bx0, by0, bw, bh;
+    block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
+    const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
+    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[1], 1ull);
+    if (staged) {
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const int ry = e / T::BW, rx = e - ry * T::BW;
+            const int sy = by0 + ry, sx = bx0 + rx;
+            float dv = 0.f, mv = 0.f, ss;
+            if (rx < bw && sy >= 0 && sy < h && sx >= 0 && sx < w) dv = depth_in_1(cam, d2, mask, base, w, sx, sy, &mv, &ss);
+            s_d[e] = dv; s_m[e] = mv; s_g[e] = 0.f;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < T::kPix; ++k) {
+        const int idx = threadIdx.x + k * T::kThreads;
+        const int yy = ty0 + idx / TX, xx = tx0 + idx % TX;
+        if (yy >= h || xx >= w) continue;
+        const Taps& q = tp[k];
+        const int64_t o = base + static_cast<int64_t>(yy) * w + xx;
+        // the loss's gradient at this pixel (norm_dist_bwd_kernel, losses.hip): a = own depth, b = warped depth, m = intersection mask
+        const float ax = (static_cast<float>(xx) - cx) / fx, ay = (static_cast<float>(yy) - cy) / fy;
+        const float mi = a.inter[z][o], av = dself[k], b = a.warped[z][o];
+        const float tt = ax * sgnf(ax * av - ax * b) + ay * sgnf(ay * av - ay * b) + sgnf(av - b);
+        const float g_own = mi * (cnum * tt + cden);
+        const float g = mi * (-cnum * tt + cden * sgnf(b));          // d loss / d warped: the warp backward's incoming gradient
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool val[4] = {q.vw && q.vn, q.ve && q.vn, q.vw && q.vs, q.ve && q.vs};
+        const float wt[4] = {q.wnw, q.wne, q.wsw, q.wse};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!val[c]) continue;
+            const int sx = q.x0 + (c & 1), sy = q.y0 + (c >> 1);
+            float mm, ss;
+            if (staged) {
+                const int oo = (sy - by0) * T::BW + (sx - bx0);
+                v[c] = s_d[oo]; mm = s_m[oo];
+                ss = plane_s(cam, sx, sy);
+                atomicAdd(&s_g[oo], warp_grad_d2_term(g, wt[c], mm, ss));
+            } else {
+                v[c] = depth_in_1(cam, d2, mask, base, w, sx, sy, &mm, &ss);
+                atomicAdd(gd2 + base + static_cast<int64_t>(sy) * w + sx, warp_grad_d2_term(g, wt[c], mm, ss));
+            }
+        }
+        atomicAdd(gd1 + o, g_own + warp_grad_d1(q, v, g, fw, fh, qxs[k], qys[k], qzs[k], zts[k], nxs[k], nys[k], opens[k], mpix[k]));
+    }
+    if (staged) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
+            const float gsum = s_g[e];
+            if (gsum != 0.f) {
+                const int ry = e / T::BW, rx = e - ry * T::BW;
+                atomicAdd(gd2 + base + static_cast<int64_t>(by0 + ry) * w + bx0 + rx, gsum);
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__ a, const float* __restrict__ mask,
                                                        float* __restrict__ out, int c, int hw) {
     const int n = blockIdx.y;
@@ -772,5 +1032,71 @@ extern "C" int endo_mask_mul(const float* a, const float* mask, float* out, int 
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     mask_mul_kernel<<<dim3(plane_blocks(hw, 256), n), 256, 0, stream>>>(a, mask, out, c, hw);
     ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+// Depth warp both ways + depth-consistency loss, forward and backward (include/endo_hip.h): one small memset and two kernels.
+extern "C" int64_t endo_warp_consistency_workspace_floats(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return -1;
+    const int64_t p = static_cast<int64_t>(n) * h * w;
+    return 4 * (p + 3) + 32 * n + 64;
+}
+
+// phase 1: memset + forward kernel (loss, coefficients, and -- zero_grads -- cleared gradients); phase 2: backward kernel (atomic adds
+// into grad_depth_*).  endo_warp_consistency runs both; endo_loss_head (head.hip) runs them around its other terms.
+int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                           const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics, float dcl_weight,
+                           float eps, float* loss, float* grad_depth_1, float* grad_depth_2, float* workspace, int n, int h, int w,
+                           int zero_grads, hipStream_t stream) {
+    const int64_t p = static_cast<int64_t>(n) * h * w;
+    float* ws = workspace;
+    auto take = [&](int64_t count) { float* q = ws; ws += (count + 3) / 4 * 4; return q; };
+    ConsistencyArgs a{};
+    a.depth[0] = depth_1; a.depth[1] = depth_2;
+    a.t[0] = t_1_wrt_2; a.t[1] = t_2_wrt_1;
+    a.R[0] = r_1_wrt_2; a.R[1] = r_2_wrt_1;
+    a.K = intrinsics; a.mask = boundaries;
+    a.warped[0] = take(p); a.warped[1] = take(p);
+    a.inter[0] = take(p); a.inter[1] = take(p);
+    a.grad[0] = grad_depth_1; a.grad[1] = grad_depth_2;
+    float* zeroed = take(2 * 2 * 4 * n);          // the sums (doubles), zeroed per call; the coefficients are written by the finalize kernel
+    a.stats = reinterpret_cast<double*>(zeroed);
+    a.coef = take(4 * n);
+    a.loss = loss;
+    a.c_dcl = static_cast<float>(static_cast<double>(dcl_weight) * 0.5);
+    a.eps = eps;
+    a.n = n; a.h = h; a.w = w;
+    a.zero_grads = zero_grads;
+    constexpr int TY = kWarpTileH, TX = kWarpTileW;
+    a.tiles_x = (w + TX - 1) / TX;
+    const int tiles_y = (h + TY - 1) / TY;
+    const dim3 grid(a.tiles_x * tiles_y, n, 2);
+    if (phase == 1) {
+        ENDO_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * (2 * 2 * 4 * n), stream));
+        consistency_fwd_kernel<TY, TX><<<grid, 256, 0, stream>>>(a);
+        consistency_finalize_kernel<<<1, 64, 0, stream>>>(a);
+    } else {
+        consistency_bwd_kernel<TY, TX><<<grid, 256, 0, stream>>>(a);
+    }
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int endo_warp_consistency(const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                                     const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics,
+                                     float dcl_weight, float eps, float* loss, float* grad_depth_1, float* grad_depth_2,
+                                     float* workspace, int n, int h, int w, void* stream_) {
+    if (!depth_1 || !depth_2 || !boundaries || !t_1_wrt_2 || !r_1_wrt_2 || !t_2_wrt_1 || !r_2_wrt_1 || !intrinsics || !loss ||
+        !grad_depth_1 || !grad_depth_2 || !workspace || n <= 0 || h <= 0 || w <= 0)
+        return ENDO_E_BADARG;
+    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    // algorithmic bytes as SURVEY.md 8(d) counts the chain: per direction warp fwd 5 planes + bwd 7, loss fwd 3 + bwd 5 = 20 planes = 160 B per pixel
+    ProfScope prof(kProfGeometry, stream, 0.0, 160.0 * static_cast<double>(n) * h * w);
+    for (int phase = 1; phase <= 2; ++phase) {
+        const int rc = endo_consistency_phase(phase, depth_1, depth_2, boundaries, t_1_wrt_2, r_1_wrt_2, t_2_wrt_1, r_2_wrt_1, intrinsics,
+                                              dcl_weight, eps, loss, grad_depth_1, grad_depth_2, workspace, n, h, w, 1, stream);
+        if (rc) return rc;
+    }
     return 0;
 }

@@ -30,25 +30,17 @@ __global__ void __launch_bounds__(256) head_add_kernel(float* __restrict__ out, 
 
 // losses[0..2] = total, dcl, sfl as train.py:299-315 forms them (fp32), losses[3] = 1 when the total is NaN / Inf (train.py:317) else 0: sfl = w_sfl * 0.5 * (a + b), dcl likewise, total = dcl + sfl;
 // up[0] = d total / d (each sparse-flow term), up[1] = d total / d (each consistency term)
-__global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl, float c_dcl, float* __restrict__ losses, float* __restrict__ up) {
+__global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl, const float* __restrict__ dcl_weighted, float* __restrict__ losses,
+                                    float* __restrict__ up) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float sfl = c_sfl * (parts[0] + parts[1]);
-        const float dcl = c_dcl * (parts[2] + parts[3]);
+        const float dcl = dcl_weighted[0];          // dcl_weight * 0.5 * (term_1 + term_2), from the fused consistency kernel
         const float total = dcl + sfl;
         losses[0] = total;
         losses[1] = dcl;
         losses[2] = sfl;
         losses[3] = (isnan(total) || isinf(total)) ? 1.f : 0.f;          // the guard of train.py:317, decided on the device
         up[0] = c_sfl;
-        up[1] = c_dcl;
-    }
-}
-
-// loss = c_dcl * (parts[0] + parts[1]) (train.py:311-314 with c_dcl = dcl_weight * 0.5); up[0] = d loss / d (each term)
-__global__ void consistency_combine_kernel(const float* __restrict__ parts, float c_dcl, float* __restrict__ loss, float* __restrict__ up) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        loss[0] = c_dcl * (parts[0] + parts[1]);
-        up[0] = c_dcl;
     }
 }
 
@@ -56,60 +48,13 @@ __global__ void consistency_combine_kernel(const float* __restrict__ parts, floa
 
 using namespace endo;
 
-// ---------------------------------------------------------------------------------------------
-// Depth warp both ways + depth-consistency loss, forward and backward, as ONE call (reference models.py:454-554 twice,
-// losses.py:112-146 twice, train.py:305-314, and their autograd backward): the second BASELINE metric ("depth-warp fwd+bwd ms
-// per pair") measures exactly this chain, and through the modules ~2/3 of it was Python / autograd time around 10 launches.
-// Same entry points as endo_loss_head composes, same arithmetic as the modules.
-// ---------------------------------------------------------------------------------------------
-extern "C" int64_t endo_warp_consistency_workspace_floats(int n, int h, int w) {
-    if (n <= 0 || h <= 0 || w <= 0) return -1;
-    const int64_t p = static_cast<int64_t>(n) * h * w;
-    return 12 * (p + 3) + 32 * n + 64;
-}
+// geometry.hip: the fused depth-warp + consistency-loss kernels, forward (phase 1) and backward (phase 2)
+int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                           const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics, float dcl_weight,
+                           float eps, float* loss, float* grad_depth_1, float* grad_depth_2, float* workspace, int n, int h, int w,
+                           int zero_grads, hipStream_t stream);
 
-extern "C" int endo_warp_consistency(const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
-                                     const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics,
-                                     float dcl_weight, float eps, float* loss, float* grad_depth_1, float* grad_depth_2,
-                                     float* workspace, int n, int h, int w, void* stream_) {
-    if (!depth_1 || !depth_2 || !boundaries || !t_1_wrt_2 || !r_1_wrt_2 || !t_2_wrt_1 || !r_2_wrt_1 || !intrinsics || !loss ||
-        !grad_depth_1 || !grad_depth_2 || !workspace || n <= 0 || h <= 0 || w <= 0)
-        return ENDO_E_BADARG;
-    if (reinterpret_cast<uintptr_t>(workspace) % 16 != 0) return ENDO_E_BADARG;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
-    const int64_t p = static_cast<int64_t>(n) * h * w;
-    float* ws = workspace;
-    auto take = [&](int64_t count) { float* q = ws; ws += (count + 3) / 4 * 4; return q; };
-    float* warped_21 = take(p);     float* warped_12 = take(p);
-    float* inter_1 = take(p);       float* inter_2 = take(p);
-    float* g_d1_dcl = take(p);      float* g_d2_dcl = take(p);
-    float* g_w21 = take(p);         float* g_w12 = take(p);
-    float* g_d1_w21 = take(p);      float* g_d2_w21 = take(p);            // warp 2->1: d1 = depth_1, d2 = depth_2
-    float* g_d2_w12 = take(p);      float* g_d1_w12 = take(p);            // warp 1->2: d1 = depth_2, d2 = depth_1
-    double* nd_stats_1 = reinterpret_cast<double*>(take(2 * 2 * 4 * n));
-    double* nd_stats_2 = nd_stats_1 + 4 * n;
-    float* parts = take(4);
-    float* up = take(4);
-    int rc;
-#define HEAD(call) do { rc = (call); if (rc) return rc; } while (0)
-    HEAD(endo_depth_warp_fwd(depth_1, depth_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, warped_21, inter_1, n, h, w, eps, stream_));
-    HEAD(endo_depth_warp_fwd(depth_2, depth_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, warped_12, inter_2, n, h, w, eps, stream_));
-    HEAD(endo_norm_dist_fwd(depth_1, warped_21, inter_1, intrinsics, parts + 0, nd_stats_1, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_norm_dist_fwd(depth_2, warped_12, inter_2, intrinsics, parts + 1, nd_stats_2, n, h, w, 1.0e-5f, stream_));
-    consistency_combine_kernel<<<1, 64, 0, stream>>>(parts, static_cast<float>(static_cast<double>(dcl_weight) * 0.5), loss, up);
-    ENDO_LAUNCH_CHECK();
-    HEAD(endo_norm_dist_bwd(up, depth_1, warped_21, inter_1, intrinsics, nd_stats_1, g_d1_dcl, g_w21, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_norm_dist_bwd(up, depth_2, warped_12, inter_2, intrinsics, nd_stats_2, g_d2_dcl, g_w12, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_depth_warp_bwd(g_w21, depth_1, depth_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_d1_w21, g_d2_w21, n, h, w, eps, stream_));
-    HEAD(endo_depth_warp_bwd(g_w12, depth_2, depth_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_d2_w12, g_d1_w12, n, h, w, eps, stream_));
-#undef HEAD
-    int blocks = static_cast<int>((p / 4 + 255) / 256);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    head_add_kernel<<<blocks, 256, 0, stream>>>(grad_depth_1, g_d1_dcl, g_d1_w21, g_d1_w12, nullptr, p);
-    head_add_kernel<<<blocks, 256, 0, stream>>>(grad_depth_2, g_d2_dcl, g_d2_w21, g_d2_w12, nullptr, p);
-    ENDO_LAUNCH_CHECK();
-    return 0;
-}
+// (endo_warp_consistency -- the depth-warp + consistency-loss chain as two fused kernels -- lives in geometry.hip.)
 
 extern "C" int64_t endo_loss_head_workspace_floats(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return -1;
@@ -138,15 +83,9 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     float* flow_1 = take(2 * p);    float* flow_2 = take(2 * p);          // raw, then masked in place
     float* msf_1 = take(2 * p);     float* msf_2 = take(2 * p);           // sparse flows * boundary
     float* msm_1 = take(p);         float* msm_2 = take(p);               // sparse flow masks * boundary
-    float* warped_21 = take(p);     float* warped_12 = take(p);
-    float* inter_1 = take(p);       float* inter_2 = take(p);
+    float* cons_ws = take(4 * (p + 3) + 32 * n + 64);                     // endo_consistency_phase's own carving (warped, intersect, sums)
     float* g_flow_1 = take(2 * p);  float* g_flow_2 = take(2 * p);        // d / d masked flow, then masked in place = d / d raw flow
-    float* g_s1_flow = take(p);     float* g_s2_flow = take(p);
-    float* g_s1_dcl = take(p);      float* g_s2_dcl = take(p);
-    float* g_w21 = take(p);         float* g_w12 = take(p);
-    float* g_s1_w21 = take(p);      float* g_s2_w21 = take(p);            // warp 2->1: d1 = scaled_1, d2 = scaled_2
-    float* g_s2_w12 = take(p);      float* g_s1_w12 = take(p);            // warp 1->2: d1 = scaled_2, d2 = scaled_1
-    float* g_s1 = take(p);          float* g_s2 = take(p);
+    float* g_s1 = take(p);          float* g_s2 = take(p);                // d loss / d scaled depth: the flow terms, then += the consistency terms
     double* dstats = reinterpret_cast<double*>(take(2 * (2 * 8 * n + 2 * n + 2 * 2 * n + 2 * 4 * n)));
     double* ds_stats_1 = dstats;            double* ds_stats_2 = ds_stats_1 + 8 * n;
     double* ds_work_1 = ds_stats_2 + 8 * n; double* ds_work_2 = ds_work_1 + n;
@@ -170,29 +109,22 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     HEAD(endo_mask_mul(flow_2, boundaries, flow_2, n, 2, hw, stream_));
     HEAD(endo_sparse_l1_fwd(msf_1, flow_1, msm_1, parts + 0, l1_stats_1, n, 2, hw, 1.0f, stream_));
     HEAD(endo_sparse_l1_fwd(msf_2, flow_2, msm_2, parts + 1, l1_stats_2, n, 2, hw, 1.0f, stream_));
-    HEAD(endo_depth_warp_fwd(scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, warped_21, inter_1, n, h, w, eps, stream_));
-    HEAD(endo_depth_warp_fwd(scaled_2, scaled_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, warped_12, inter_2, n, h, w, eps, stream_));
-    HEAD(endo_norm_dist_fwd(scaled_1, warped_21, inter_1, intrinsics, parts + 2, nd_stats_1, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_norm_dist_fwd(scaled_2, warped_12, inter_2, intrinsics, parts + 3, nd_stats_2, n, h, w, 1.0e-5f, stream_));
-    head_combine_kernel<<<1, 64, 0, stream>>>(parts, static_cast<float>(static_cast<double>(sfl_weight) * 0.5),
-                                              static_cast<float>(static_cast<double>(dcl_weight) * 0.5), losses, up);
+    // depth warp both ways + depth-consistency loss: the two fused kernels of endo_warp_consistency (geometry.hip); the forward one
+    // leaves dcl_weight * 0.5 * (term_1 + term_2) in parts[4] and the backward coefficients in its workspace
+    HEAD(endo_consistency_phase(1, scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, t_2_wrt_1, r_2_wrt_1, intrinsics, dcl_weight, eps,
+                                parts + 4, g_s1, g_s2, cons_ws, n, h, w, 0, stream));
+    head_combine_kernel<<<1, 64, 0, stream>>>(parts, static_cast<float>(static_cast<double>(sfl_weight) * 0.5), parts + 4, losses, up);
     ENDO_LAUNCH_CHECK();
     // ---- backward ----
     HEAD(endo_sparse_l1_bwd(up + 0, msf_1, flow_1, msm_1, l1_stats_1, nullptr, g_flow_1, n, 2, hw, 1.0f, stream_));
     HEAD(endo_sparse_l1_bwd(up + 0, msf_2, flow_2, msm_2, l1_stats_2, nullptr, g_flow_2, n, 2, hw, 1.0f, stream_));
     HEAD(endo_mask_mul(g_flow_1, boundaries, g_flow_1, n, 2, hw, stream_));
     HEAD(endo_mask_mul(g_flow_2, boundaries, g_flow_2, n, 2, hw, stream_));
-    HEAD(endo_flow_from_depth_bwd(g_flow_1, scaled_1, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_s1_flow, n, h, w, stream_));
-    HEAD(endo_flow_from_depth_bwd(g_flow_2, scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_s2_flow, n, h, w, stream_));
-    HEAD(endo_norm_dist_bwd(up + 1, scaled_1, warped_21, inter_1, intrinsics, nd_stats_1, g_s1_dcl, g_w21, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_norm_dist_bwd(up + 1, scaled_2, warped_12, inter_2, intrinsics, nd_stats_2, g_s2_dcl, g_w12, n, h, w, 1.0e-5f, stream_));
-    HEAD(endo_depth_warp_bwd(g_w21, scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_s1_w21, g_s2_w21, n, h, w, eps, stream_));
-    HEAD(endo_depth_warp_bwd(g_w12, scaled_2, scaled_1, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_s2_w12, g_s1_w12, n, h, w, eps, stream_));
-    int blocks = static_cast<int>((p / 4 + 255) / 256);
-    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
-    head_add_kernel<<<blocks, 256, 0, stream>>>(g_s1, g_s1_flow, g_s1_dcl, g_s1_w21, g_s1_w12, p);
-    head_add_kernel<<<blocks, 256, 0, stream>>>(g_s2, g_s2_flow, g_s2_dcl, g_s2_w21, g_s2_w12, p);
-    ENDO_LAUNCH_CHECK();
+    // the flow terms initialise d loss / d scaled depth (every element written), the consistency kernel adds its own
+    HEAD(endo_flow_from_depth_bwd(g_flow_1, scaled_1, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_s1, n, h, w, stream_));
+    HEAD(endo_flow_from_depth_bwd(g_flow_2, scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_s2, n, h, w, stream_));
+    HEAD(endo_consistency_phase(2, scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, t_2_wrt_1, r_2_wrt_1, intrinsics, dcl_weight, eps,
+                                parts + 4, g_s1, g_s2, cons_ws, n, h, w, 0, stream));
     HEAD(endo_depth_scale_bwd(g_s1, nullptr, pred_1, sparse_depths_1, ds_stats_1, grad_pred_1, ds_work_1, n, hw, eps, stream_));
     HEAD(endo_depth_scale_bwd(g_s2, nullptr, pred_2, sparse_depths_2, ds_stats_2, grad_pred_2, ds_work_2, n, hw, eps, stream_));
 #undef HEAD

@@ -811,7 +811,8 @@ extern "C" int N16(bwd)(endo_net16* net, const float* params, const void* tape_,
         const int64_t count = static_cast<int64_t>(net->n) * net->lv[0].plane;
         int gb = static_cast<int>((count + 8191) / 8192);
         gb = gb > 256 ? 256 : gb;
-        s16_grad_scale_kernel<<<gb, 1024, 0, stream>>>(grad_out, count, reinterpret_cast<float*>(c.ws + net->ws_gscale));
+        s16_grad_max_kernel<<<gb, 1024, 0, stream>>>(grad_out, count, reinterpret_cast<float*>(c.ws + net->ws_gscale));
+        s16_grad_scale_kernel<<<1, 64, 0, stream>>>(reinterpret_cast<float*>(c.ws + net->ws_gscale));
     }
     ENDO_LAUNCH_CHECK();
 #endif
