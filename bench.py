@@ -364,8 +364,12 @@ def main():
     barrier()
     fam_warm = {f: prof_read(lib, f) for f in MFMA_FAMILIES} if serial_steps > 0 else None
     lib.endo_prof_enable(0)
-    model.set_kernel_option(5, 1)
-    model.set_wgrad_overlap16(True)
+    overlap_mode = 1          # ENDO_OPT_WGRAD_OVERLAP of the timed region: 1, or what --kernel-option 5=... asked for (2 = one fork per dense block)
+    for spec in args.kernel_option:
+        if int(spec.split("=")[0]) == 5:
+            overlap_mode = int(spec.split("=")[1])
+    model.set_kernel_option(5, overlap_mode)
+    model.set_wgrad_overlap16(int(os.environ.get("ENDO16_WGRAD_OVERLAP", "1")))          # development A/B: 2 = one fork per dense block
     for _ in range(args.warmup - serial_steps):
         scheduler.batch_step(batch_iteration=it)
         step_fn(batch)

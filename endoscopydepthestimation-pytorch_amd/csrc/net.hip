@@ -841,12 +841,17 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     for (int j = kLayers - 1; j >= 0; --j) {
         int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b, &pending, pending_nl);
         if (rc) return rc;
-        {
+        // ENDO_OPT_WGRAD_OVERLAP 1: fork after every prep_dy; 2: ONE fork per dense block, after its last prep_dy (nothing rewrites a
+        // prepared G before the join, so the four weight gradients may start late; 55 -> 22 event record / wait pairs per backward pass)
+        const bool defer = c.net->opt[ENDO_OPT_WGRAD_OVERLAP] == 2;
+        if (!defer || j == 0) {
             Ctx cw;
             rc = c.fork_wgrad(cw, level);
             if (rc) return rc;
-            rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * j, bn[j], cv[j]);
-            if (rc) return rc;
+            for (int jj = defer ? kLayers - 1 : j; jj >= j; --jj) {
+                rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * jj, bn[jj], cv[jj]);
+                if (rc) return rc;
+            }
         }
         if (j > 0) {
             // Gradient into the 12 new maps of layer j-1 from ALL its consumers inside the block (layers j..3) in one pass:

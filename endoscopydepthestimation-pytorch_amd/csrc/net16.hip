@@ -393,7 +393,7 @@ extern "C" void N16(destroy)(endo_net16* net) {
 // 0: everything in line on the caller's stream (what a caller capturing the step into a graph on one stream wants)
 extern "C" int N16(set_wgrad_overlap)(endo_net16* net, int on) {
     if (!net) return ENDO_E_BADARG;
-    net->use_wstream = on ? 1 : 0;
+    net->use_wstream = on < 0 ? 0 : (on > 2 ? 2 : on);          // 2: one fork per dense block (the four weight gradients behind the block's last prep_dy)
     return 0;
 }
 extern "C" int64_t N16(tape_bytes)(const endo_net16* net) { return net ? net->tape_bytes : 0; }
@@ -647,22 +647,29 @@ void fill_dgrad(const Ctx16& c, Conv16Params& p, int g_level, int gc0, int level
 // dense layer j of a block with `c0` base channels (reads [0, c0 + 12 j), wrote [c0 + 12 j, + 12)): bias gradient + deferred terms,
 // weight gradient, and the data gradient with respect to the NEW maps it reads ([c0, c0 + 12 j): they carry the layer-to-layer
 // dependency); the base channels of all four layers follow in one pass (dense_block_bwd16)
-int dense_bwd16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const Conv16& cv) {
+int dense_wgrad16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const Conv16& cv, hipStream_t side) {
+    const auto& lv = c.net->lv[level];
+    const int oc0 = c0 + k16Growth * j;
+    const double px = static_cast<double>(c.net->n) * lv.plane;
+    Wgrad16Params p{};
+    p.n = c.net->n; p.h = lv.h; p.w = lv.w;
+    fill_wgrad_a(c, p, level, 0, cv.cin, &b, cv);
+    p.g = c.dbuf(level); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = oc0; p.cout = cv.cout;
+    ProfScope prof(kProfWgradDense, side, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin + cv.cout));
+    return launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
+}
+
+int dense_bwd16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const Conv16& cv, bool with_wgrad = true) {
     const auto& lv = c.net->lv[level];
     const int oc0 = c0 + k16Growth * j;
     int rc = prep_dy16(c, level, oc0, cv.cout, c.grads + cv.b);
     if (rc) return rc;
     const double px = static_cast<double>(c.net->n) * lv.plane;
-    {
-        Wgrad16Params p{};
-        p.n = c.net->n; p.h = lv.h; p.w = lv.w;
-        fill_wgrad_a(c, p, level, 0, cv.cin, &b, cv);
-        p.g = c.dbuf(level); p.g_ns = lv.plane * lv.t; p.g_blk = k16Blk; p.gc0 = oc0; p.cout = cv.cout;
+    if (with_wgrad) {
         hipStream_t side;
         rc = c.fork_wgrad(side);
         if (rc) return rc;
-        ProfScope prof(kProfWgradDense, side, 2.0 * px * cv.cin * cv.cout * 9, 2.0 * px * (cv.cin + cv.cout));
-        rc = launch_bf16_wgrad<3>(p, c.grads + cv.w, side);
+        rc = dense_wgrad16(c, level, c0, j, b, cv, side);
         if (rc) return rc;
     }
     if (j == 0) return 0;
@@ -679,9 +686,19 @@ int dense_bwd16(const Ctx16& c, int level, int c0, int j, const Bn16& b, const C
 
 // a dense block with c0 base channels [0, c0) and its four layers' maps at [c0, c0 + 48)
 int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const Conv16* cv) {
+    const bool defer = c.net->wstream && c.net->use_wstream == 2;          // one fork per block: nothing rewrites a prepared G before the join
     for (int j = k16Layers - 1; j >= 0; --j) {
-        const int rc = dense_bwd16(c, level, c0, j, bn[j], cv[j]);
+        const int rc = dense_bwd16(c, level, c0, j, bn[j], cv[j], !defer);
         if (rc) return rc;
+    }
+    if (defer) {
+        hipStream_t side;
+        int rc = c.fork_wgrad(side);
+        if (rc) return rc;
+        for (int j = k16Layers - 1; j >= 0; --j) {
+            rc = dense_wgrad16(c, level, c0, j, bn[j], cv[j], side);
+            if (rc) return rc;
+        }
     }
     const auto& lv = c.net->lv[level];
     DgradBlock16Params p{};

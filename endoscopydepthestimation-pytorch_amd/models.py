@@ -423,10 +423,11 @@ class FCDenseNet(nn.Module):
     def set_wgrad_overlap16(self, on):
         """The 16-bit-storage family's weight gradients on the backward pass's own side stream (default) or in line on the caller's
         stream (``endo_net16_set_wgrad_overlap``): applies to this module's handles, present and future."""
-        self.__dict__["_wgrad_overlap16"] = bool(on)
+        # 0: in line; 1 / True: forked after every layer's prep_dy; 2: one fork per dense block
+        self.__dict__["_wgrad_overlap16"] = int(on)
         for key, (hnd, _, _) in self._handles.items():
             if key[0] in ("bf16", "fp16"):
-                self._api16(key[0] == "fp16")("set_wgrad_overlap")(hnd, 1 if on else 0)
+                self._api16(key[0] == "fp16")("set_wgrad_overlap")(hnd, int(on))
 
     def _handle16(self, n, h, w, groups=1, half=False):
         """n: samples per group"""
@@ -435,7 +436,7 @@ class FCDenseNet(nn.Module):
         if key not in self._handles:
             hnd = ctypes.c_void_p()
             _lib.check(api("create")(ctypes.byref(hnd), n, h, w, groups), "endo_net16_create(%d,%d,%d,%d)" % (n, h, w, groups))
-            api("set_wgrad_overlap")(hnd, 1 if self.__dict__.get("_wgrad_overlap16", True) else 0)
+            api("set_wgrad_overlap")(hnd, int(self.__dict__.get("_wgrad_overlap16", 1)))
             self._handles[key] = (hnd, int(api("tape_bytes")(hnd)), int(api("bwd_workspace_bytes")(hnd)))
         return self._handles[key]
 
