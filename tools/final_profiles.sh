@@ -1,6 +1,6 @@
 # The profile set committed under profiles/ (run on an MI355X box through gpurun): tools/final_profiles.sh <tag>, e.g. r03_f
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
