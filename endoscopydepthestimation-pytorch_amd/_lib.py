@@ -91,6 +91,7 @@ SIGNATURES = {
     "endo_jpeg_entropy_decode": (_I, [_P, _L, _P, _L, _P]),
     "endo_jpeg_workspace_bytes": (_L, [_P, _L]),
     "endo_jpeg_decode_crop": (_I, [_P, _L, ctypes.c_double, _I, _I, _I, _I, _I, _P, _P, _P, _P, _L, _P]),
+    "endo_hsv_full": (_I, [_P, _L, _I, _P, _P, _P]),
     "endo_point_brightness": (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _I, ctypes.c_double, ctypes.c_double, _P, _P, _P, _P]),
     "endo_prof_enable": (_I, [_I]),
     "endo_prof_sample": (_I, [_I]),

@@ -60,9 +60,45 @@ __global__ void __launch_bounds__(128) point_brightness_kernel(const uint8_t* __
     brightness[o] = fmaxf(b0, fmaxf(b1, b2));
 }
 
+// cv2.COLOR_BGR2HSV_FULL / COLOR_RGB2HSV_FULL on 8-bit pixels (reference utils.py:449-450, 80-81; dataset.py:434-442), OpenCV's scalar
+// fixed-point path: v = max, s = (diff * sdiv[v] + 2048) >> 12, h = (hterm * hdiv[diff] + 2048) >> 12 (+ 256 when negative) with
+// sdiv[i] = round((255 << 12) / i), hdiv[i] = round((256 << 12) / (6 i)) (round half to even).  One thread per pixel; writes the uint8
+// HWC image and / or the Normalize(0.5, 0.5) fp32 CHW tensor of dataset.py:446-451.
+__global__ void __launch_bounds__(256) hsv_full_kernel(const uint8_t* __restrict__ src, int64_t pixels, int blue_index, uint8_t* __restrict__ out_u8,
+                                                       float* __restrict__ out_f32) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < pixels; i += 256ll * gridDim.x) {
+        const int c0 = src[3 * i], c1 = src[3 * i + 1], c2 = src[3 * i + 2];
+        const int b = blue_index == 0 ? c0 : c2, g = c1, r = blue_index == 0 ? c2 : c0;
+        const int v = max(max(b, g), r), vmin = min(min(b, g), r), diff = v - vmin;
+        const int sdiv = v ? static_cast<int>(rint(static_cast<double>(255 << 12) / v)) : 0;
+        const int hdiv = diff ? static_cast<int>(rint(static_cast<double>(256 << 12) / (6.0 * diff))) : 0;
+        const int s = (diff * sdiv + (1 << 11)) >> 12;
+        const int hterm = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+        int h = (hterm * hdiv + (1 << 11)) >> 12;
+        h += h < 0 ? 256 : 0;
+        h = h > 255 ? 255 : h;
+        if (out_u8) { out_u8[3 * i] = static_cast<uint8_t>(h); out_u8[3 * i + 1] = static_cast<uint8_t>(s); out_u8[3 * i + 2] = static_cast<uint8_t>(v); }
+        if (out_f32) {          // (x / 255 - 0.5) / 0.5 as albumentations.Normalize(mean 0.5, std 0.5, max_pixel_value 255) evaluates it in fp32
+            out_f32[i] = (static_cast<float>(h) - 127.5f) * (1.0f / 127.5f);
+            out_f32[pixels + i] = (static_cast<float>(s) - 127.5f) * (1.0f / 127.5f);
+            out_f32[2 * pixels + i] = (static_cast<float>(v) - 127.5f) * (1.0f / 127.5f);
+        }
+    }
+}
+
 }  // namespace endo
 
 using namespace endo;
+
+extern "C" int endo_hsv_full(const uint8_t* src, int64_t pixels, int blue_index, uint8_t* out_u8, float* out_f32, void* stream_) {
+    if (!src || pixels <= 0 || (blue_index != 0 && blue_index != 2) || (!out_u8 && !out_f32)) return ENDO_E_BADARG;
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    int blocks = static_cast<int>((pixels + 255) / 256);
+    blocks = blocks > 4096 ? 4096 : blocks;
+    hsv_full_kernel<<<blocks, 256, 0, stream>>>(src, pixels, blue_index, out_u8, out_f32);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int endo_point_brightness(const uint8_t* imgs, int frames, int height, int width, const double* points, int n_points,
                                      const double* projections, const double* extrinsics, const float* visibility, const uint8_t* mask, int d,

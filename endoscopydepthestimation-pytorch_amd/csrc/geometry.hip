@@ -644,6 +644,7 @@ struct ConsistencyArgs {
     float eps;
     int n, h, w, tiles_x;
     int zero_grads;                  // 1: the forward kernel zeroes grad[]; 0: the caller has initialised them (endo_loss_head: the flow terms)
+    int loss_in_bwd;                 // 1: no finalize kernel ran; the backward kernel's first block writes the loss
 };
 
 __device__ __forceinline__ float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
@@ -780,7 +781,27 @@ __global__ void __launch_bounds__(256) consistency_bwd_kernel(const ConsistencyA
     const int64_t base = static_cast<int64_t>(n) * h * w;
     const float fw = static_cast<float>(w), fh = static_cast<float>(h);
     const int tx0 = (blockIdx.x % a.tiles_x) * TX, ty0 = (blockIdx.x / a.tiles_x) * TY;
-    const float cnum = a.coef[2 * (z * a.n + n)], cden = a.coef[2 * (z * a.n + n) + 1];
+    // this sample's coefficients from the forward kernel's sums (consistency_finalize_kernel's arithmetic; the stand-alone call skips
+    // that kernel and block (0, 0, 0) writes the loss here)
+    float cnum, cden;
+    {
+        const double* st = a.stats + 4 * (z * a.n + n);
+        const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
+        const float den = 1.0e-5f * (s0 / (1.0e-5f + s1)) + s3;
+        const float g = a.c_dcl / static_cast<float>(a.n);
+        cnum = 2.0f * g / den;
+        cden = -2.0f * g * s2 / (den * den);
+    }
+    if (a.loss_in_bwd && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
+        float term = 0.f;
+        for (int i = threadIdx.x; i < 2 * a.n; i += 64) {
+            const double* st = a.stats + 4 * i;
+            const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
+            term += 2.0f * s2 / (1.0e-5f * (s0 / (1.0e-5f + s1)) + s3);
+        }
+        term = wave_sum(term);
+        if (threadIdx.x == 0) a.loss[0] = a.c_dcl * (term / static_cast<float>(a.n));
+    }
     const float fx = a.K[9 * n + 0], fy = a.K[9 * n + 4], cx = a.K[9 * n + 2], cy = a.K[9 * n + 5];
     Taps tp[T::kPix];
     float qxs[T::kPix], qys[T::kPix], qzs[T::kPix], zts[T::kPix], nxs[T::kPix], nys[T::kPix], mpix[T::kPix], dself[T::kPix];
@@ -1067,6 +1088,7 @@ int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2
     a.eps = eps;
     a.n = n; a.h = h; a.w = w;
     a.zero_grads = zero_grads;
+    a.loss_in_bwd = zero_grads;          // the stand-alone call (endo_warp_consistency) needs the loss only at its end
     constexpr int TY = kWarpTileH, TX = kWarpTileW;
     a.tiles_x = (w + TX - 1) / TX;
     const int tiles_y = (h + TY - 1) / TY;
@@ -1074,7 +1096,7 @@ int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2
     if (phase == 1) {
         ENDO_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * (2 * 2 * 4 * n), stream));
         consistency_fwd_kernel<TY, TX><<<grid, 256, 0, stream>>>(a);
-        consistency_finalize_kernel<<<1, 64, 0, stream>>>(a);
+        if (!a.loss_in_bwd) consistency_finalize_kernel<<<1, 64, 0, stream>>>(a);          // the loss head reads the loss between the phases
     } else {
         consistency_bwd_kernel<TY, TX><<<grid, 256, 0, stream>>>(a);
     }

@@ -67,13 +67,14 @@ class TrainingBatches(object):
 
     def __init__(self, folder_list, adjacent_range, batch_size, downsampling=4.0, network_downsampling=64, visible_interval=30,
                  precompute_path=None, image_file_names=None, num_iter=None, shuffle=True, rgb_mode="rgb", suggested_h=None,
-                 suggested_w=None, device="cuda", seed=None, inlier_percentage=None, reader_threads=4, prefetch=1):
+                 suggested_w=None, device="cuda", seed=None, inlier_percentage=None, reader_threads=4, prefetch=1, is_hsv=False):
         assert len(adjacent_range) == 2
         self.folders = [str(f) for f in folder_list]
         self.adjacent_range = list(adjacent_range)
         self.batch_size = int(batch_size)
         self.downsampling = float(downsampling)
         self.rgb_mode = rgb_mode
+        self.is_hsv = bool(is_hsv)          # train.py --use_hsv_colorspace: frames enter the network as cv2.COLOR_BGR2HSV_FULL values (dataset.py:439-442)
         self.shuffle = shuffle
         self.device = torch.device(device)
         self.rng = random.Random(seed)
@@ -122,7 +123,13 @@ class TrainingBatches(object):
         with open(path, "rb") as f:
             data = f.read()
         with torch.cuda.device(self.device), torch.cuda.stream(stream):
-            decoder.decode(data, window[0], window[1], window[2], window[3], self.downsampling, self.rgb_mode, out_f32=dst)
+            if self.is_hsv:
+                scratch = torch.empty((dst.shape[1], dst.shape[2], 3), dtype=torch.uint8, device=self.device)
+                decoder.decode(data, window[0], window[1], window[2], window[3], self.downsampling, "bgr", out_u8=scratch)
+                reader.hsv_full(scratch, blue_index=0, out_f32=dst)
+                scratch.record_stream(stream)
+            else:
+                decoder.decode(data, window[0], window[1], window[2], window[3], self.downsampling, self.rgb_mode, out_f32=dst)
 
     def __len__(self):
         return (self.num_iter + self.batch_size - 1) // self.batch_size

@@ -349,40 +349,65 @@ def _frame_bytes(prefix_seq, index):
 
 def get_pair_color_imgs(prefix_seq, pair_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False, rgb_mode="rgb",
                         decoder=None):
-    """uint8 (len(pair_indexes), H, W, 3) DEVICE tensor with the values of the reference's numpy array  [utils.py:441-457]"""
-    if is_hsv:
-        raise NotImplementedError("is_hsv=True (cv2.COLOR_BGR2HSV_FULL) is not part of the training configuration")
+    """uint8 (len(pair_indexes), H, W, 3) DEVICE tensor with the values of the reference's numpy array  [utils.py:441-457].
+    is_hsv (train.py --use_hsv_colorspace): the BGR frame through cv2.COLOR_BGR2HSV_FULL (endo_hsv_full: OpenCV's 8-bit fixed-point
+    arithmetic, parity unpinned against cv2 itself); rgb_mode is then not looked at, as in the reference."""
     decoder = decoder or _decoder()
     out = torch.empty((len(pair_indexes), end_h - start_h, end_w - start_w, 3), dtype=torch.uint8, device=decoder.device)
     for k, index in enumerate(pair_indexes):
-        decoder.decode(_frame_bytes(prefix_seq, index), start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode, out_u8=out[k])
+        decoder.decode(_frame_bytes(prefix_seq, index), start_h, end_h, start_w, end_w, downsampling_factor, "bgr" if is_hsv else rgb_mode, out_u8=out[k])
+    if is_hsv:
+        hsv_full(out, blue_index=0, out_u8=out)
     return out
 
 
-def get_pair_color_tensors(prefix_seq, pair_indexes, start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode="rgb", decoder=None):
+def hsv_full(img_u8, blue_index=0, out_u8=None, out_f32=None):
+    """cv2.cvtColor(img, COLOR_BGR2HSV_FULL) (blue_index 0) / COLOR_RGB2HSV_FULL (2) of a uint8 (..., H, W, 3) device tensor into a uint8
+    tensor of the same shape and / or, for ONE image, the Normalize(0.5, 0.5) fp32 (3, H, W) tensor of dataset.py:446-451; in place when
+    out_u8 is img_u8  [utils.py:449-450, 80-81; dataset.py:439-442]."""
+    lib = _lib.load()
+    if img_u8.dtype != torch.uint8 or not img_u8.is_cuda or not img_u8.is_contiguous() or img_u8.shape[-1] != 3:
+        raise ValueError("expected a contiguous uint8 device tensor (..., H, W, 3)")
+    pixels = img_u8.numel() // 3
+    if out_u8 is None and out_f32 is None:
+        out_u8 = torch.empty_like(img_u8)
+    if out_f32 is not None and (img_u8.dim() != 3 or tuple(out_f32.shape) != (3, img_u8.shape[0], img_u8.shape[1]) or out_f32.dtype != torch.float32
+                                or not out_f32.is_contiguous()):
+        raise ValueError("out_f32 is the (3, H, W) fp32 tensor of one (H, W, 3) image")
+    _lib.check(lib.endo_hsv_full(_lib.ptr(img_u8), pixels, int(blue_index), _lib.ptr(out_u8), _lib.ptr(out_f32), _lib.stream()), "endo_hsv_full")
+    return out_u8 if out_u8 is not None else out_f32
+
+
+def get_pair_color_tensors(prefix_seq, pair_indexes, start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode="rgb", decoder=None, is_hsv=False):
     """fp32 (len(pair_indexes), 3, H, W) device tensor: get_pair_color_imgs + Normalize(0.5, 0.5) + img_to_tensor, the network's
     colour input when no augmentation runs in between (dataset.py:446-451 validation branch; evaluate.py)."""
     decoder = decoder or _decoder()
-    out = torch.empty((len(pair_indexes), 3, end_h - start_h, end_w - start_w), dtype=torch.float32, device=decoder.device)
+    h, w = end_h - start_h, end_w - start_w
+    out = torch.empty((len(pair_indexes), 3, h, w), dtype=torch.float32, device=decoder.device)
+    scratch = torch.empty((h, w, 3), dtype=torch.uint8, device=decoder.device) if is_hsv else None
     for k, index in enumerate(pair_indexes):
-        decoder.decode(_frame_bytes(prefix_seq, index), start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode, out_f32=out[k])
+        if is_hsv:
+            decoder.decode(_frame_bytes(prefix_seq, index), start_h, end_h, start_w, end_w, downsampling_factor, "bgr", out_u8=scratch)
+            hsv_full(scratch, blue_index=0, out_f32=out[k])
+        else:
+            decoder.decode(_frame_bytes(prefix_seq, index), start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode, out_f32=out[k])
     return out
 
 
 def get_test_color_img(img_file_name, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False, rgb_mode="rgb", decoder=None):
-    """fp32 (H, W, 3) device tensor holding the uint8 values  [utils.py:72-83]"""
-    if is_hsv:
-        raise NotImplementedError("is_hsv=True is not part of the training configuration")
+    """fp32 (H, W, 3) device tensor holding the uint8 values  [utils.py:72-83]; is_hsv: cv2.COLOR_BGR2HSV_FULL of the BGR frame"""
     decoder = decoder or _decoder()
     out = torch.empty((end_h - start_h, end_w - start_w, 3), dtype=torch.uint8, device=decoder.device)
     with open(str(img_file_name), "rb") as fp:
-        decoder.decode(fp.read(), start_h, end_h, start_w, end_w, downsampling_factor, rgb_mode, out_u8=out)
+        decoder.decode(fp.read(), start_h, end_h, start_w, end_w, downsampling_factor, "bgr" if is_hsv else rgb_mode, out_u8=out)
+    if is_hsv:
+        hsv_full(out, blue_index=0, out_u8=out)
     return out.float()
 
 
 def get_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False, decoder=None):
     """uint8 (views, H, W, 3) DEVICE tensor in cv2 order (B, G, R): the values of the reference's float32 array  [utils.py:288-300]"""
-    return get_pair_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv, "bgr", decoder)
+    return get_pair_color_imgs(prefix_seq, visible_view_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv, "bgr", decoder)          # is_hsv: HSV_FULL frames, as the reference returns them
 
 
 # ---------------------------------------------------------------------------------------------
@@ -442,9 +467,10 @@ def point_brightness(imgs, point_cloud, view_indexes_per_point, mask_boundary, p
 def get_clean_point_list(imgs, point_cloud, view_indexes_per_point, mask_boundary, inlier_percentage, projection_matrices,
                          extrinsic_matrices, is_hsv=False):
     """float32 (points,) 1 = keep, 0 = contaminated: in at least half of the frames it appears in, the point's depth^2 x brightness
-    lies outside the window holding `inlier_percentage` of that frame's points  [utils.py:339-404].  imgs as reader.get_color_imgs."""
-    if is_hsv:
-        raise NotImplementedError("is_hsv=True is not part of the training configuration")
+    lies outside the window holding `inlier_percentage` of that frame's points  [utils.py:339-404].  imgs as reader.get_color_imgs in
+    cv2 order (B, G, R).  The reference's is_hsv branch first takes its HSV frames BACK to BGR (cv2.COLOR_HSV2BGR_FULL, utils.py:362-363)
+    and then runs the same filter: callers here hand over the BGR frames themselves (reader.load_sequence always does), so the flag
+    changes nothing -- up to the 8-bit loss of the reference's round trip."""
     n_points = len(point_cloud)
     if inlier_percentage <= 0.0 or inlier_percentage >= 1.0:
         return list()

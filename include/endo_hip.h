@@ -40,7 +40,7 @@ extern "C" {
  * adds endo_warp_consistency and endo_warp_fallback_blocks.
  * 4: round 3 -- the 16-bit-storage family (endo_net16_*, endo_net16h_*, endo_bf16_*, endo_f16_*).
  * 5: round 4 -- the non-finite-loss guard moves onto the device: endo_loss_head writes a FOURTH float (the flag),
- * endo_sgd_clip_step takes a `skip_flag` device pointer; endo_net16_offset what = 7. */
+ * endo_sgd_clip_step takes a `skip_flag` device pointer; endo_net16_offset what = 7; adds endo_hsv_full. */
 #define ENDO_ABI_VERSION 5
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
@@ -360,6 +360,13 @@ int endo_point_brightness(const uint8_t* imgs, int frames, int height, int width
                           const double* projections, const double* extrinsics, const float* visibility, const uint8_t* mask,
                           int d, double sigma_color, double sigma_space, int32_t* valid, double* depth, float* brightness,
                           void* stream);
+
+/* cv2.cvtColor(img, COLOR_BGR2HSV_FULL) (blue_index 0) / COLOR_RGB2HSV_FULL (blue_index 2) on 8-bit interleaved pixels -- the reader's
+ * HSV input mode, reference utils.py:449-450, 80-81 and dataset.py:434-442 (`--use_hsv_colorspace`).  OpenCV's scalar fixed-point
+ * arithmetic (H over [0, 256), tables round((255 << 12) / v), round((256 << 12) / (6 diff))); PARITY UNPINNED against cv2 itself (no
+ * converted image in the reference tree).  src [pixels][3] uint8; out_u8 [pixels][3] (H, S, V) and / or out_f32 [3][pixels] =
+ * (x / 255 - 0.5) / 0.5 (dataset.py:446-451); either may be null, src == out_u8 is allowed. */
+int endo_hsv_full(const uint8_t* src, int64_t pixels, int blue_index, uint8_t* out_u8, float* out_f32, void* stream);
 
 /* live per-kernel-family timing for bench.py's roofline line: HIP events recorded on the launch
  * stream around every entry of the selected families.  family_mask: bit f enables family f

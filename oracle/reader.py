@@ -387,14 +387,42 @@ def decode_jpeg_blocks(coefficients, quant, width, height):
     return ycc_to_rgb(y, cb, cr)
 
 
+def bgr_to_hsv_full(img_u8, blue_index=0):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2HSV_FULL) (blue_index 0) / COLOR_RGB2HSV_FULL (blue_index 2) on uint8, restated from OpenCV's
+    scalar 8-bit path (imgproc/src/color_hsv: RGB2HSV_b with hrange = 256): v = max, s = (diff * sdiv[v] + 2048) >> 12 with
+    sdiv[i] = round((255 << 12) / i), h = (hterm * hdiv[diff] + 2048) >> 12 with hdiv[i] = round((256 << 12) / (6 i)) and
+    hterm = g - b | b - r + 2 diff | r - g + 4 diff by which channel holds the maximum (r first, then g), + 256 when negative,
+    saturated to 8 bits.  PARITY UNPINNED: no cv2-converted image exists in the reference tree (reference utils.py:449-450,
+    dataset.py:434-442); known answers below come from the formula (pure red / green / blue -> h = 0 / 85 / 171, s = v = 255)."""
+    img = np.asarray(img_u8, dtype=np.uint8)
+    b = img[..., blue_index].astype(np.int64)
+    g = img[..., 1].astype(np.int64)
+    r = img[..., 2 - blue_index].astype(np.int64)
+    idx = np.arange(1, 256, dtype=np.float64)
+    sdiv = np.zeros(256, dtype=np.int64)
+    hdiv = np.zeros(256, dtype=np.int64)
+    sdiv[1:] = np.rint((255 << 12) / idx).astype(np.int64)          # saturate_cast<int>(double) = cvRound: half to even
+    hdiv[1:] = np.rint((256 << 12) / (6.0 * idx)).astype(np.int64)
+    v = np.maximum(np.maximum(b, g), r)
+    vmin = np.minimum(np.minimum(b, g), r)
+    diff = v - vmin
+    s = (diff * sdiv[v] + (1 << 11)) >> 12
+    hterm = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (hterm * hdiv[diff] + (1 << 11)) >> 12          # arithmetic shift: floor for negatives, as C++ >> on int
+    h = np.where(h < 0, h + 256, h)
+    return np.stack([np.clip(h, 0, 255), s, v], axis=-1).astype(np.uint8)
+
+
 def get_pair_color_imgs(prefix_seq, pair_indexes, start_h, end_h, start_w, end_w, downsampling_factor, is_hsv=False, rgb_mode="rgb"):
-    """utils.py:441-457 for is_hsv False: uint8 (2, H, W, 3)."""
-    assert not is_hsv, "the HSV branch is not part of the training configuration (train.py: is_hsv False)"
+    """utils.py:441-457: uint8 (2, H, W, 3); is_hsv: the BGR frame through cv2.COLOR_BGR2HSV_FULL (rgb_mode is then not looked at)."""
     imgs = []
     for i in pair_indexes:
         rgb = decode_jpeg_pil(os.path.join(str(prefix_seq), "%08d.jpg" % i))
         small = resize_linear(rgb, downsampling_factor)[start_h:end_h, start_w:end_w, :]
-        imgs.append(small if rgb_mode == "rgb" else small[..., ::-1])
+        if is_hsv:
+            imgs.append(bgr_to_hsv_full(small[..., ::-1], 0))
+        else:
+            imgs.append(small if rgb_mode == "rgb" else small[..., ::-1])
     return np.asarray(imgs, dtype=np.uint8)
 
 
