@@ -156,6 +156,19 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+}  // namespace endo
+
+// geometry.hip, used by head.hip: the fused depth-warp + consistency-loss kernels (endo_warp_consistency), forward (phase 1: memset,
+// forward kernel, and -- unless the caller asks for the loss only at the end -- the one-wave finalize) and backward (phase 2).  Not part
+// of the C ABI.  zero_grads: 1 = the forward kernel zeroes grad_depth_* and the backward kernel also writes the loss (the stand-alone
+// call); 0 = the caller has initialised grad_depth_* (the loss head: its flow terms) and reads the loss between the phases.
+int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
+                           const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics, float dcl_weight,
+                           float eps, float* loss, float* grad_depth_1, float* grad_depth_2, float* workspace, int n, int h, int w,
+                           int zero_grads, hipStream_t stream);
+
+namespace endo {
+
 // live profiling hooks (prof.hip)
 struct ProfScope {
     int family;

@@ -48,11 +48,7 @@ __global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl
 
 using namespace endo;
 
-// geometry.hip: the fused depth-warp + consistency-loss kernels, forward (phase 1) and backward (phase 2)
-int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
-                           const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics, float dcl_weight,
-                           float eps, float* loss, float* grad_depth_1, float* grad_depth_2, float* workspace, int n, int h, int w,
-                           int zero_grads, hipStream_t stream);
+// (endo_consistency_phase: geometry.hip, declared in common.h)
 
 // (endo_warp_consistency -- the depth-warp + consistency-loss chain as two fused kernels -- lives in geometry.hip.)
 
