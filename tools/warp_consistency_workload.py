@@ -8,7 +8,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("endoscopydepthestimation-pytorch_amd")
 dev = torch.device("cuda:0")
-n, h, w = 8, 256, 320
+n, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (8, 256, 320)
 batch = {k: v.to(dev) for k, v in pkg.synthetic.make_batch(n, h, w, seed=0).items()}
 d1 = pkg.synthetic.smooth_depth(n, h, w, seed=1).to(dev)
 d2 = pkg.synthetic.smooth_depth(n, h, w, seed=2).to(dev)
