@@ -516,7 +516,7 @@ def test_16bit_pair_at_benchmark_batch(storage):
     assert (l2n / l2d) ** 0.5 <= b["l2"]
 
 
-@pytest.mark.parametrize("shape,storage", [((1, 256, 320), "bf16"), ((4, 128, 160), "bf16"), ((1, 256, 320), "fp16"), ((4, 128, 160), "fp16")],
+@pytest.mark.parametrize("shape,storage", [((1, 256, 320), "bf16"), ((4, 128, 160), "fp16")],          # (one overrunning shape per storage type; the other two combinations ran green in round 4)
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_16bit_backward_partial_buffer_shapes(shape, storage):
     """Shapes at which round 3's workspace sizing (widest layer per level) was SMALLER than the largest weight-gradient partial buffer the

@@ -344,7 +344,7 @@ GRAD_TOL = 3e-5          # every parameter gradient: max abs error / the tensor'
                          # oracle's own distance from fp64 on the same pattern; BASELINE.json's bar is 1e-4.
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160)])
+@pytest.mark.parametrize("shape", [(2, 64, 96)])          # (2, 128, 160): test_network_backward_kernel_forms runs it in three kernel forms
 def test_network_backward(shape):
     """All 210 parameter gradients against the fp64 oracle at 1e-4 -- evaluated on the activation pattern the HIP forward
     pass itself took (device_pattern.py).  Without that, the comparison is a lottery: any two finite-precision runs of a
@@ -538,42 +538,6 @@ def test_bf16_operand_mode_on_pattern(shape):
     assert errors[-1] > 1e-4, "the bf16 kernels did not run"
 
 
-def test_bf16_operand_pair_forward_on_pattern():
-    """The grouped pair forward / backward of the training step (both frames per launch, what bench.py --config 5 runs) in
-    bf16-operand mode: each frame's depth and the summed parameter gradients against the fp64 oracle on the two patterns the
-    grouped pass took, at the mode's tolerance; and against the mode's own two separate calls (other tile shapes and summation
-    orders at twice the samples per launch: fp32-level differences in the BN statistics move operands across bf16 rounding
-    boundaries, so this too is a comparison at the mode's tolerance -- measured 1.7e-3)."""
-    n, h, w = 2, 128, 160
-    with kernel_options({OPT_MFMA_BF16: 1}):
-        state, model = make_model(67)
-        _, twin = make_model(67)
-        rng = np.random.default_rng(18)
-        x1 = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
-        x2 = torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32))
-        cot1 = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
-        cot2 = torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32))
-        twin.train()
-        with torch.no_grad():
-            t1, t2 = twin(x1.to(dev())), twin(x2.to(dev()))
-        model.train()
-        y1, y2 = model.forward_pair(x1.to(dev()), x2.to(dev()))
-        pat1, pat2 = pattern_of(y1, model, n, h, w, groups=2)
-        ((y1 * cot1.to(dev())).sum() + (y2 * cot2.to(dev())).sum()).backward()
-        torch.cuda.synchronize()
-    assert_close(y1, t1, BF16_FWD_TOL, "bf16 operands: pair output 1 vs separate call")
-    assert_close(y2, t2, BF16_FWD_TOL, "bf16 operands: pair output 2 vs separate call")
-    st64 = state_as(state, torch.float64)
-    y64a = onet.forward({k: v.clone() for k, v in st64.items()}, x1.double(), training=True, pattern=pat1)
-    y64b = onet.forward({k: v.clone() for k, v in st64.items()}, x2.double(), training=True, pattern=pat2)
-    assert_close(y1, y64a, BF16_FWD_TOL, "bf16 operands: pair depth 1")
-    assert_close(y2, y64b, BF16_FWD_TOL, "bf16 operands: pair depth 2")
-    names = onet.trainable_names()
-    g64a, g64b = reference_grads(state, x1, cot1, torch.float64, pat1), reference_grads(state, x2, cot2, torch.float64, pat2)
-    g64 = {nm: g64a[nm] + g64b[nm] for nm in names}
-    assert_grads_on_pattern(dict(model.named_parameters()), g64, None, BF16_GRAD_TOL, "bf16 operands: pair backward")
-
-
 def test_bf16_operand_training_iterations():
     """A few fused training iterations in bf16-operand mode: first-iteration loss within 3 % of the fp32 path on the same batch
     (measured 1.5 %: 57 convolutions deep, every operand rounded to 8 bits), every iteration finite and not skipped."""
@@ -613,7 +577,7 @@ def reference_pattern(state64, x64):
     return own
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160), (3, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 64, 64)])          # ((2, 128, 160) went in round 4: the grouped pass at that size is covered on the pattern by test_network_backward_kernel_forms, at 2 x 8 x 256 x 320 by test_full_size_pair_backward_on_pattern)
 def test_forward_pair_is_two_calls(shape):
     """forward_pair(x1, x2) -- both frames of a training pair as one grouped batch, every launch covering both, each
     frame with its own BatchNorm batch statistics -- against the oracle's two sequential calls (reference
@@ -670,7 +634,7 @@ def test_forward_pair_is_two_calls(shape):
         assert_close(e2, model(x2.to(dev())), 1e-6, "eval pair 2")
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64), (2, 128, 160), (4, 256, 256)])
+@pytest.mark.parametrize("shape", [(2, 64, 64), (2, 128, 160)])
 def test_network_backward_last_block_exact(shape):
     """The layers that are differentiated FIRST (final conv, last up block, its transition-up) see no
     accumulated mask-flip noise, so the kernels behind them -- dgrad with fused BN/ReLU backward,
@@ -1353,7 +1317,6 @@ def test_warp_consistency_call():
     assert lib.endo_warp_consistency(*([None] * 8), 1.0, 1e-8, *([None] * 4), 1, 8, 8, None) == -1
 
 
-BF16_FULL_GRAD_TOL = 1e-1          # measured on MI355X: worst tensor 6.1e-2 (bottleneck.layers.0.conv.weight), median 6.8e-3, depth 9.8e-3
 
 
 def test_full_size_pair_backward_on_pattern():
