@@ -34,7 +34,8 @@ constexpr int kNsBuf = 12 * kNsMap + 64;           // + zero rows read by the un
 constexpr int kNsMG = 7;
 constexpr int kNsUnits = 12 * kNsMap / 4;          // 360 float4
 
-// EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x loads, 2 = no dY DMA, 4 = no barrier
+// EXP: diagnostic bit mask for tools/conv_bench (0 in the library): 1 = no x loads, 2 = no dY DMA, 4 = no barrier,
+// 8 = fragment reads at consecutive (conflict-free, wrong) LDS addresses: what the 61 % bank conflicts of the real gathers cost
 // BF: 1 = bf16 MFMA operands (fp32 accumulation, fp32 memory): the 8 k-steps of a lane's two float4s become one v_mfma_f32_16x16x32_bf16;
 // 2 = fp32 operands as three bf16 terms each, six such MFMAs (fp32-accurate: common.h split_bf16x8)
 template <int NG, int EXP = 0, int BF = 0>
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(kConvThreads) wgrad_nsplit_kernel(const WgradP
             for (int e = 0; e < 4; ++e) {
                 float a[kNsMG];
 #pragma unroll
-                for (int m = 0; m < kNsMG; ++m) a[m] = s_dy[aoff[m] + 16 * q + e];
+                for (int m = 0; m < kNsMG; ++m) a[m] = s_dy[((EXP & 8) ? lane + 64 * m : aoff[m]) + 16 * q + e];          // EXP 8: conflict-free (wrong) addresses
 #pragma unroll
                 for (int g = 0; g < NG; ++g)
                     if (g < ngw) {          // wave-uniform
