@@ -13,6 +13,7 @@
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_taps_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_nsplit_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_x3_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_f34_kernels.h"
 
 using namespace endo;
 
@@ -91,12 +92,12 @@ int main(int argc, char** argv) {
     double maxref = 0; for (double v : ref) maxref = fmax(maxref, fabs(v));
 
     struct V { const char* name; int mode; };
-    const V vs[] = {{"fp32 MFMA (v_mfma_f32_16x16x4_f32)", 0}, {"operands rounded to bf16 (1 x bf16 MFMA)", 1}, {"three-term split per fragment, 6 x bf16 MFMA", 2}, {"three-term split, G pre-split in LDS (wgrad_x3_kernel)", 3}, {"diagnostic: 6 MFMAs on rounded operands, no split", 5}, {"diagnostic: fp32 MFMA, conflict-free (wrong) fragment addresses", 6}};
+    const V vs[] = {{"fp32 MFMA (v_mfma_f32_16x16x4_f32)", 0}, {"operands rounded to bf16 (1 x bf16 MFMA)", 1}, {"three-term split per fragment, 6 x bf16 MFMA", 2}, {"three-term split, G pre-split in LDS (wgrad_x3_kernel)", 3}, {"diagnostic: 6 MFMAs on rounded operands, no split", 5}, {"diagnostic: fp32 MFMA, conflict-free (wrong) fragment addresses", 6}, {"Winograd F(3x3, 4x4), fp32 MFMA (wgrad_f34_kernel)", 7}, {"diagnostic: F(3x3, 4x4) without x loads", 9}};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<float> got((size_t)12 * cin * 9);
     for (const V& v : vs) {
         CK(hipMemset(dw, 0, got.size() * 4));
-        auto run = [&](int mode) { if (mode == 6) { const int groups = (g.cin + 15) / 16, passes = (groups + 11) / 12, ng = ((groups + passes - 1) / passes + 3) / 4; return ng <= 1 ? launch_wgrad_nsplit_ng<1, 8>(g, wscratch, passes, 0) : ng == 2 ? launch_wgrad_nsplit_ng<2, 8>(g, wscratch, passes, 0) : launch_wgrad_nsplit_ng<3, 8>(g, wscratch, passes, 0); } return mode == 3 ? launch_wgrad_x3(g, wscratch, 0) : launch_wgrad_nsplit(g, wscratch, 0, mode == 5 ? 3 : mode); };
+        auto run = [&](int mode) { if (mode == 6) { const int groups = (g.cin + 15) / 16, passes = (groups + 11) / 12, ng = ((groups + passes - 1) / passes + 3) / 4; return ng <= 1 ? launch_wgrad_nsplit_ng<1, 8>(g, wscratch, passes, 0) : ng == 2 ? launch_wgrad_nsplit_ng<2, 8>(g, wscratch, passes, 0) : launch_wgrad_nsplit_ng<3, 8>(g, wscratch, passes, 0); } if (mode == 7) return wgrad_f34_ok(g) ? launch_wgrad_f34(g, wscratch, 0) : -1; if (mode == 9) return launch_wgrad_f34<2>(g, wscratch, 0); return mode == 3 ? launch_wgrad_x3(g, wscratch, 0) : launch_wgrad_nsplit(g, wscratch, 0, mode == 5 ? 3 : mode); };
         int rc = run(v.mode);
         if (rc) { printf("%s: launch failed %d\n", v.name, rc); continue; }
         CK(hipDeviceSynchronize());
