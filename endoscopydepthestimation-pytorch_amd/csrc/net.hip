@@ -23,6 +23,7 @@
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
 #include "wgrad_x3_kernels.h"
+#include "wgrad_f34_kernels.h"
 #include "wgrad_subpix_kernels.h"
 #include "wino_fwd_kernels.h"
 #include "dgrad_wino_kernels.h"
@@ -558,6 +559,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //                            the chip several times; tests set 1 to reach the kernels at small sizes)
 //   ENDO_OPT_MFMA_X3         bit mask of the kernel families (1 wgrad, 2 forward, 4 dgrad) that evaluate fp32 products as three-term bf16 splits (common.h)
 //   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
+//   ENDO_OPT_WGRAD_F34       1 = dense weight gradients of the fine levels in the Winograd domain F(3x3, 4x4) (wgrad_f34_kernels.h)
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 1;
     opt[ENDO_OPT_WINO_DGRAD] = 1;
@@ -566,6 +568,7 @@ static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_MFMA_BF16] = 0;
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
     opt[ENDO_OPT_MFMA_X3] = 0;
+    opt[ENDO_OPT_WGRAD_F34] = 1;
 }
 static int wino_fwd_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_FWD]; }
 static bool wino_fwd_enabled(const Ctx& c) { return wino_fwd_mode(c) != 0; }
@@ -770,6 +773,8 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
+    if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_ok(p, 16l * c.net->opt[ENDO_OPT_WINO_MIN_TILES]))
+        return launch_wgrad_f34(p, c.gradws + c.net->wg_scratch_off, c.stream);          // Winograd F(3x3, 4x4)
     if (wgrad_nsplit_ok(p)) {
         if (wgrad_mfma_mode(c) == 2) return launch_wgrad_x3(p, c.gradws + c.net->wg_scratch_off, c.stream);          // fp32 products as bf16 splits (wgrad_x3_kernels.h)
         return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, wgrad_mfma_mode(c));
@@ -1077,7 +1082,7 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->slot_stride = align_up(tb.bn_width_total * 2, 32);
     net->scratch_bytes = net->slot_stride * 8 * kBnSlots;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
-    net->tuw_scratch_off = net->wg_scratch_off + (kNsScratchFloats > kSpScratchFloats ? kNsScratchFloats : kSpScratchFloats);
+    net->tuw_scratch_off = net->wg_scratch_off + std::max(std::max(kNsScratchFloats, kSpScratchFloats), kF34ScratchFloats);
     net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
     net->gradws_floats = net->wd_off + tb.wino_dgrad_floats;
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates

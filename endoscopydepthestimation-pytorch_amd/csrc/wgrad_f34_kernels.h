@@ -172,8 +172,10 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         const int yseg = rest % YS;
         const int n = rest / YS;
         const WgSample sm(p, n);
-        const __amdgpu_buffer_rsrc_t xr = f34_rsrc(p.in + sm.in_off(p), static_cast<int>(p.in_ns * 4));
-        const __amdgpu_buffer_rsrc_t gr = f34_rsrc(p.dy + sm.dy_off(p), static_cast<int>(p.dy_ns * 4));
+        // descriptors over this sample's cin activation planes / 12 gradient planes: anything past them (the padding channels of the last
+        // group, the rows below the last plane) reads zeros
+        const __amdgpu_buffer_rsrc_t xr = f34_rsrc(p.in + sm.in_off(p), p.cin * p.in_cs * 4);
+        const __amdgpu_buffer_rsrc_t gr = f34_rsrc(p.dy + sm.dy_off(p), 12 * p.dy_cs * 4);
         if (sm.grp != cst_grp) {
             const float* saved = p.saved + sm.grp * p.gs;
             sc = 0.f; sh = 0.f;
@@ -343,18 +345,18 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
 }
 
 constexpr int kF34Blocks = 512;                      // two blocks of four waves per CU
-constexpr int kF34MinQuads = 1024;
+constexpr int kF34MinTiles = 1024 * 16;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
 // scratch: groups * 9 rows of `slots` x 256 floats, groups * slots <= 8 * 256 waves
 constexpr int64_t kF34ScratchFloats = static_cast<int64_t>(9) * 8 * kF34WavesPerXcd * 256;
 
-inline bool wgrad_f34_ok(const WgradParams& p) {
+inline bool wgrad_f34_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
     const bool aligned = (p.w % 16 == 0) && (p.h % 16 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
                          (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
     const long quads = static_cast<long>(p.w / 16) * (p.h / 16) * p.n;
     // (the buffer descriptors address one sample with 32-bit byte offsets)
-    const bool small = p.in_ns * 4 < (1ll << 31) && p.dy_ns * 4 < (1ll << 31);
-    return aligned && small && p.cout == 12 && p.cin >= 16 && (p.cin + 15) / 16 <= kF34WavesPerXcd && quads >= kF34MinQuads;
+    const bool small = static_cast<int64_t>(p.in_cs) * (p.cin + 16) * 4 < (1ll << 31) && static_cast<int64_t>(p.dy_cs) * 12 * 4 < (1ll << 31);
+    return aligned && small && p.cout == 12 && p.cin >= 16 && (p.cin + 15) / 16 <= kF34WavesPerXcd && quads * 16 >= min_tiles;
 }
 
 // waves per group and segment length: the longest segments (fewest restarts) among those that keep the waves evenly loaded

@@ -224,7 +224,11 @@ int endo_net_groups(const endo_net* net);
  *                            6 / 16 of the fp32 matrix instructions' issue time.  Ignored where ENDO_OPT_MFMA_BF16 selects rounded operands.
  *   ENDO_OPT_WGRAD_OVERLAP   endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient
  *                            chain and joined before it returns: 1 (default); 0 puts them back in line on the
- *                            caller's stream (clean per-kernel timings) */
+ *                            caller's stream (clean per-kernel timings)
+ *   ENDO_OPT_WGRAD_F34       dense-layer weight gradient at the fine levels (width and height multiples of 16): 1 (default) = in the
+ *                            Winograd domain, F(3x3, 4x4) -- 36 multiplications per 4 x 4 tile of the output gradient instead of 144,
+ *                            fp32 throughout (csrc/wgrad_f34_kernels.h); 0 = the direct kernels.  Ignored where ENDO_OPT_MFMA_BF16 or
+ *                            ENDO_OPT_MFMA_X3 select another operand form for the weight gradients. */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2
@@ -232,7 +236,8 @@ int endo_net_groups(const endo_net* net);
 #define ENDO_OPT_MFMA_BF16 4
 #define ENDO_OPT_WGRAD_OVERLAP 5
 #define ENDO_OPT_MFMA_X3 6
-#define ENDO_OPT_COUNT 7
+#define ENDO_OPT_WGRAD_F34 7
+#define ENDO_OPT_COUNT 8
 int endo_net_set_option(endo_net* net, int option_id, int value);
 int endo_net_get_option(const endo_net* net, int option_id);
 int64_t endo_net_group_stride(const endo_net* net);

@@ -386,7 +386,7 @@ def test_network_backward(shape):
     assert_close(model.flat_gradients(), 2.0 * first, 1e-5, "accumulated gradient")
 
 
-OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES, OPT_MFMA_BF16, OPT_WGRAD_OVERLAP, OPT_MFMA_X3 = 0, 1, 2, 3, 4, 5, 6
+OPT_WINO_FWD, OPT_WINO_DGRAD, OPT_DGRAD_VEC, OPT_WINO_MIN_TILES, OPT_MFMA_BF16, OPT_WGRAD_OVERLAP, OPT_MFMA_X3, OPT_WGRAD_F34 = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class kernel_options(object):
@@ -443,14 +443,15 @@ def test_kernel_options_are_per_model():
                                          ("x3", (2, 128, 160))],          # x3: needs >= 2048 row chunks at level 0 to reach the n-split / x3 weight-gradient kernels
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_network_backward_kernel_forms(shape, which):
-    """The Winograd kernels (dense-layer forward, fused base-channel data gradient) are chosen by launch size and the parity
+    """The Winograd kernels (dense-layer forward, fused base-channel data gradient, F(3x3, 4x4) weight gradient where width and height are
+    multiples of 16) are chosen by launch size and the parity
     tests above are too small to reach them: here they are forced on (ENDO_OPT_WINO_MIN_TILES = 1) or off for every eligible
     level and all 210 gradients are checked on the pass's own activation pattern as in test_network_backward -- so both forms
     of every such layer are held to the same 3e-5, at sizes the fp64 oracle finishes in seconds."""
     n, h, w = shape
     # "x3": the dense weight gradient with its fp32 products as three-term bf16 splits on the bf16 matrix cores (ENDO_OPT_MFMA_X3 bit 0,
     # csrc/wgrad_x3_kernels.h; DESIGN.md 4.15: not the default) -- the SAME function, held to the same fp32 bound
-    opts = {OPT_WINO_MIN_TILES: 1} if which == "winograd" else ({OPT_MFMA_X3: 1} if which == "x3" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0})
+    opts = {OPT_WINO_MIN_TILES: 1} if which == "winograd" else ({OPT_MFMA_X3: 1} if which == "x3" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0, OPT_WGRAD_F34: 0})
     with kernel_options(opts):
         state, model = make_model(62)
         rng = np.random.default_rng(16)
