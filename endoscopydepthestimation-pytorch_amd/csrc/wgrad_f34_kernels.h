@@ -17,7 +17,7 @@
 //     stay in registers).  Loading them lane by lane costs the L1 one tag look-up per lane and instruction (16 channel planes: no two
 //     lanes share a line; the texture cache was 2/3 busy, the waves waited on it 38 % of their time), so they arrive COALESCED through
 //     LDS-DMA: buffer_load_dwordx4 ... lds, lane e of instruction i = channel 2 i + (e >> 5), row (e >> 3) & 3, 16-byte unit e & 7 of a
-//     32-column window, straight into a wave-private LDS image (8.4 KB), one step ahead, no registers; each lane then reads a float4 and
+//     32-column window, straight into one of two wave-private LDS images (8.4 KB each), two steps ahead, no registers; each lane then reads a float4 and
 //     the two halo columns per row, applies BN + ReLU and runs the 6 x 6 input transform (packed fp32 where the pairs fall out naturally).
 //   * G: lane (co = lane & 15, tile = lane >> 4) loads its 4 x 4 tile and transforms it in registers -- exactly the A operand's layout
 //     (lanes co >= 12 load out of the descriptor's range, i.e. zeros).  The scale factors of S (1/4, -1/6, 1/24) are folded into the
@@ -102,7 +102,7 @@ __device__ __forceinline__ float f34_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff
 // EXP (tools/x3_bench only): 2 = no x loads
 template <int EXP = 0>
 __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradParams p, float* __restrict__ partial, const F34Plan plan) {
-    __shared__ __attribute__((aligned(16))) float smem[4 * kF34Xs];
+    extern __shared__ __attribute__((aligned(16))) float smem[];          // [wave][2 images]: the rows of the next two steps
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     const int ch = 16 * group + li;
     const bool ch_ok = ch < p.cin;
     const unsigned bo = 4u * static_cast<unsigned>(min(ch, p.cin - 1) * p.in_cs + 4 * lk);          // (lane-by-lane loads of a segment's first rows)
-    float* const xs = smem + wave * kF34Xs;
+    float* const xs = smem + wave * 2 * kF34Xs;
     const unsigned x_vo = 4u * static_cast<unsigned>((lane >> 5) * p.in_cs + ((lane >> 3) & 3) * p.in_w + 4 * (lane & 7));
     const float* const xs_r = xs + (li >> 1) * kF34XsPair + (li & 1) * 128 + 4 * lk;
     const unsigned x_grp = 4u * static_cast<unsigned>(16 * group * p.in_cs);
@@ -155,14 +155,15 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     // starts 8 columns left of the strip (at column 0 for the first strip); rows below the image and columns past the row end are whatever
     // follows in memory (zeros past the sample) and are zeroed after BN + ReLU.
     // Of the window's 8 units the reads touch columns 7 .. 24 (units 1 .. 6), 0 .. 16 for the first strip (units 0 .. 4): the other lanes stay out.
-    auto x_issue = [&](const __amdgpu_buffer_rsrc_t r, int s, int row) {
+    auto x_issue = [&](const __amdgpu_buffer_rsrc_t r, int s, int row, int img) {
         const unsigned so = x_grp + 4u * static_cast<unsigned>(row * p.in_w + 16 * s - (s > 0 ? 8 : 0));
         const int unit = lane & 7;
+        float* dst = xs + img * kF34Xs;
         if (s > 0 ? (unit >= 1 && unit <= 6) : unit <= 4) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (!(EXP & 2))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(xs + i * kF34XsPair), 16, x_vo, so + 8u * static_cast<unsigned>(i * p.in_cs), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)(dst + i * kF34XsPair), 16, x_vo, so + 8u * static_cast<unsigned>(i * p.in_cs), 0, 0);
         }
     };
 
@@ -191,9 +192,10 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         const int rd_shift = s > 0 ? 8 : 0;          // where the strip's first column sits in the staged window
         const int row_begin = 16 * yseg * segq, row_end = row_begin + 16 * segq;
 
-        // the segment's first step: its four new rows on their way, image rows row_begin - 1 and row_begin lane by lane meanwhile
-        // (the previous segment's last step has consumed the image: every LDS read of it was waited for)
-        x_issue(xr, s, row_begin + 1);
+        // the segment's first two steps: their new rows on their way (image 0, image 1), image rows row_begin - 1 and row_begin lane by
+        // lane meanwhile (the previous segment's last steps have consumed both images: every LDS read of them was waited for)
+        x_issue(xr, s, row_begin + 1, 0);
+        if (row_begin + 4 < row_end) x_issue(xr, s, row_begin + 5, 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row = row_begin - 1 + i;
@@ -218,14 +220,16 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gt[i] = f34_ld4(gr, g_vo, so + i * pitch);
             }
-            // the step's x rows are in LDS once at most the four G loads are in flight
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            // the step's x rows are in LDS once at most the next step's 8 DMAs and the four G loads are in flight
+            const int img = ((row - row_begin) >> 2) & 1;
+            if (row + 4 < row_end) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             float d[6][6];          // [row][column in the order 0, 5, 1, 2, 3, 4]
 #pragma unroll
             for (int e = 0; e < 6; ++e) { d[0][e] = keep[0][e]; d[1][e] = keep[1][e]; }
             {
-                const float* rp = xs_r + rd_shift;
+                const float* rp = xs_r + img * kF34Xs + rd_shift;
                 f32x4 m[4];
                 float hl[4], hr[4];
 #pragma unroll
@@ -237,7 +241,7 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
                 // every read of the image has returned: the next step's rows may overwrite it
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (row + 4 < row_end) x_issue(xr, s, row + 5);
+                if (row + 8 < row_end) x_issue(xr, s, row + 9, img);          // two steps ahead, into the image just read
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) act_row(hl[i], m[i], hr[i], sc_e, sh_e, d[2 + i]);
@@ -345,7 +349,7 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
 }
 
 constexpr int kF34Blocks = 512;                      // two blocks of four waves per CU
-constexpr int kF34MinTiles = 1024 * 16;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
+constexpr int kF34MinTiles = 4096;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
 // scratch: groups * 9 rows of `slots` x 256 floats, groups * slots <= 8 * 256 waves
 constexpr int64_t kF34ScratchFloats = static_cast<int64_t>(9) * 8 * kF34WavesPerXcd * 256;
 
@@ -381,7 +385,9 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p) {
 template <int EXP = 0>
 inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream) {
     const F34Plan plan = wgrad_f34_plan(p);
-    wgrad_f34_kernel<EXP><<<kF34Blocks, kConvThreads, 0, stream>>>(p, scratch, plan);
+    constexpr int lds = 4 * 2 * kF34Xs * 4;          // 67,584 bytes per block, two blocks per CU
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    wgrad_f34_kernel<EXP><<<kF34Blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
     ENDO_LAUNCH_CHECK();
     wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();

@@ -97,7 +97,7 @@ int main(int argc, char** argv) {
     std::vector<float> got((size_t)12 * cin * 9);
     for (const V& v : vs) {
         CK(hipMemset(dw, 0, got.size() * 4));
-        auto run = [&](int mode) { if (mode == 6) { const int groups = (g.cin + 15) / 16, passes = (groups + 11) / 12, ng = ((groups + passes - 1) / passes + 3) / 4; return ng <= 1 ? launch_wgrad_nsplit_ng<1, 8>(g, wscratch, passes, 0) : ng == 2 ? launch_wgrad_nsplit_ng<2, 8>(g, wscratch, passes, 0) : launch_wgrad_nsplit_ng<3, 8>(g, wscratch, passes, 0); } if (mode == 7) return wgrad_f34_ok(g) ? launch_wgrad_f34(g, wscratch, 0) : -1; if (mode == 9) return launch_wgrad_f34<2>(g, wscratch, 0); return mode == 3 ? launch_wgrad_x3(g, wscratch, 0) : launch_wgrad_nsplit(g, wscratch, 0, mode == 5 ? 3 : mode); };
+        auto run = [&](int mode) { if (mode == 6) { const int groups = (g.cin + 15) / 16, passes = (groups + 11) / 12, ng = ((groups + passes - 1) / passes + 3) / 4; return ng <= 1 ? launch_wgrad_nsplit_ng<1, 8>(g, wscratch, passes, 0) : ng == 2 ? launch_wgrad_nsplit_ng<2, 8>(g, wscratch, passes, 0) : launch_wgrad_nsplit_ng<3, 8>(g, wscratch, passes, 0); } if (mode == 7) return wgrad_f34_ok(g, 16) ? launch_wgrad_f34(g, wscratch, 0) : -1; if (mode == 9) return launch_wgrad_f34<2>(g, wscratch, 0); return mode == 3 ? launch_wgrad_x3(g, wscratch, 0) : launch_wgrad_nsplit(g, wscratch, 0, mode == 5 ? 3 : mode); };
         int rc = run(v.mode);
         if (rc) { printf("%s: launch failed %d\n", v.name, rc); continue; }
         CK(hipDeviceSynchronize());
