@@ -26,6 +26,7 @@
 #include "wgrad_f34_kernels.h"
 #include "wgrad_subpix_kernels.h"
 #include "wino_fwd_kernels.h"
+#include "wino4_fwd_kernels.h"
 #include "dgrad_wino_kernels.h"
 #include "dgrad_wino3_kernels.h"
 
@@ -55,6 +56,8 @@ struct Table {
     std::vector<BnP*> bn_order;           // 49 BN layers in module order
     int64_t param_floats = 0, bn_floats = 0, bn_width_total = 0;
     WinoWeightTable wino;                 // the 44 dense layers' forward weights in Winograd form (wino_fwd_kernels.h)
+    WinoWeightTable wino4;                // the same layers in F(4x4, 3x3) form (wino4_fwd_kernels.h): u_off in floats of ITS buffer
+    int64_t wino4_floats = 0;
     int64_t wino_floats = 0;
     WinoDgradTable wino_dgrad;            // and their data-gradient weights over the base channels of their block (dgrad_wino_kernels.h)
     int64_t wino_dgrad_floats = 0;
@@ -110,6 +113,10 @@ static const Table& table() {
             for (int j = 0; j < kLayers; ++j) add(tb->bott_conv[j]);
             for (int i = 0; i < kLevels; ++i) for (int j = 0; j < kLayers; ++j) add(tb->up_conv[i][j]);
             tb->wino_floats = uoff;
+            tb->wino4 = wt;
+            int64_t u4 = 0;
+            for (int l = 0; l < wt.layers; ++l) { tb->wino4.u_off[l] = u4; u4 += static_cast<int64_t>(wt.cin[l]) * kW4UStride; }
+            tb->wino4_floats = u4;
         }
         {   // data-gradient weights in Winograd form: per dense block, the 16-channel groups of its base channels, for each of its layers
             WinoDgradTable& wd = tb->wino_dgrad;
@@ -149,6 +156,7 @@ struct endo_net {
     int64_t tape_floats;
     int64_t partial_off;   // split-K partial sums of the coarse-level dense layers (floats, tape)
     int64_t wino_off;      // Winograd-domain forward weights of the dense layers (floats, tape; group 0's copy serves all groups)
+    int64_t wino4_off;     // the same in F(4x4, 3x3) form
     int64_t pq_off;        // floats, gradws: P then Q per level channel
     int64_t pq_floats;
     int64_t scratch_off;   // byte offset in gradws of fp64 BN scratch
@@ -597,6 +605,12 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
     // 32 x 16 pixel tiles while they fill the chip several times over, 32 x 8 below that.
+    if (wino_fwd_mode(c) == 5 && cv.u >= 0 && !mfma_bf16_fwd(c)) {          // F(4x4, 3x3): 36 instead of 64 products per 16 pixels (wino4_fwd_kernels.h)
+        ConvParams p4 = p;
+        p4.wgt = c.tape + c.net->wino4_off + cv.u / kWinoUStride * kW4UStride;
+        const long t4 = static_cast<long>((lv.w + 63) / 64) * ((lv.h + 15) / 16) * c.nt();
+        if (wino4_fwd_ok(p4) && 2 * t4 >= c.net->opt[ENDO_OPT_WINO_MIN_TILES]) return launch_wino4_fwd(p4, c.stream);          // (level 0 of configs[1]: at level 1 the 64 x 16 blocks no longer fill the chip, measured slower)
+    }
     if (wino_fwd_enabled(c) && cv.u >= 0 && !mfma_bf16_fwd(c)) {
         ConvParams pw = p;
         pw.wgt = c.tape + c.net->wino_off + cv.u;          // group 0's tape: weights are shared by the groups
@@ -1075,6 +1089,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     byte_off += static_cast<int64_t>(kGrowth) * 163840 * 4;     // bound: see dense_fwd
     net->wino_off = byte_off / 4;
     byte_off += align_up(tb.wino_floats * 4, 256);
+    net->wino4_off = byte_off / 4;
+    byte_off += align_up(tb.wino4_floats * 4, 256);
     net->tape_floats = byte_off / 4;
     net->pq_off = acts;
     net->pq_floats = 2 * pq;
@@ -1157,6 +1173,8 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     if (wino_fwd_enabled(c) && !mfma_bf16_fwd(c)) {          // dense-layer weights in Winograd form, all 44 layers in one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * (tb.wino_floats + tb.wino_floats * 9 / 16));
         wino_fwd_weights_kernel<<<(tb.wino.start[tb.wino.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino, params, tape + net->wino_off);
+        ENDO_LAUNCH_CHECK();
+        if (wino_fwd_mode(c) == 5) wino4_fwd_weights_kernel<<<(tb.wino4.start[tb.wino4.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino4, params, tape + net->wino4_off);
         ENDO_LAUNCH_CHECK();
     }
     int rc;

@@ -440,6 +440,7 @@ def test_kernel_options_are_per_model():
 
 @pytest.mark.parametrize("which,shape", [("winograd", (2, 64, 96)), ("winograd", (2, 128, 160)), ("winograd", (1, 64, 128)),
                                          ("direct", (2, 64, 96)), ("direct", (2, 128, 160)), ("direct", (1, 64, 128)),
+                                         ("winograd4", (2, 64, 96)), ("winograd4", (2, 128, 160)), ("winograd4", (1, 64, 128)),
                                          ("x3", (2, 128, 160))],          # x3: needs >= 2048 row chunks at level 0 to reach the n-split / x3 weight-gradient kernels
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_network_backward_kernel_forms(shape, which):
@@ -451,7 +452,12 @@ def test_network_backward_kernel_forms(shape, which):
     n, h, w = shape
     # "x3": the dense weight gradient with its fp32 products as three-term bf16 splits on the bf16 matrix cores (ENDO_OPT_MFMA_X3 bit 0,
     # csrc/wgrad_x3_kernels.h; DESIGN.md 4.15: not the default) -- the SAME function, held to the same fp32 bound
-    opts = {OPT_WINO_MIN_TILES: 1} if which == "winograd" else ({OPT_MFMA_X3: 1} if which == "x3" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0, OPT_WGRAD_F34: 0})
+    # "winograd4": the dense-layer forward in F(4x4, 3x3) form (ENDO_OPT_WINO_FWD = 5, csrc/wino4_fwd_kernels.h) wherever height and width allow.
+    # Its transforms carry factors up to 8: the depth is held to 2e-5 of its maximum (measured 4e-6 .. 6e-6; the other forms 1e-5, measured 1e-6),
+    # the gradients -- taken on the pass's own pattern, from activations that carry the forward's rounding -- to 1.6e-4 (measured 5.8e-5 .. 1.1e-4
+    # with EVERY level in this form, as forced here).  NOT the default: five times the forward rounding flips more ReLU / pooling decisions,
+    # and the full-size step's gradients moved from 2x to 3x the reference's own distance from fp64.
+    opts = {OPT_WINO_MIN_TILES: 1, OPT_WINO_FWD: 1} if which == "winograd" else {OPT_WINO_MIN_TILES: 1, OPT_WINO_FWD: 5} if which == "winograd4" else ({OPT_MFMA_X3: 1} if which == "x3" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0, OPT_WGRAD_F34: 0})
     with kernel_options(opts):
         state, model = make_model(62)
         rng = np.random.default_rng(16)
@@ -465,8 +471,8 @@ def test_network_backward_kernel_forms(shape, which):
     params = dict(model.named_parameters())
     g64p = reference_grads(state, x, cot, torch.float64, pattern)
     y64 = onet.forward(state_as(state, torch.float64), x.double(), training=True, pattern=pattern)
-    assert_close(y, y64, 1e-5, "depth, %s kernels" % which)
-    assert_grads_on_pattern(params, g64p, None, GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
+    assert_close(y, y64, 2e-5 if which == "winograd4" else 1e-5, "depth, %s kernels" % which)
+    assert_grads_on_pattern(params, g64p, None, 1.6e-4 if which == "winograd4" else GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
 
 
 def test_network_backward_eval_mode():
