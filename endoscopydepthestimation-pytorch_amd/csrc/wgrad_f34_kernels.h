@@ -364,7 +364,7 @@ inline bool wgrad_f34_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
 }
 
 // waves per group and segment length: the longest segments (fewest restarts) among those that keep the waves evenly loaded
-inline F34Plan wgrad_f34_plan(const WgradParams& p) {
+inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34WavesPerXcd) {
     F34Plan plan{};
     plan.groups = (p.cin + 15) / 16;
     const int CY = p.h / 16, S = p.w / 16;
@@ -372,7 +372,7 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p) {
     for (int segq = 4; segq >= 1; segq >>= 1) {
         if (CY % segq) continue;
         const int per_xcd = (p.n * (CY / segq) * S + 7) / 8;
-        const int wpg = std::min(kF34WavesPerXcd / plan.groups, per_xcd);
+        const int wpg = std::min(waves_per_xcd / plan.groups, per_xcd);
         const int iters = (per_xcd + wpg - 1) / wpg;
         // time ~ iterations x (steps of a segment + its start-up)
         const float cost = iters * (4.f * segq + 1.5f);
@@ -382,12 +382,19 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p) {
     return plan;
 }
 
+// blocks: 512 = two per CU (the default), 256 = one per CU (in-job A/B: leaves half of every CU's registers to the other stream's kernels)
 template <int EXP = 0>
-inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream) {
-    const F34Plan plan = wgrad_f34_plan(p);
+inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream, int blocks = kF34Blocks) {
+    const F34Plan plan = wgrad_f34_plan(p, blocks / 2);
     constexpr int lds = 4 * 2 * kF34Xs * 4;          // 67,584 bytes per block, two blocks per CU
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    wgrad_f34_kernel<EXP><<<kF34Blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
+    static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!configured_by_device[dev & 15]) {
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured_by_device[dev & 15] = true;
+    }
+    wgrad_f34_kernel<EXP><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
     ENDO_LAUNCH_CHECK();
     wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();

@@ -47,7 +47,8 @@ def classify(name):
     base, a = split_name(name)
     if not CONV_LIKE.search(base):
         return None
-    if base in ("wgrad_nsplit_kernel", "wgrad_nsplit_reduce_kernel", "wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_wino_finish_kernel"):
+    if base in ("wgrad_nsplit_kernel", "wgrad_nsplit_reduce_kernel", "wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_wino_finish_kernel",
+                "wgrad_f34_kernel", "wgrad_f34_reduce_kernel", "wgrad_x3_kernel"):
         return "wgrad_dense"
     if base == "wgrad_taps_kernel":                       # <COUT, IN_MODE, BF>: IN_MODE 1 = BN + ReLU input (dense layer), 0 = raw (first conv), 2 = x2 gather (transition up)
         return "wgrad_dense" if a[1] == "1" else "other"
@@ -55,7 +56,7 @@ def classify(name):
         return "wgrad_dense" if a[0] == "3" and a[1] == "1" else "other"
     if base in ("dgrad_block_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_dense_kernel"):
         return "dgrad_dense"
-    if base == "wino_fwd_kernel" or base == "finalize_partial_kernel":
+    if base in ("wino_fwd_kernel", "wino4_fwd_kernel", "finalize_partial_kernel"):
         return "conv3x3_dense_fwd"
     if base in ("conv_dma_kernel", "conv_mfma_kernel"):   # <KS, KC, Q, IN_MODE, EPI, ...>
         if a[0] == "3" and a[2] == "1" and a[3] == "1" and a[4] == "0":
@@ -76,7 +77,7 @@ def classify(name):
         return "wgrad_dense" if a[0] == "3" else "other"
     if base == "bf16_wgrad_reduce_kernel":                # one per bf16_wgrad_kernel launch, 3x3 and 1x1 alike (5 of 55 are the 1x1's: ~1 % of the family's bytes)
         return "wgrad_dense"
-    if base in ("wgrad1x1_dma_kernel", "wgrad1x1_mfma_kernel", "tu_wgrad_subpix_kernel", "tu_wgrad_subpix_reduce_kernel", "wino_fwd_weights_kernel",
+    if base in ("wgrad1x1_dma_kernel", "wgrad1x1_mfma_kernel", "tu_wgrad_subpix_kernel", "tu_wgrad_subpix_reduce_kernel", "wino_fwd_weights_kernel", "wino4_fwd_weights_kernel",
                 "dgrad_wino_weights_kernel", "tu_subpix_dgrad_weights_kernel", "wgrad_wino_weights_kernel", "td_bwd_prep_kernel",
                 "td_dgrad_gemm_kernel", "td_wgrad_gemm_kernel", "td_wgrad_reduce_kernel"):
         return "other"
