@@ -386,7 +386,11 @@ def main():
     # neighbours: timing all 44 launches of a step cost the step 0.36 ms = 2.7 % (profiles/r03_y_events_cost.txt; in fp32 the dominant
     # family is on the side stream and the events cost nothing).  There one launch in 7 is timed -- 7 is coprime with the launch counts
     # of all three families, so 7 or more steps visit every launch of the step equally often and the sample mean is the launch mean.
-    period = 7 if bf16_storage and args.steps >= 7 else 1
+    # Since the fp32 weight gradients run in F(3x3, 4x4) form (round 4) the fp32 path's dominant family is the data gradient, on the caller's
+    # stream as well (409.0 frame-pairs/s with every launch timed, 411 with none): the same sampling applies whenever the dominant family is
+    # not the side stream's.
+    on_side_stream = dominant == 6 and not bf16_storage and overlap_mode != 0          # family 6 = wgrad_dense
+    period = 7 if not on_side_stream and args.steps >= 7 else 1
     lib.endo_prof_sample(period)
     lib.endo_prof_enable(mask)
     t0 = time.perf_counter()

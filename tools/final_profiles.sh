@@ -38,3 +38,17 @@ python bench.py --config 4 --no-cpu-baseline > $O/${TAG}_bench_config4.json 2> $
 python bench.py --config 3 --no-cpu-baseline > $O/${TAG}_bench_config3.json 2> $O/bench3.err
 tail -1 $O/${TAG}_bench.json | cut -c1-900
 ls -la $O
+# the F(3x3, 4x4) weight gradient stand-alone against the direct kernels (tools/x3_bench, built by hand: see its header) and its counters
+if [ -x $R/tools/bin/x3_bench ]; then
+  ( for a in "48 16 256 320" "60 16 256 320" "84 16 256 320" "128 16 256 320" "180 16 256 320" "144 16 128 160" "228 16 128 160" "156 16 64 80" "264 16 64 80"; do
+      $R/tools/bin/x3_bench $a 2>&1 | grep "dense-layer\|fp32 MFMA (v\|F(3x3" | cut -c1-240; done ) > $O/${TAG}_wgrad_f34_bench.txt
+  cd /tmp
+  i=0
+  for set in "FETCH_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES"; do
+    i=$((i+1))
+    rocprofv3 --pmc $set -d /tmp/f34p$i -o s -- $R/tools/bin/x3_bench 180 16 256 320 > /dev/null 2> $O/f34p$i.err
+  done
+  python3 $R/tools/pmc_sq_report.py $O/f34_all.txt /tmp/f34p*/s_results.db > $O/f34sq.log 2>&1
+  ( echo "# rocprofv3 --pmc <set> -- tools/bin/x3_bench 180 16 256 320 (five passes; values per dispatch): the F(3x3, 4x4) kernel, its diagnostic build without activation loads (<2>), the direct n-split kernel (<3, 0, 0>)"; grep -A3 "f34_kernel\|nsplit_kernel<3, 0, 0>" $O/f34_all.txt | cut -c1-1600 ) > $O/${TAG}_wgrad_f34_sq_counters.txt
+  cd $R
+fi
