@@ -1,14 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/f34g
-for i in 1 2; do
- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --kernel-option 7=2 > gpurun_out/f34g/bench_half_$i.json 2>> gpurun_out/f34g/bench.err
- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/f34g/bench_full_$i.json 2>> gpurun_out/f34g/bench.err
-done
-python - <<'PY'
-import json,glob
-for f in sorted(glob.glob("gpurun_out/f34g/bench_*.json")):
-    try:
-        d=json.loads([l for l in open(f) if l.startswith("{")][-1])
-        print(f, round(d["value"],1), round(d["ms_per_step"],3), {k: round(v,2) for k,v in d["roofline_serial"]["families_ms_per_step"].items()})
-    except Exception as e: print(f, "ERR", e)
-PY
+mkdir -p gpurun_out/r04_d2
+python bench.py > gpurun_out/r04_d2/r04_d_bench.json 2> gpurun_out/r04_d2/bench.err
+python bench.py --config 3 --no-cpu-baseline > gpurun_out/r04_d2/r04_d_bench_config3.json 2> gpurun_out/r04_d2/bench3.err
+python bench.py --kernel-option 0=5 --no-cpu-baseline > gpurun_out/r04_d2/r04_d_bench_option_wino4_fwd.json 2> gpurun_out/r04_d2/bench5.err
+tail -1 gpurun_out/r04_d2/r04_d_bench.json | cut -c1-400
