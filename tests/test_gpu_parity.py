@@ -1359,6 +1359,43 @@ def test_full_size_pair_backward_on_pattern():
     assert_grads_on_pattern(params, ref, None, 1e-4, "full-size pair backward")
 
 
+def test_wgrad_f34_against_the_direct_kernels_at_benchmark_size():
+    """The F(3x3, 4x4) Winograd weight gradient (csrc/wgrad_f34_kernels.h, ENDO_OPT_WGRAD_F34; levels 0-2 at this size) against the direct
+    kernels it replaces, on the SAME model, inputs and forward pass -- the grouped 2 x 8 x 256 x 320 launch bench.py times, so both forms see
+    identical activations, BatchNorm statistics of both sample groups and prepared gradients: every dense layer's weight gradient within
+    2e-5 of its maximum (measured 8e-6: the two forms' fp32 roundings, 3-6e-6 and 5e-7 against fp64 in tools/x3_bench), every other
+    gradient (BN parameters, the other layers' weights: same kernels, same inputs) within the atomics' summation order, 1e-5."""
+    n, h, w = 8, 256, 320
+    state, model = make_model(61)
+    rng = np.random.default_rng(23)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)).to(dev()) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)).to(dev()) for _ in range(2)]
+    model.train()
+    grads = {}
+    for form in (1, 0):
+        model.set_kernel_option(OPT_WGRAD_F34, form)
+        model.zero_grad(set_to_none=True)
+        y1, y2 = model.forward_pair(xs[0], xs[1])
+        ((y1 * cots[0]).sum() + (y2 * cots[1]).sum()).backward()
+        torch.cuda.synchronize()
+        grads[form] = {nm: p.grad.detach().clone() for nm, p in model.named_parameters()}
+    model.set_kernel_option(OPT_WGRAD_F34, 1)
+    worst_dense, worst_other = (0.0, ""), (0.0, "")
+    gmax = max(float(b.abs().max()) for b in grads[0].values())          # (conv biases in front of a BatchNorm have gradients that are rounding noise around 0)
+    for nm, a in grads[1].items():
+        b = grads[0][nm]
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-4 * gmax))
+        dense_w = ("denseBlocks" in nm or "bottleneck" in nm) and nm.endswith("conv.weight")
+        if dense_w:
+            worst_dense = max(worst_dense, (err, nm))
+        elif ".norm." in nm or not nm.endswith(".bias"):          # (a conv bias in front of a BatchNorm: its gradient is the rounding noise of sums that cancel)
+            worst_other = max(worst_other, (err, nm))
+    print("F(3x3, 4x4) vs direct weight gradients: worst dense-layer weight %.2e (%s), worst other tensor %.2e (%s)" % (worst_dense + worst_other))
+    assert worst_dense[0] <= 2e-5, worst_dense
+    assert worst_dense[0] > 0.0, "the option did not change the kernel"
+    assert worst_other[0] <= 1e-5, worst_other
+
+
 # ---------------------------------------------------------------------------------------------
 # full-size properties (BASELINE.json config 2: N = 8, 256 x 320)
 # ---------------------------------------------------------------------------------------------

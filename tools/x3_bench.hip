@@ -1,6 +1,7 @@
 // fp32 products on the bf16 matrix cores ("bf16x3", csrc/common.h split_bf16x8): speed and ACCURACY of the dense-layer weight gradient in its
 // three operand modes -- fp32 MFMA, operands rounded to bf16 (the mixed-precision mode), three-term split with six bf16 MFMAs -- against an
-// fp64 evaluation of the same sums on the host (a sample of the weight-gradient entries).  Development tool, not part of the product.
+// fp64 evaluation of the same sums on the host (a sample of the weight-gradient entries) -- and, since round 4, of the Winograd F(3x3, 4x4)
+// form (csrc/wgrad_f34_kernels.h) with its diagnostic build without activation loads.  Development tool, not part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/x3_bench.hip -o tools/bin/x3_bench
 //   tools/bin/x3_bench [cin] [n] [h] [w]
 #include <cstdio>
