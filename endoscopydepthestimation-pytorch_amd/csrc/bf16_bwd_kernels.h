@@ -196,6 +196,45 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __r
     }
 }
 
+// the same for the four BN layers of a dense block over the block's base channels [0, cnt): one launch instead of four, the layers' terms added
+// to P and Q in the order (and with the fp32 roundings) of four single-layer launches
+struct BnFin16x4 {
+    const double* sums[4];
+    const float* saved[4];
+    const float* gamma[4];
+    float* ggamma[4];
+    float* gbeta[4];
+    int rot[4], rot_n[4];
+};
+__global__ void __launch_bounds__(128) bf16_bn_finalize4_kernel(const BnFin16x4 a, float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum,
+                                                                int cnt, double count, int training, int64_t gs_sums, int64_t gs_saved, int64_t gs_pq,
+                                                                const float* __restrict__ gscale) {
+    const double inv = gscale ? gscale[1] : 1.0;
+    pq_p += blockIdx.y * gs_pq; pq_q += blockIdx.y * gs_pq;
+    for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < cnt; ci += gridDim.x * blockDim.x) {
+        float pp = pq_p[ci], qq = pq_q[ci];
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            const double* sums = a.sums[l] + blockIdx.y * gs_sums;
+            const float* saved = a.saved[l] + blockIdx.y * gs_saved;
+            const int pc = rot_index(ci, a.rot[l], a.rot_n[l]);
+            const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
+            const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
+            atomicAdd(a.ggamma[l] + pc, static_cast<float>(s2 * inv));
+            atomicAdd(a.gbeta[l] + pc, static_cast<float>(s1 * inv));
+            const double scale = a.gamma[l][pc] * rstd;
+            if (training) {
+                const double k = scale * rstd * s2 / count;
+                pp += static_cast<float>(-k);
+                qq += static_cast<float>(-scale * s1 / count + k * mean);
+            } else {
+                atomicAdd(gsum + 2 * ci, scale * s1);
+            }
+        }
+        if (training) { pq_p[ci] = pp; pq_q[ci] = qq; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // weight gradient
 // ---------------------------------------------------------------------------------------------

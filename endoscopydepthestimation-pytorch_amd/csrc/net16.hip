@@ -718,10 +718,16 @@ int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const C
         const int rc = launch_bf16_dgrad_block(p, c.stream);
         if (rc) return rc;
     }
+    static_assert(k16Layers == 4, "bf16_bn_finalize4_kernel");
+    BnFin16x4 fin{};
     for (int j = 0; j < k16Layers; ++j) {
-        const int rc = bn_finalize16(c, bn[j], cv[j], level, 0, c0);
-        if (rc) return rc;
+        fin.sums[j] = c.bnsums(bn[j]); fin.saved[j] = c.saved(bn[j]); fin.gamma[j] = c.params + bn[j].g;
+        fin.ggamma[j] = c.grads + bn[j].g; fin.gbeta[j] = c.grads + bn[j].b; fin.rot[j] = cv[j].rot; fin.rot_n[j] = cv[j].rot_n;
     }
+    bf16_bn_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(
+        fin, c.pq_p(level), c.pq_q(level), c.gsum(level), c0, static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved,
+        2 * lv.t, c.gscale());
+    ENDO_LAUNCH_CHECK();
     return 0;
 }
 
