@@ -787,7 +787,7 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dy = c.gbuf(level) + oc0 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = cv.cout;
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
-    if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_ok(p, 4l * c.net->opt[ENDO_OPT_WINO_MIN_TILES]))          // 4 x 4 tiles: levels 0-2 of configs[1]
+    if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_ok(p, c.net->opt[ENDO_OPT_WINO_MIN_TILES] / 4l))          // from 256 tiles of 4 x 4 pixels: levels 0-4 of configs[1] (level 5 is 8 x 10)
         return launch_wgrad_f34(p, c.gradws + c.net->wg_scratch_off, c.stream, c.net->opt[ENDO_OPT_WGRAD_F34] == 2 ? 256 : kF34Blocks);          // Winograd F(3x3, 4x4)
     if (wgrad_nsplit_ok(p)) {
         if (wgrad_mfma_mode(c) == 2) return launch_wgrad_x3(p, c.gradws + c.net->wg_scratch_off, c.stream);          // fp32 products as bf16 splits (wgrad_x3_kernels.h)

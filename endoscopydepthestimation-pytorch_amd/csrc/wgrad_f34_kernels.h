@@ -28,7 +28,7 @@
 //     2.5 times, L2 hit rate 2 %).
 //   * per-wave partial sums of the 9 taps (the output transform is linear, so it is applied to the wave's own sums) go to scratch;
 //     wgrad_f34_reduce_kernel adds them in a fixed order and accumulates into the flat gradient.
-// Needs w % 16 == 0 and h % 16 == 0 (levels 0-2 of the 256 x 320 and 512 x 640 configurations).
+// Needs w % 4 == 0 and h % 16 == 0 (levels 0-3 of the 256 x 320 configuration, 0-4 of 512 x 640).
 #pragma once
 
 #include <algorithm>
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     const int wq = wi / plan.groups;
 
     // work units: column segments (sample n, segment of `segq` quads of 16 rows, strip s), numbered with s fastest
-    const int S = p.w >> 4, CY = p.h >> 4, segq = plan.segq, YS = CY / segq;
+    const int S = (p.w + 15) >> 4, CY = p.h >> 4, segq = plan.segq, YS = CY / segq;          // the last strip may be partly outside (w % 4 == 0)
     const int units = p.n * YS * S;
     const int per_xcd = (units + 7) >> 3;
     const int u_first = xcd * per_xcd + wq;
@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     const float* const xs_r = xs + (li >> 1) * kF34XsPair + (li & 1) * 128 + 4 * lk;
     const unsigned x_grp = 4u * static_cast<unsigned>(16 * group * p.in_cs);
     // G side: the lane's (co, tile) offset; lanes co >= 12 point past the descriptor's range (zeros)
-    const unsigned g_vo = li < 12 ? 4u * static_cast<unsigned>(li * p.dy_cs + 4 * lk) : 0x80000000u;
+    const unsigned g_vo_in = li < 12 ? 4u * static_cast<unsigned>(li * p.dy_cs + 4 * lk) : 0x80000000u;
 
     float sc = 0.f, sh = 0.f;          // BN + ReLU as relu(sc * x + sh), constants of the current sample group
     int cst_grp = -1;
@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
             cst_grp = sm.grp;
         }
         // halo columns outside the image: masked through the constants (relu(0 * x + 0) = 0)
-        const bool l_out = s == 0 && lk == 0, r_out = s == S - 1 && lk == 3;
+        // a tile right of the image (last strip of a width that is no multiple of 16) takes part with a zero gradient tile
+        const unsigned g_vo = 16 * s + 4 * lk < p.w ? g_vo_in : 0x80000000u;
+        const bool l_out = s == 0 && lk == 0, r_out = 16 * s + 4 * lk + 4 >= p.w;
         const f32x2 sc_e = {l_out ? 0.f : sc, r_out ? 0.f : sc}, sh_e = {l_out ? 0.f : sh, r_out ? 0.f : sh};
         const int rd_shift = s > 0 ? 8 : 0;          // where the strip's first column sits in the staged window
         const int row_begin = 16 * yseg * segq, row_end = row_begin + 16 * segq;
@@ -349,15 +351,15 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
 }
 
 constexpr int kF34Blocks = 512;                      // two blocks of four waves per CU
-constexpr int kF34MinTiles = 4096;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
+constexpr int kF34MinTiles = 256;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
 // scratch: groups * 9 rows of `slots` x 256 floats, groups * slots <= 8 * 256 waves
 constexpr int64_t kF34ScratchFloats = static_cast<int64_t>(9) * 8 * kF34WavesPerXcd * 256;
 
 inline bool wgrad_f34_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
-    const bool aligned = (p.w % 16 == 0) && (p.h % 16 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
+    const bool aligned = (p.w % 4 == 0) && (p.h % 16 == 0) && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.dy_ns % 4 == 0) && (p.in_w % 4 == 0) &&
                          (p.in_cs % 4 == 0) && (p.in_ns % 4 == 0) && (reinterpret_cast<uintptr_t>(p.dy) % 16 == 0) &&
                          (reinterpret_cast<uintptr_t>(p.in) % 16 == 0);
-    const long quads = static_cast<long>(p.w / 16) * (p.h / 16) * p.n;
+    const long quads = static_cast<long>((p.w + 15) / 16) * (p.h / 16) * p.n;
     // (the buffer descriptors address one sample with 32-bit byte offsets)
     const bool small = static_cast<int64_t>(p.in_cs) * (p.cin + 16) * 4 < (1ll << 31) && static_cast<int64_t>(p.dy_cs) * 12 * 4 < (1ll << 31);
     return aligned && small && p.cout == 12 && p.cin >= 16 && (p.cin + 15) / 16 <= kF34WavesPerXcd && quads * 16 >= min_tiles;
@@ -367,7 +369,7 @@ inline bool wgrad_f34_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
 inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34WavesPerXcd) {
     F34Plan plan{};
     plan.groups = (p.cin + 15) / 16;
-    const int CY = p.h / 16, S = p.w / 16;
+    const int CY = p.h / 16, S = (p.w + 15) / 16;
     float best = 1e30f;
     for (int segq = 4; segq >= 1; segq >>= 1) {
         if (CY % segq) continue;

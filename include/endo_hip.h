@@ -227,7 +227,7 @@ int endo_net_groups(const endo_net* net);
  *   ENDO_OPT_WGRAD_OVERLAP   endo_net_bwd runs the weight gradients on a side stream of its own, overlapped with the data-gradient
  *                            chain and joined before it returns: 1 (default); 0 puts them back in line on the
  *                            caller's stream (clean per-kernel timings)
- *   ENDO_OPT_WGRAD_F34       dense-layer weight gradient at the fine levels (width and height multiples of 16): 1 (default) = in the
+ *   ENDO_OPT_WGRAD_F34       dense-layer weight gradient where the height is a multiple of 16 and the width of 4 (levels 0-4 at 256 x 320): 1 (default) = in the
  *                            Winograd domain, F(3x3, 4x4) -- 36 multiplications per 4 x 4 tile of the output gradient instead of 144,
  *                            fp32 throughout (csrc/wgrad_f34_kernels.h); 0 = the direct kernels.  Ignored where ENDO_OPT_MFMA_BF16 or
  *                            ENDO_OPT_MFMA_X3 select another operand form for the weight gradients. */

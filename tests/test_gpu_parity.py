@@ -444,8 +444,8 @@ def test_kernel_options_are_per_model():
                                          ("x3", (2, 128, 160))],          # x3: needs >= 2048 row chunks at level 0 to reach the n-split / x3 weight-gradient kernels
                          ids=lambda v: "x".join(str(i) for i in v) if isinstance(v, tuple) else v)
 def test_network_backward_kernel_forms(shape, which):
-    """The Winograd kernels (dense-layer forward, fused base-channel data gradient, F(3x3, 4x4) weight gradient where width and height are
-    multiples of 16) are chosen by launch size and the parity
+    """The Winograd kernels (dense-layer forward, fused base-channel data gradient, F(3x3, 4x4) weight gradient where the height is a multiple of 16
+    and the width of 4) are chosen by launch size and the parity
     tests above are too small to reach them: here they are forced on (ENDO_OPT_WINO_MIN_TILES = 1) or off for every eligible
     level and all 210 gradients are checked on the pass's own activation pattern as in test_network_backward -- so both forms
     of every such layer are held to the same 3e-5, at sizes the fp64 oracle finishes in seconds."""
@@ -1360,7 +1360,7 @@ def test_full_size_pair_backward_on_pattern():
 
 
 def test_wgrad_f34_against_the_direct_kernels_at_benchmark_size():
-    """The F(3x3, 4x4) Winograd weight gradient (csrc/wgrad_f34_kernels.h, ENDO_OPT_WGRAD_F34; levels 0-2 at this size) against the direct
+    """The F(3x3, 4x4) Winograd weight gradient (csrc/wgrad_f34_kernels.h, ENDO_OPT_WGRAD_F34; levels 0-4 at this size, the last strip of levels 3 and 4 partly outside the image) against the direct
     kernels it replaces, on the SAME model, inputs and forward pass -- the grouped 2 x 8 x 256 x 320 launch bench.py times, so both forms see
     identical activations, BatchNorm statistics of both sample groups and prepared gradients: every dense layer's weight gradient within
     2e-5 of its maximum (measured 8e-6: the two forms' fp32 roundings, 3-6e-6 and 5e-7 against fp64 in tools/x3_bench), every other
