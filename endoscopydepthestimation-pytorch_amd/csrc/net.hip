@@ -1300,6 +1300,11 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         if (rc) return rc;
         {
             ProfScope prof(kProfWgradOther, cw.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * lv.plane * (3 + kFirst));
+            // 3 -> 48 channels: in the F(3x3, 4x4) form the four sets of 12 output channels share one launch (the tap-folded kernel runs a
+            // 108-row GEMM with 3 of 16 columns in use, four times: 216 us alone on the chip at the very end of the backward)
+            if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_raw_ok(p, c.net->opt[ENDO_OPT_WINO_MIN_TILES] / 4l))
+                rc = launch_wgrad_f34<0, true>(p, c.gradws + c.net->wg_scratch_off, cw.stream);
+            else
             rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, cw.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, cw.stream);
             if (rc) return rc;
         }

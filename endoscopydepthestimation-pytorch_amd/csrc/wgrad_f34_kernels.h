@@ -100,7 +100,10 @@ __device__ __forceinline__ float f34_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff
 }
 
 // EXP (tools/x3_bench only): 2 = no x loads
-template <int EXP = 0>
+// RAW: the convolution reads its input as it is (the network's first convolution: the image, 3 channels, no BatchNorm, no ReLU) and has
+// 12 * plan.groups output channels: a wave's "group" is then a SET OF 12 OUTPUT CHANNELS (its 12 gradient planes), every wave transforms the
+// same (<= 16) input channels
+template <int EXP = 0, bool RAW = false>
 __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradParams p, float* __restrict__ partial, const F34Plan plan) {
     extern __shared__ __attribute__((aligned(16))) float smem[];          // [wave][2 images]: the rows of the next two steps
     const int tid = threadIdx.x;
@@ -128,13 +131,13 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     for (int m = 0; m < 36; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // x side
-    const int ch = 16 * group + li;
+    const int ch = RAW ? li : 16 * group + li;
     const bool ch_ok = ch < p.cin;
     const unsigned bo = 4u * static_cast<unsigned>(min(ch, p.cin - 1) * p.in_cs + 4 * lk);          // (lane-by-lane loads of a segment's first rows)
     float* const xs = smem + wave * 2 * kF34Xs;
     const unsigned x_vo = 4u * static_cast<unsigned>((lane >> 5) * p.in_cs + ((lane >> 3) & 3) * p.in_w + 4 * (lane & 7));
     const float* const xs_r = xs + (li >> 1) * kF34XsPair + (li & 1) * 128 + 4 * lk;
-    const unsigned x_grp = 4u * static_cast<unsigned>(16 * group * p.in_cs);
+    const unsigned x_grp = RAW ? 0u : 4u * static_cast<unsigned>(16 * group * p.in_cs);
     // G side: the lane's (co, tile) offset; lanes co >= 12 point past the descriptor's range (zeros)
     const unsigned g_vo_in = li < 12 ? 4u * static_cast<unsigned>(li * p.dy_cs + 4 * lk) : 0x80000000u;
 
@@ -147,9 +150,15 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         const f32x2 e = __builtin_elementwise_fma(f32x2{hl, hr}, sc_e, sh_e);
         const f32x2 a = __builtin_elementwise_fma(f32x2{m[0], m[1]}, f32x2{sc, sc}, f32x2{sh, sh});
         const f32x2 b = __builtin_elementwise_fma(f32x2{m[2], m[3]}, f32x2{sc, sc}, f32x2{sh, sh});
-        o[0] = fmaxf(e[0], 0.f); o[1] = fmaxf(e[1], 0.f);
-        o[2] = fmaxf(a[0], 0.f); o[3] = fmaxf(a[1], 0.f);
-        o[4] = fmaxf(b[0], 0.f); o[5] = fmaxf(b[1], 0.f);
+        if constexpr (RAW) {          // sc = 1 (0 for a masked column or channel), sh = 0; no max() here to turn "0 * garbage" into 0: the halo
+            // column outside the image is read from LDS that was never written and is selected away
+            o[0] = sc_e[0] != 0.f ? e[0] : 0.f; o[1] = sc_e[1] != 0.f ? e[1] : 0.f;
+            o[2] = a[0]; o[3] = a[1]; o[4] = b[0]; o[5] = b[1];
+        } else {
+            o[0] = fmaxf(e[0], 0.f); o[1] = fmaxf(e[1], 0.f);
+            o[2] = fmaxf(a[0], 0.f); o[3] = fmaxf(a[1], 0.f);
+            o[4] = fmaxf(b[0], 0.f); o[5] = fmaxf(b[1], 0.f);
+        }
     };
     // the four new rows of a step (image rows `row` .. `row` + 3) into the LDS image: 8 DMA instructions, no registers.  The window
     // starts 8 columns left of the strip (at column 0 for the first strip); rows below the image and columns past the row end are whatever
@@ -176,11 +185,13 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         // descriptors over this sample's cin activation planes / 12 gradient planes: anything past them (the padding channels of the last
         // group, the rows below the last plane) reads zeros
         const __amdgpu_buffer_rsrc_t xr = f34_rsrc(p.in + sm.in_off(p), p.cin * p.in_cs * 4);
-        const __amdgpu_buffer_rsrc_t gr = f34_rsrc(p.dy + sm.dy_off(p), 12 * p.dy_cs * 4);
+        const __amdgpu_buffer_rsrc_t gr = f34_rsrc(p.dy + sm.dy_off(p) + (RAW ? static_cast<int64_t>(12 * group) * p.dy_cs : 0), 12 * p.dy_cs * 4);
         if (sm.grp != cst_grp) {
-            const float* saved = p.saved + sm.grp * p.gs;
             sc = 0.f; sh = 0.f;
-            if (ch_ok) {
+            if constexpr (RAW) {
+                if (ch_ok) sc = 1.f;
+            } else if (ch_ok) {
+                const float* saved = p.saved + sm.grp * p.gs;
                 sc = p.gamma[ch] * saved[2 * ch + 1];
                 sh = fmaf(-saved[2 * ch], sc, p.beta[ch]);
             }
@@ -323,7 +334,8 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 }
 
 // grid (groups * 9, slices): adds the partial rows of (group, tap) over the group's waves in a fixed order per slice
-__global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __restrict__ partial, int slots, int cin, float* __restrict__ dw) {
+// raw: the groups are sets of 12 output channels over the same <= 16 input channels (wgrad_f34_kernel<.., RAW>)
+__global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __restrict__ partial, int slots, int cin, float* __restrict__ dw, int raw) {
     __shared__ f32x4 s_part[4][64];
     const int gm = blockIdx.x;
     const int group = gm / 9, tap = gm - group * 9;
@@ -346,8 +358,8 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
     const float total = (sp[e] + sp[256 + e]) + (sp[512 + e] + sp[768 + e]);
     const int lane = e & 63, r = e >> 6;
     const int co = 4 * (lane >> 4) + r;
-    const int ci = 16 * group + (lane & 15);
-    if (co < 12 && ci < cin) atomicAdd(dw + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, total);
+    const int ci = (raw ? 0 : 16 * group) + (lane & 15);
+    if (co < 12 && ci < cin) atomicAdd(dw + (static_cast<int64_t>(co + (raw ? 12 * group : 0)) * cin + ci) * 9 + tap, total);
 }
 
 constexpr int kF34Blocks = 512;                      // two blocks of four waves per CU
@@ -364,11 +376,17 @@ inline bool wgrad_f34_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
     const bool small = static_cast<int64_t>(p.in_cs) * (p.cin + 16) * 4 < (1ll << 31) && static_cast<int64_t>(p.dy_cs) * 12 * 4 < (1ll << 31);
     return aligned && small && p.cout == 12 && p.cin >= 16 && (p.cin + 15) / 16 <= kF34WavesPerXcd && quads * 16 >= min_tiles;
 }
+// the first convolution: a raw input of at most 16 channels, output channels in sets of 12
+inline bool wgrad_f34_raw_ok(const WgradParams& p, long min_tiles = kF34MinTiles) {
+    WgradParams q = p;
+    q.cout = 12; q.cin = 16;
+    return p.cin <= 16 && p.cout % 12 == 0 && p.cout / 12 <= 16 && static_cast<int64_t>(p.in_cs) * 32 * 4 < (1ll << 31) && wgrad_f34_ok(q, min_tiles);
+}
 
 // waves per group and segment length: the longest segments (fewest restarts) among those that keep the waves evenly loaded
-inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34WavesPerXcd) {
+inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34WavesPerXcd, bool raw = false) {
     F34Plan plan{};
-    plan.groups = (p.cin + 15) / 16;
+    plan.groups = raw ? p.cout / 12 : (p.cin + 15) / 16;
     const int CY = p.h / 16, S = (p.w + 15) / 16;
     float best = 1e30f;
     for (int segq = 4; segq >= 1; segq >>= 1) {
@@ -385,20 +403,20 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34Wave
 }
 
 // blocks: 512 = two per CU (the default), 256 = one per CU (in-job A/B: leaves half of every CU's registers to the other stream's kernels)
-template <int EXP = 0>
+template <int EXP = 0, bool RAW = false>
 inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream, int blocks = kF34Blocks) {
-    const F34Plan plan = wgrad_f34_plan(p, blocks / 2);
+    const F34Plan plan = wgrad_f34_plan(p, blocks / 2, RAW);
     constexpr int lds = 4 * 2 * kF34Xs * 4;          // 67,584 bytes per block, two blocks per CU
     static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!configured_by_device[dev & 15]) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_by_device[dev & 15] = true;
     }
-    wgrad_f34_kernel<EXP><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
+    wgrad_f34_kernel<EXP, RAW><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
     ENDO_LAUNCH_CHECK();
-    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw);
+    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw, RAW ? 1 : 0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
