@@ -283,7 +283,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS), help="index into BASELINE.json configs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-family time table to stderr")
@@ -342,20 +342,27 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up: all three dense-layer conv families carry HIP events (around every launch, on the launch stream), with the
-    # weight-gradient side stream switched OFF so that kernels run one at a time: that gives each family's stand-alone
-    # duration ("roofline_serial") and names the dominant family.  The last warm-up step and the timed steps run the
-    # product configuration -- weight gradients overlapped with the data-gradient chain -- with events only on the
-    # dominant family (two events per launch serialise neighbouring kernels; the launches of the other two families need
-    # not pay for it).  Under overlap a kernel shares the chip with its neighbour, so its duration in the timed region is
-    # longer than stand-alone: `roofline` reports what the timed region measured, `roofline_serial` the stand-alone figure.
+    # Warm-up (W = --warmup untimed steps in all): the LAST min(W, 3) of them run the product configuration -- weight gradients on the side
+    # stream, overlapped with the data-gradient chain, events on nothing but a launch counter -- so that the timed region starts from the
+    # steady state it measures (clocks, caches, the allocator's and the side stream's state).  The up to two steps before those carry HIP events
+    # around every launch of the three dense-layer conv families (on the launch stream) with the side stream switched OFF, so that kernels run
+    # one at a time: each family's stand-alone duration ("roofline_serial"), which also names the dominant family.  In the timed steps only
+    # the dominant family carries events (two events per launch serialise neighbouring kernels).  Under overlap a kernel shares the chip with
+    # its neighbour, so its duration in the timed region is longer than stand-alone: `roofline` reports what the timed region measured,
+    # `roofline_serial` the stand-alone figure.
     all_mask = 0
     for f in MFMA_FAMILIES:
         all_mask |= 1 << f
     it = 0
-    serial_steps = max(args.warmup - 1, 0)
+    product_steps = min(args.warmup, 3)
+    serial_steps = min(args.warmup - product_steps, 2)
+    for _ in range(args.warmup - product_steps - serial_steps):          # --warmup > 5: the rest, uninstrumented, first
+        scheduler.batch_step(batch_iteration=it)
+        step_fn(batch)
+        it += 1
     model.set_kernel_option(5, 0)                                      # ENDO_OPT_WGRAD_OVERLAP off: kernels one at a time
     model.set_wgrad_overlap16(False)                                   # the same for the 16-bit-storage family's handles
+    lib.endo_prof_sample(1)
     lib.endo_prof_enable(all_mask if serial_steps > 0 else 0)
     for _ in range(serial_steps):
         scheduler.batch_step(batch_iteration=it)
@@ -370,11 +377,20 @@ def main():
             overlap_mode = int(spec.split("=")[1])
     model.set_kernel_option(5, overlap_mode)
     model.set_wgrad_overlap16(int(os.environ.get("ENDO16_WGRAD_OVERLAP", "1")))          # development A/B: 2 = one fork per dense block
-    for _ in range(args.warmup - serial_steps):
+    NEVER = 1 << 30                                                    # a sampling period nothing reaches: launches are counted, not timed
+    lib.endo_prof_sample(NEVER)
+    lib.endo_prof_enable(all_mask)                                     # (the first launch of each family gets one event pair; nothing else)
+    for _ in range(product_steps):
         scheduler.batch_step(batch_iteration=it)
         step_fn(batch)
         it += 1
     barrier()
+    launches_per_step = {}
+    for f in MFMA_FAMILIES:
+        n_seen = ctypes.c_int64(0)
+        lib.endo_prof_seen(f, ctypes.byref(n_seen))
+        launches_per_step[f] = n_seen.value // product_steps if product_steps else 0
+    lib.endo_prof_enable(0)
     if fam_warm is not None:
         dominant = max(MFMA_FAMILIES, key=lambda f: fam_warm[f][0])
         mask = 1 << dominant
@@ -382,16 +398,20 @@ def main():
         dominant, mask = None, all_mask
     if os.environ.get("ENDO_BENCH_NO_EVENTS"):                         # development: what the per-launch events cost the timed region
         mask = 0
-    # The 16-bit modes' dominant family runs on the caller's stream, where the two events around a launch serialise it with its
-    # neighbours: timing all 44 launches of a step cost the step 0.36 ms = 2.7 % (profiles/r03_y_events_cost.txt; in fp32 the dominant
-    # family is on the side stream and the events cost nothing).  There one launch in 7 is timed -- 7 is coprime with the launch counts
-    # of all three families, so 7 or more steps visit every launch of the step equally often and the sample mean is the launch mean.
-    # Since the fp32 weight gradients run in F(3x3, 4x4) form (round 4) the fp32 path's dominant family is the data gradient, on the caller's
-    # stream as well (409.0 frame-pairs/s with every launch timed, 411 with none): the same sampling applies whenever the dominant family is
-    # not the side stream's.
+    # A dominant family on the caller's stream (the data gradient in fp32 since round 4, in the 16-bit modes always) is SAMPLED: the two
+    # events around a launch serialise it with its neighbours -- timing all 44 launches of a step cost the 16-bit step 0.36 ms = 2.7 %
+    # (profiles/r03_y_events_cost.txt), the fp32 step 0.5 % (409.0 against 411 frame-pairs/s).  One launch in `period` is timed, with
+    # gcd(period, launches per step) = 1 (the launch count is the one just counted, not assumed), so `period` consecutive steps time every
+    # launch of the step exactly once; only whole multiples of `period` steps are sampled (the remaining steps of the timed region run
+    # untimed), so every launch enters the average equally often and launches_per_step x avg_launch_ms IS the family's time per step.
+    # On the side stream (the fp32 weight gradients when they dominate) events cost nothing and every launch is timed.
+    import math
     on_side_stream = dominant == 6 and not bf16_storage and overlap_mode != 0          # family 6 = wgrad_dense
-    # (7, 5 and 3 are all coprime with 44; a run of fewer steps takes the largest of them it can visit every launch with)
-    period = 1 if on_side_stream else next((q for q in (7, 5, 3) if args.steps >= q), 1)
+    lps = launches_per_step.get(dominant, 0) if dominant is not None else 0
+    period = 1
+    if not on_side_stream and dominant is not None and lps > 1:
+        period = next((q for q in (7, 5, 3, 11, 9, 13, 4, 2) if args.steps >= q and math.gcd(q, lps) == 1), 1)
+    sampled_steps = (args.steps // period) * period
     lib.endo_prof_sample(period)
     lib.endo_prof_enable(mask)
     t0 = time.perf_counter()
@@ -400,7 +420,9 @@ def main():
     # late: the guard itself is decided on the device (StepOutput, train_step.py), so the read of step k - 1 happens while step k is
     # queued and the GPU does not idle at the loss
     pending = None
-    for _ in range(args.steps):
+    for k in range(args.steps):
+        if k == sampled_steps and period > 1:
+            lib.endo_prof_sample(NEVER)          # the even cover is complete: the rest of the timed region is counted, not timed
         scheduler.batch_step(batch_iteration=it)
         out = step_fn(batch)
         if pending is not None:
@@ -538,13 +560,19 @@ def main():
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch (PMC 2*FETCH_SIZE+WRITE_SIZE)",
                      "traffic_source": traffic_src, "algorithmic_bytes_per_launch": by / cnt if cnt else None,
-                     "launches": seen[dominant], "timed_launches": cnt,
-                     "sampling": None if period == 1 else "1 launch in %d, in rotation over the step's launches" % period,
+                     "launches": seen[dominant], "timed_launches": cnt, "launches_per_step": lps or None,
+                     "sampling": None if period == 1 else "1 launch in %d over the first %d steps: every launch of the step timed %d times" % (
+                         period, sampled_steps, sampled_steps // period),
                      "avg_launch_ms": ms / cnt if cnt else None,
+                     "family_ms_per_step": (ms / cnt) * lps if cnt and lps else None,
+                     # the algorithmic work the timed launches add up to per step, beside SURVEY.md Appendix B's figure for one dense-layer
+                     # family (12 244.8 MMAC x 2 x 16 frames at 256 x 320, batch 8; scaled to this config's pixels and batch)
+                     "family_gflop_per_step": {"implied_by_timed_launches": (fl / cnt) * lps / 1e9 if cnt and lps else None,
+                                               "survey": 391.8336 * (height * width) / (256.0 * 320.0) * batch_size / 8.0},
                      "algorithmic_gbs": by / ms / 1e6 if ms > 0 else None,
                      "concurrent": True},
         "roofline_serial": None if fam_warm is None else {
-            "note": "stand-alone kernel durations: warm-up steps with the weight-gradient side stream off (ENDO_OPT_WGRAD_OVERLAP = 0)",
+            "note": "stand-alone kernel durations: %d warm-up steps with the weight-gradient side stream off (ENDO_OPT_WGRAD_OVERLAP = 0), followed by %d warm-up steps in the product configuration" % (serial_steps, product_steps),
             "kernel": dom_name, "achieved": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9,
             "frac": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9 / FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "families_ms_per_step": {lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / serial_steps for f in MFMA_FAMILIES},

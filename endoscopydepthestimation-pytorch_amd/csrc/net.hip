@@ -557,8 +557,8 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 }
 
 // Tuning options, per network handle (endo_net_set_option; defaults set by endo_net_create*, no environment variables):
-//   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd (2 LDS stages), 3 / 4 = Winograd
-//                            with 3 / 4 stages
+//   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd F(2x2, 3x3) (2 LDS stages), 3 / 4 = the same
+//                            with 3 / 4 stages, 5 (default) = F(4x4, 3x3) for the launches that fill the chip with 64 x 16 blocks, F(2x2, 3x3) for the rest
 //   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
 //                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h)
 //   ENDO_OPT_DGRAD_VEC       new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
@@ -569,7 +569,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
 //   ENDO_OPT_WGRAD_F34       1 = dense weight gradients of the fine levels in the Winograd domain F(3x3, 4x4) (wgrad_f34_kernels.h)
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
-    opt[ENDO_OPT_WINO_FWD] = 1;
+    opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
     opt[ENDO_OPT_WINO_DGRAD] = 1;
     opt[ENDO_OPT_DGRAD_VEC] = 1;
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;

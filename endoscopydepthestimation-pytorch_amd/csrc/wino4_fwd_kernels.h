@@ -15,7 +15,7 @@
 //
 // Rounding: the transforms carry factors up to 8 (A^T) / 5 (B^T) / 1/24 (G); against fp64 the network's output is within 6e-6 of its maximum
 // with every dense layer in this form (4e-6 .. 6e-6 at 64x96 .. 256x320; direct and F(2x2, 3x3): 8e-7 .. 1e-6) -- inside the 1e-4 the
-// parity target states, and the reason ENDO_OPT_WINO_FWD keeps F(2x2, 3x3) selectable.
+// parity target states (the default form of level 0 since round 5; ENDO_OPT_WINO_FWD = 1 keeps F(2x2, 3x3) selectable).
 #pragma once
 
 #include "conv_dma_kernels.h"

@@ -469,8 +469,13 @@ def get_clean_point_list(imgs, point_cloud, view_indexes_per_point, mask_boundar
     """float32 (points,) 1 = keep, 0 = contaminated: in at least half of the frames it appears in, the point's depth^2 x brightness
     lies outside the window holding `inlier_percentage` of that frame's points  [utils.py:339-404].  imgs as reader.get_color_imgs in
     cv2 order (B, G, R).  The reference's is_hsv branch first takes its HSV frames BACK to BGR (cv2.COLOR_HSV2BGR_FULL, utils.py:362-363)
-    and then runs the same filter: callers here hand over the BGR frames themselves (reader.load_sequence always does), so the flag
-    changes nothing -- up to the 8-bit loss of the reference's round trip."""
+    and then runs the same filter.  That inverse conversion is not built here, and the kernel below reads its input as B, G, R: frames
+    from get_color_imgs(..., is_hsv=True) would be filtered as if H, S, V were colours.  So is_hsv=True raises; hand over the BGR
+    frames (get_color_imgs(..., is_hsv=False), as reader.load_sequence does) -- the filter then sees what the reference's sees, up to
+    the 8-bit loss of its round trip."""
+    if is_hsv:
+        raise NotImplementedError("get_clean_point_list filters BGR frames: decode them with get_color_imgs(..., is_hsv=False); "
+                                  "the reference's HSV -> BGR round trip (utils.py:362-363) is not implemented")
     n_points = len(point_cloud)
     if inlier_percentage <= 0.0 or inlier_percentage >= 1.0:
         return list()

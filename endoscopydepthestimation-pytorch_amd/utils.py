@@ -68,6 +68,20 @@ def save_model(model, optimizer, epoch, step, model_path, validation_loss, modul
                 'validation': validation_loss}, str(model_path))
 
 
+def load_checkpoint(model_path, model=None, optimizer=None, map_location=None):
+    """Read a checkpoint file in the reference's wire format (utils.py:674-682) and, when given, restore ``model`` (keys with or
+    without 'module.', train.py:222 / evaluate.py:150) and ``optimizer`` (torch.optim.SGD's layout: FusedClipSGD or SGD).  Returns
+    the dictionary {model, optimizer, epoch, step, validation}.  The file is a pickle and is read as one (the param group's lr is a
+    numpy scalar once scheduler.CyclicLR has stepped, which torch's weights-only loader refuses): load files you trust, exactly as
+    the reference's own ``torch.load(path)`` (train.py:218) assumes."""
+    state = torch.load(str(model_path), map_location=map_location, weights_only=False)
+    if model is not None:
+        load_model_state(model, state["model"])
+    if optimizer is not None:
+        optimizer.load_state_dict(state["optimizer"])
+    return state
+
+
 def load_model_state(model, state):
     """Load a reference checkpoint's ``state['model']`` with or without the 'module.' prefix."""
     cleaned = {(k[7:] if k.startswith("module.") else k): v for k, v in state.items()}

@@ -208,9 +208,10 @@ int endo_net_groups(const endo_net* net);
  * that handle (a forward and the backward that differentiates it must run under the same ENDO_OPT_MFMA_BF16 value).
  * Every setting but ENDO_OPT_MFMA_BF16 computes the same function up to fp32 summation order; tests use
  * ENDO_OPT_WINO_MIN_TILES = 1 to reach the Winograd kernels at small sizes.
- *   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 direct convolution, 1 Winograd F(2x2,3x3) (default), 3 / 4 = with 3 / 4 LDS stages,
- *                            5 = F(4x4,3x3) at the finest level (csrc/wino4_fwd_kernels.h: +3 % frame-pairs/s, five times the forward rounding --
- *                            6e-6 of the depth's maximum instead of 1e-6; not the default)
+ *   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 direct convolution, 1 Winograd F(2x2,3x3), 3 / 4 = with 3 / 4 LDS stages,
+ *                            5 (default since round 5) = F(4x4,3x3) for the launches whose 64 x 16 blocks fill the chip (level 0 at 256 x 320; csrc/wino4_fwd_kernels.h)
+ *                            and F(2x2,3x3) below: +3 % frame-pairs/s; the depth is 5e-6 of its maximum from fp64 instead of 1e-6, against the
+ *                            1e-4 of the parity target
  *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd with phase-skewed workers (default),
  *                            2 Winograd, the round-2 kernel
  *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 1 = 16-byte DMA of the gradient tiles (default), 0 = dword

@@ -28,3 +28,18 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
     return load
+
+
+def checkpoint_from_fixture(g):
+    """The reference-written checkpoint of tests/golden/checkpoint_2x64x96.npz (make_golden.py checkpoint_case: the reference's
+    DataParallel-wrapped model + torch.optim.SGD after two iterations, saved by ITS utils.save_model) back in the shape torch.load
+    returns: {model: {'module.<key>': tensor}, optimizer: {state: {i: {momentum_buffer}}, param_groups: [..]}, epoch, step, validation}."""
+    import numpy as np
+    import torch
+    model = {str(k): torch.from_numpy(np.array(g["model::" + str(k)])) for k in g["model_keys"]}
+    index = [int(i) for i in g["opt_params"]]
+    state = {i: {"momentum_buffer": torch.from_numpy(np.array(g["opt_state::%d" % i]))} for i in index}
+    group = {"lr": float(g["opt_lr"]), "momentum": float(g["opt_momentum"]), "dampening": float(g["opt_dampening"]),
+             "weight_decay": float(g["opt_weight_decay"]), "nesterov": bool(g["opt_nesterov"]), "params": index}
+    return {"model": model, "optimizer": {"state": state, "param_groups": [group]}, "epoch": int(g["epoch"]), "step": int(g["step"]),
+            "validation": float(g["validation"])}

@@ -231,6 +231,118 @@ def train_step_case(ref, n, h, w, seed, path):
     print("wrote", path, "losses", float(out["step0_loss"]), float(out["step1_loss"]))
 
 
+def _reference_iteration(ref, net, opt, sched, batch, step, h, w):
+    """One iteration of the reference's batch-loop body (train.py:272-328) on `net` (possibly DataParallel-wrapped)."""
+    scaling = ref["models"].DepthScalingLayer(epsilon=1.0e-8)
+    flow_layer = ref["models"].FlowfromDepthLayer()
+    warp_layer = ref["models"].DepthWarpingLayer(epsilon=1.0e-8)
+    sfl_fn = ref["losses"].SparseMaskedL1Loss()
+    dcl_fn = ref["losses"].NormalizedDistanceLoss(height=h, width=w)
+    sched.batch_step(batch_iteration=step)
+    b = batch["boundaries"]
+    p1 = net(b * batch["colors_1"])
+    p2 = net(b * batch["colors_2"])
+    s1, _ = scaling([p1, batch["sparse_depths_1"], batch["sparse_depth_masks_1"]])
+    s2, _ = scaling([p2, batch["sparse_depths_2"], batch["sparse_depth_masks_2"]])
+    f1 = flow_layer([s1, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]]) * b
+    f2 = flow_layer([s2, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]]) * b
+    sfl = 20.0 * 0.5 * (sfl_fn([batch["sparse_flows_1"] * b, f1, batch["sparse_flow_masks_1"] * b]) +
+                        sfl_fn([batch["sparse_flows_2"] * b, f2, batch["sparse_flow_masks_2"] * b]))
+    w21, i1 = warp_layer([s1, s2, b, batch["translations_1_wrt_2"], batch["rotations_1_wrt_2"], batch["intrinsics"]])
+    w12, i2 = warp_layer([s2, s1, b, batch["translations_2_wrt_1"], batch["rotations_2_wrt_1"], batch["intrinsics"]])
+    dcl = 0.1 * 0.5 * (dcl_fn([s1, w21, i1, batch["intrinsics"]]) + dcl_fn([s2, w12, i2, batch["intrinsics"]]))
+    loss = dcl + sfl
+    opt.zero_grad()
+    loss.backward()
+    gnorm = torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+    opt.step()
+    return loss, gnorm
+
+
+def checkpoint_case(ref, n, h, w, seed, path):
+    """SURVEY 8(f2), the checkpoint wire format (utils.py:674-682, train.py:197, 214-227; evaluate.py:144-155).
+    The reference's FCDenseNet57 under nn.DataParallel (as train.py:197 wraps it: state-dict keys carry 'module.') runs two
+    iterations with torch.optim.SGD(momentum 0.9), then the reference's OWN utils.save_model writes the checkpoint file.  The
+    fixture holds the TENSORS of that file ('model::<key>', 'opt_state::<i>', the param group's scalars, epoch / step /
+    validation) and what the reference itself does next: it reloads the file into fresh objects (model.load_state_dict as
+    train.py:222; optimizer.load_state_dict for the momentum, which train.py does not restore but the format carries) and runs
+    iteration 3 -- loss, gradient norm, per-tensor parameter norms and sums after it.
+    Container-side assertions (need the reference, so they live here and not in tests/): a file written by THIS repository's
+    utils.save_model + FusedClipSGD.state_dict() loads into the reference's DataParallel model and into torch.optim.SGD, bit for bit."""
+    import tempfile
+    ea = importlib.import_module("endoscopydepthestimation-pytorch_amd")
+    state = onet.keep_depth_positive(onet.perturb_affine(onet.synthetic_state(seed), seed + 1))
+    net = torch.nn.DataParallel(load_reference_net(ref, state))          # no GPU here: forward() runs the module directly
+    net.train()
+    base_lr, max_lr, step_size = 1.0e-4, 1.0e-3, 4
+    opt = torch.optim.SGD(net.parameters(), lr=max_lr, momentum=0.9)
+    sched = ref["scheduler"].CyclicLR(opt, base_lr=base_lr, max_lr=max_lr, step_size=step_size)
+    batches = [synthetic.make_batch(n, h, w, seed=seed + 10 + i, sparse_points=min(500, h * w // 6)) for i in range(3)]
+    for it in range(2):
+        _reference_iteration(ref, net, opt, sched, batches[it], it, h, w)
+    tmp = tempfile.mkdtemp()
+    ckpt = os.path.join(tmp, "checkpoint_model_epoch_1_validation_0.5.pt")
+    ref["utils"].save_model(model=net, optimizer=opt, epoch=1, step=2, model_path=ckpt, validation_loss=0.5)
+    blob = torch.load(ckpt, weights_only=False)          # the param group's lr is a numpy scalar (scheduler.py:133-135 assigns it): not in the weights-only allow-list
+    assert set(blob) == {"model", "optimizer", "epoch", "step", "validation"}
+    assert all(k.startswith("module.") for k in blob["model"])
+    out = {"n": n, "h": h, "w": w, "seed": seed, "base_lr": base_lr, "max_lr": max_lr, "step_size": step_size,
+           "epoch": blob["epoch"], "step": blob["step"], "validation": blob["validation"],
+           "model_keys": np.array(list(blob["model"].keys()))}
+    for k, v in blob["model"].items():
+        out["model::" + k] = t2n(v)
+    group = blob["optimizer"]["param_groups"][0]
+    out["opt_params"] = np.array(group["params"], dtype=np.int64)
+    for key in ("lr", "momentum", "dampening", "weight_decay"):
+        out["opt_" + key] = np.float64(group[key])
+    out["opt_nesterov"] = np.bool_(group["nesterov"])
+    for i, entry in blob["optimizer"]["state"].items():
+        out["opt_state::%d" % i] = t2n(entry["momentum_buffer"])
+    # what the reference does with its own file: fresh objects, reload, iteration 3
+    net2 = torch.nn.DataParallel(ref["models"].FCDenseNet57(n_classes=1))
+    net2.load_state_dict(blob["model"])
+    net2.train()
+    opt2 = torch.optim.SGD(net2.parameters(), lr=max_lr, momentum=0.9)
+    opt2.load_state_dict(blob["optimizer"])
+    sched2 = ref["scheduler"].CyclicLR(opt2, base_lr=base_lr, max_lr=max_lr, step_size=step_size)
+    before = [p.detach().clone() for p in net2.parameters()]
+    loss, gnorm = _reference_iteration(ref, net2, opt2, sched2, batches[2], 2, h, w)
+    out["step2_loss"] = t2n(loss)
+    out["step2_grad_norm"] = t2n(gnorm)
+    out["step2_lr"] = np.float64(opt2.param_groups[0]["lr"])
+    out["step2_param_norms"] = np.array([float(p.double().norm()) for p in net2.parameters()])
+    out["step2_param_sums"] = np.array([float(p.double().sum()) for p in net2.parameters()])
+    out["step2_update_norms"] = np.array([float((p.detach().double() - q.double()).norm()) for p, q in zip(net2.parameters(), before)])
+    np.savez_compressed(path, **out)
+    print("wrote", path, "iteration-3 loss", float(loss), "lr", float(out["step2_lr"]))
+
+    # ---- the other direction: a file written here loads into the reference's objects -------------------------------------
+    mine = ea.FCDenseNet57(1)
+    ea.utils.load_model_state(mine, blob["model"])
+    fused = ea.optim.FusedClipSGD(mine, lr=max_lr)
+    fused.load_state_dict(blob["optimizer"])
+    ckpt2 = os.path.join(tmp, "written_here.pt")
+    ea.utils.save_model(mine, fused, 1, 2, ckpt2, 0.5)
+    blob2 = torch.load(ckpt2, weights_only=False)
+    assert set(blob2) == set(blob) and list(blob2["model"].keys()) == list(blob["model"].keys())
+    net3 = torch.nn.DataParallel(ref["models"].FCDenseNet57(n_classes=1))
+    res = net3.load_state_dict(blob2["model"])
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in net3.state_dict().items():
+        assert torch.equal(v, blob["model"][k]), k
+    opt3 = torch.optim.SGD(net3.parameters(), lr=0.5, momentum=0.1)
+    opt3.load_state_dict(blob2["optimizer"])
+    g3 = opt3.param_groups[0]
+    assert g3["lr"] == group["lr"] and g3["momentum"] == group["momentum"] and g3["nesterov"] == group["nesterov"]
+    for i, p in enumerate(net3.parameters()):
+        assert torch.equal(opt3.state[p]["momentum_buffer"], blob["optimizer"]["state"][i]["momentum_buffer"]), i
+    # evaluate.py:144-155: load, then unwrap .module
+    plain = net3.module
+    assert not any(k.startswith("module.") for k in plain.state_dict())
+    print("checkpoint written by this repository loads into the reference's DataParallel model and torch.optim.SGD: bit-identical")
+
+
+
 FULL_KEEP = ("firstconv.weight", "firstconv.bias", "finalConv.weight", "finalConv.bias",
              "denseBlocksDown.0.layers.0.conv.weight", "denseBlocksDown.0.layers.0.norm.weight",
              "denseBlocksDown.0.layers.3.norm.bias", "denseBlocksDown.1.layers.2.conv.weight",
@@ -532,6 +644,9 @@ def main():
     if "--reader-only" in sys.argv:
         reader_case(ref, os.path.join(HERE, "reader_example.npz"))
         return
+    if "--checkpoint-only" in sys.argv:
+        checkpoint_case(ref, 2, 64, 96, 41, os.path.join(HERE, "checkpoint_2x64x96.npz"))
+        return
     if "--full-only" in sys.argv:          # the benchmark-size case alone (minutes of CPU, ~25 GB with the fp64 yardstick)
         train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
         return
@@ -542,6 +657,7 @@ def main():
     network_case(ref, 2, 32, 32, 21, os.path.join(HERE, "network_2x32x32.npz"))
     network_case(ref, 2, 64, 96, 22, os.path.join(HERE, "network_2x64x96.npz"))
     train_step_case(ref, 2, 64, 96, 31, os.path.join(HERE, "train_step_2x64x96.npz"))
+    checkpoint_case(ref, 2, 64, 96, 41, os.path.join(HERE, "checkpoint_2x64x96.npz"))
     cyclic_lr_case(ref, os.path.join(HERE, "cyclic_lr.npz"))
     scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
     point_cloud_case(ref, os.path.join(HERE, "point_cloud.npz"))

@@ -92,6 +92,59 @@ def test_flat_buffers_and_checkpoint_roundtrip(tmp_path):
     assert torch.equal(other.flat_parameters(), model.flat_parameters())
 
 
+def test_reference_written_checkpoint_loads(golden, tmp_path):
+    """the checkpoint the REFERENCE wrote (its utils.save_model on its DataParallel-wrapped model and torch.optim.SGD after
+    two iterations; tensors in tests/golden/checkpoint_2x64x96.npz) loads into FCDenseNet57 + FusedClipSGD, comes back out of
+    state_dict() bit for bit in torch.optim.SGD's layout (which the stock optimizer accepts), and survives this repository's
+    save_model / load_checkpoint.  The opposite direction -- a file written here loaded by the reference's modules -- needs the
+    reference and is asserted by make_golden.py checkpoint_case in the build container.  The resumed ITERATION is the GPU test
+    tests/test_gpu_parity.py::test_checkpoint_resume_matches_reference."""
+    from conftest import checkpoint_from_fixture
+    blob = checkpoint_from_fixture(golden("checkpoint_2x64x96.npz"))
+    assert all(k.startswith("module.") for k in blob["model"]) and len(blob["model"]) == 357
+    assert len(blob["optimizer"]["state"]) == 210 and blob["epoch"] == 1 and blob["step"] == 2
+    model = ea.FCDenseNet57(1)
+    res = ea.utils.load_model_state(model, blob["model"])
+    assert not res.missing_keys and not res.unexpected_keys
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, blob["model"]["module." + k]), k
+    opt = ea.optim.FusedClipSGD(model, lr=0.5)
+    assert opt.state_dict()["state"] == {}                                   # no step yet: nothing to carry (torch.optim.SGD does the same)
+    opt.load_state_dict(blob["optimizer"])
+    assert opt.param_groups[0]["lr"] == blob["optimizer"]["param_groups"][0]["lr"] and opt.param_groups[0]["momentum"] == 0.9
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == list(range(210)) and sd["param_groups"][0]["params"] == list(range(210))
+    for i, p in enumerate(model.parameters()):
+        buf = sd["state"][i]["momentum_buffer"]
+        assert buf.shape == p.shape and torch.equal(buf, blob["optimizer"]["state"][i]["momentum_buffer"]), i
+    stock = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.5)
+    stock.load_state_dict(sd)                                                # the reference's optimizer takes FusedClipSGD's dictionary as is
+    assert stock.param_groups[0]["momentum"] == 0.9 and stock.param_groups[0]["nesterov"] is False
+    for i, p in enumerate(model.parameters()):
+        assert torch.equal(stock.state[p]["momentum_buffer"], blob["optimizer"]["state"][i]["momentum_buffer"])
+    # a partial optimizer state is refused, not silently zero-filled
+    broken = {"state": {i: v for i, v in blob["optimizer"]["state"].items() if i != 7}, "param_groups": blob["optimizer"]["param_groups"]}
+    with pytest.raises(ValueError, match="209 of 210"):
+        ea.optim.FusedClipSGD(model, lr=0.5).load_state_dict(broken)
+    # file round trip through this repository's writer / reader
+    path = tmp_path / "checkpoint_model_epoch_1_validation_0.5.pt"
+    ea.utils.save_model(model, opt, blob["epoch"], blob["step"], path, blob["validation"])
+    other = ea.FCDenseNet57(1)
+    other_opt = ea.optim.FusedClipSGD(other, lr=0.5)
+    back = ea.utils.load_checkpoint(path, other, other_opt)
+    assert list(back["model"].keys()) == list(blob["model"].keys()) and (back["epoch"], back["step"], back["validation"]) == (1, 2, 0.5)
+    assert torch.equal(other.flat_parameters(), model.flat_parameters()) and torch.equal(other_opt._momentum, opt._momentum)
+    for k, v in other.state_dict().items():
+        assert torch.equal(v, blob["model"]["module." + k]), k
+
+
+def test_clean_point_list_refuses_hsv_frames():
+    """reader.get_clean_point_list filters B, G, R bytes; the reference converts HSV frames back first (utils.py:362-363), which is not
+    built here -- so the flag must fail loudly instead of filtering H, S, V as colours."""
+    with pytest.raises(NotImplementedError, match="BGR"):
+        ea.reader.get_clean_point_list(None, [[0, 0, 0, 1]], None, None, 0.99, None, None, is_hsv=True)
+
+
 def test_no_cpu_fallback():
     model = ea.FCDenseNet57(1)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
