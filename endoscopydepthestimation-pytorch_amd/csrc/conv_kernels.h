@@ -92,6 +92,11 @@ struct ConvParams {
     int group_n;
     int64_t gs, in_gs, out_gs;
     int sub_c;        // IN_SUBPIX: real channels per sub-pixel phase (cin = 4 * sub_c pseudo-channels)
+    // ---- the last dense layer of the network (wino4_fwd_kernel<true>): the final 1x1 convolution over the channels this launch streams
+    // anyway -- fin_out[sample][pixel] = sum over the launch's input channels of fin_w[c] * x_raw[c][pixel] (no BN, no ReLU: finalConv reads the
+    // raw concatenation, reference models.py:167, 186).  fin_out is a tape pointer: it moves with the group like `out`'s tape does (gs).
+    const float* fin_w;
+    float* fin_out;
 };
 
 // this block's group and sample inside it

@@ -51,6 +51,13 @@ struct DgradBlockParams {
     // grouped batch (see ConvParams): blockIdx.z = group * group_n + sample; g, x, out, saved, scratch move by group * gs floats
     int group_n;
     int64_t gs;
+    // "virtual" old gradient (the last up block at the finest level): what `out` holds before this launch is the final 1x1
+    // convolution's data gradient, g(pixel) * vw[channel] (reference models.py:167, 186: finalConv + abs) -- a rank-one tensor.  With vg set the
+    // kernel forms it from the ONE plane g = grad_out * sign(pre) (vg: [group][sample][pixel], groups gs floats apart) and the 192
+    // final-conv weights instead of reading 4 bytes per channel and pixel that another kernel would first have had to write
+    // (192 planes = 1 GB at 16 x 256 x 320).  vw points at the range's first channel.
+    const float* vg;
+    const float* vw;
 };
 
 // VEC = 4: the G tile starts 4 pixels left of the output tile so that its rows are whole aligned float4s and arrive by 16-byte
@@ -228,7 +235,11 @@ __global__ void __launch_bounds__(kConvThreads) dgrad_block_kernel(const DgradBl
                 dc[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (!(EXP & 1) && co < p.count && y < p.h && px + 3 < p.w) {
                     xc[a][r] = *reinterpret_cast<const f32x4*>(x_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
-                    if (co >= p.acc_from) dc[a][r] = *reinterpret_cast<const f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
+                    if (p.vg) {          // (block-uniform) the old gradient is g * w_final[co]
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(p.vg + grp_off + static_cast<int64_t>(n) * p.cs + y * p.w + px);
+                        const float wf = p.vw[co];
+                        dc[a][r] = f32x4{gv[0] * wf, gv[1] * wf, gv[2] * wf, gv[3] * wf};
+                    } else if (co >= p.acc_from) dc[a][r] = *reinterpret_cast<const f32x4*>(out_n + static_cast<int64_t>(co) * p.cs + y * p.w + px);
                 }
             }
         }

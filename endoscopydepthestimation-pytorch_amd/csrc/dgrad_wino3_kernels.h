@@ -145,12 +145,21 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) t[2 * r + hh] = (EXP & 1) ? 0.f : x_n[pix_off(co, r, hh)];
     };
+    // the old gradient of a group: the buffer's content -- or, with p.vg (dgrad_block_kernels.h: the final convolution's rank-one data
+    // gradient, never materialised), g of the lane's pixels (the same 64 bytes for every group: L1 / L2 hits) times the channel's
+    // final-conv weight
+    const float* vg_n = p.vg ? p.vg + grp_off + static_cast<int64_t>(n) * p.cs : nullptr;
     auto load_old = [&](int co, f32x4 (&dst)[2][2]) {
+        const float wf = vg_n ? p.vw[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                if ((EXP & 1) != 0 || co < p.acc_from) dst[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if ((EXP & 1) != 0) dst[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
+                else if (vg_n) {
+                    const f32x4 gv = *reinterpret_cast<const f32x4*>(vg_n + pix0 + static_cast<unsigned>(r * p.w + 4 * hh));
+                    dst[r][hh] = f32x4{gv[0] * wf, gv[1] * wf, gv[2] * wf, gv[3] * wf};
+                } else if (co < p.acc_from) dst[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f};
                 else dst[r][hh] = *reinterpret_cast<const f32x4*>(out_n + pix_off(co, r, hh));
             }
     };
@@ -169,20 +178,23 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) { total[r][hh] = f32x4{0.f, 0.f, 0.f, 0.f}; dc[r][hh] = total[r][hh]; }
-    float av[3][16];                                 // this step's A operands: V_xi of the lane's patch of map 4 quad + lk
+    // this step's A operands: V_xi of the lane's patch of map 4 quad + lk, xi = 4 a + i at av[quad][2 a + (i >> 1)][i & 1] -- register PAIRS: the
+    // transforms are written on pairs (v_pk_add_f32 / v_pk_fma_f32).  That does NOT make them faster on gfx950 -- a packed fp32 instruction
+    // takes two issue slots, measured round 5: 45 % fewer vector instructions, the same time -- but the compiler allocates this form in
+    // 216 instead of 254 registers, which is the room the virtual old gradient (load_old) needs
+    f32x2 av[3][8];
     f32x4 acc[16];
 
     // ---- T: input transform of the lane's 4x4 patches of layer l's 12 maps: raw patch values into av (24 8-byte reads), transformed in place ----
     auto load_patches = [&](int l) {
 #pragma unroll
         for (int quad = 0; quad < 3; ++quad) {
-            // LDS rows 2 w4 .. 2 w4 + 3, columns 2 li .. 2 li + 3 (two aligned pairs)
+            // LDS rows 2 w4 .. 2 w4 + 3, columns 2 li .. 2 li + 3 (two aligned pairs): row r's pairs land in av[quad][2 r], av[quad][2 r + 1]
             const float* a_base = s_g + (l * 12 + quad * 4 + lk) * G::kCS + (2 * w4) * G::kCols + 2 * li;
 #pragma unroll
             for (int row = 0; row < 4; ++row) {
-                const f32x2 lo = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols);
-                const f32x2 hi = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 2);
-                av[quad][4 * row + 0] = lo[0]; av[quad][4 * row + 1] = lo[1]; av[quad][4 * row + 2] = hi[0]; av[quad][4 * row + 3] = hi[1];
+                av[quad][2 * row] = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols);
+                av[quad][2 * row + 1] = *reinterpret_cast<const f32x2*>(a_base + row * G::kCols + 2);
             }
         }
     };
@@ -190,18 +202,23 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
         if constexpr ((EXP & 64) != 0) return;
 #pragma unroll
         for (int quad = 0; quad < 3; ++quad) {
-            float d[4][4];
+            // B^T d on the column pairs (c0, c1) | (c2, c3): rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3) -- 8 packed adds
+            // (there is no packed subtract and clang scalarises a - b on ext-vectors: the difference is a packed add with the neg bits set;
+            // operands here come from LDS reads, never straight from an MFMA -- the hazard recogniser does not look into inline assembly)
+            auto sub2 = [](const f32x2 a, const f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r; };
+            const f32x2 l0 = av[quad][0], h0 = av[quad][1], l1 = av[quad][2], h1 = av[quad][3];
+            const f32x2 l2 = av[quad][4], h2 = av[quad][5], l3 = av[quad][6], h3 = av[quad][7];
+            const f32x2 tl[4] = {sub2(l0, l2), l1 + l2, sub2(l2, l1), sub2(l1, l3)};
+            const f32x2 th[4] = {sub2(h0, h2), h1 + h2, sub2(h2, h1), sub2(h1, h3)};
 #pragma unroll
-            for (int col = 0; col < 4; ++col) {          // B^T d: rows (d0 - d2, d1 + d2, d2 - d1, d1 - d3)
-                const float r0 = av[quad][col], r1 = av[quad][4 + col], r2 = av[quad][8 + col], r3 = av[quad][12 + col];
-                d[0][col] = r0 - r2; d[1][col] = r1 + r2; d[2][col] = r2 - r1; d[3][col] = r1 - r3;
-            }
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {                // (.) B: columns (c0 - c2, c1 + c2, c2 - c1, c1 - c3)
-                av[quad][4 * a + 0] = d[a][0] - d[a][2];
-                av[quad][4 * a + 1] = d[a][1] + d[a][2];
-                av[quad][4 * a + 2] = d[a][2] - d[a][1];
-                av[quad][4 * a + 3] = d[a][1] - d[a][3];
+            for (int a = 0; a < 4; ++a) {
+                // (.) B: (v0, v1) = (c0 - c2, c1 + c2), (v2, v3) = (c2 - c1, c1 - c3) -- one packed add each: the operand-select bits pick c2 for
+                // both halves / c1 for both halves, the neg bits the signs (clang turns the same arithmetic on ext-vectors into moves + xor)
+                f32x2 v01, v23;
+                asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(v01) : "v"(tl[a]), "v"(th[a]));
+                asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(v23) : "v"(th[a]), "v"(tl[a]));
+                av[quad][2 * a] = v01;
+                av[quad][2 * a + 1] = v23;
             }
         }
     };
@@ -211,7 +228,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
     auto mfmas = [&](int buf) {
         if constexpr ((EXP & 128) != 0) {          // diagnostic: no M phase at all
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = f32x4{av[0][i], av[1][i], av[2][i], av[0][i]};
+            for (int i = 0; i < 16; ++i) acc[i] = f32x4{av[0][i >> 1][i & 1], av[1][i >> 1][i & 1], av[2][i >> 1][i & 1], av[0][i >> 1][i & 1]};
             return;
         }
         if constexpr ((OPT & 32) != 0) __builtin_amdgcn_s_setprio(1);
@@ -225,12 +242,12 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if constexpr ((EXP & 32) != 0) {
-                        if (quad == 0) acc[4 * a + i] = f32x4{av[quad][4 * a + i] * b[i], 0.f, 0.f, 0.f};
-                        else acc[4 * a + i][quad] += av[quad][4 * a + i] * b[i];
+                        if (quad == 0) acc[4 * a + i] = f32x4{av[quad][2 * a + (i >> 1)][i & 1] * b[i], 0.f, 0.f, 0.f};
+                        else acc[4 * a + i][quad] += av[quad][2 * a + (i >> 1)][i & 1] * b[i];
                     } else if (quad == 0) {
-                        acc[4 * a + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[quad][4 * a + i], b[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        acc[4 * a + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[quad][2 * a + (i >> 1)][i & 1], b[i], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     } else {
-                        acc[4 * a + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[quad][4 * a + i], b[i], acc[4 * a + i], 0, 0, 0);
+                        acc[4 * a + i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[quad][2 * a + (i >> 1)][i & 1], b[i], acc[4 * a + i], 0, 0, 0);
                     }
                 }
             }
@@ -247,32 +264,46 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
             for (int i = 0; i < 16; ++i) total[i >> 3][(i >> 2) & 1][i & 3] += acc[i][0];
             return;
         }
-        const float scale = bn[0], beta = bn[1], mean = bn[2], rstd = bn[3];
-        float s1 = 0.f, s2 = 0.f;
+        // On register pairs: the output transform A^T M A runs on the tile pairs (e, e + 1) of the accumulators (adjacent registers of an MFMA
+        // result), BN + ReLU backward on the pixel pairs (k, k + 1) of x / the running total (adjacent registers of a 16-byte load); the
+        // per-pixel select between the two (dz = z > 0 ? d : 0) writes its results where the second layout wants them: the transposition.
+        const f32x2 sb = {bn[0], bn[1]}, mr = {bn[2], bn[3]};          // (scale, beta), (mean, rstd)
+        const float rstd = bn[3];
+        f32x2 s1v = {0.f, 0.f}, s2v = {0.f, 0.f};
+        f32x2 minus1 = {-1.f, -1.f};
+        asm("" : "+v"(minus1));          // opaque: with a visible constant the fma below folds back into a subtraction, which is scalarised
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float u0r[4], u1r[4];
+        for (int hh = 0; hh < 2; ++hh) {          // tiles e = 2 hh, 2 hh + 1 = the lane's column half hh
+            f32x2 u0r[4], u1r[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float m0 = acc[c][e], m1 = acc[4 + c][e], m2 = acc[8 + c][e], m3 = acc[12 + c][e];
+                const f32x2 m0 = {acc[c][2 * hh], acc[c][2 * hh + 1]}, m1 = {acc[4 + c][2 * hh], acc[4 + c][2 * hh + 1]};
+                const f32x2 m2 = {acc[8 + c][2 * hh], acc[8 + c][2 * hh + 1]}, m3 = {acc[12 + c][2 * hh], acc[12 + c][2 * hh + 1]};
                 u0r[c] = m0 + m1 + m2;
-                u1r[c] = m1 - m2 - m3;
+                u1r[c] = __builtin_elementwise_fma(m2 + m3, minus1, m1);          // m1 - m2 - m3 (compiler-made instructions here: they read MFMA results, and the MFMA -> VALU wait states are the compiler's to insert)
             }
-            const float d[2][2] = {{u0r[0] + u0r[1] + u0r[2], u0r[1] - u0r[2] - u0r[3]},
-                                   {u1r[0] + u1r[1] + u1r[2], u1r[1] - u1r[2] - u1r[3]}};
+            // d[r][cx] over the tile pair: pixel k = 2 (e & 1) + cx of the column half
+            const f32x2 d[2][2] = {{u0r[0] + u0r[1] + u0r[2], __builtin_elementwise_fma(u0r[2] + u0r[3], minus1, u0r[1])},
+                                   {u1r[0] + u1r[1] + u1r[2], __builtin_elementwise_fma(u1r[2] + u1r[3], minus1, u1r[1])}};
 #pragma unroll
-            for (int r = 0; r < 2; ++r)
+            for (int r = 0; r < 2; ++r) {
 #pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    const int hh = e >> 1, k = 2 * (e & 1) + cx;
-                    const float xcen = xc[r][hh][k] - mean;
-                    const float z = fmaf(xcen, scale, beta);
-                    const float dz = z > 0.f ? d[r][cx] : 0.f;
-                    s1 += dz;
-                    s2 = fmaf(dz, xcen, s2);
-                    total[r][hh][k] = fmaf(dz, scale, total[r][hh][k]);
+                for (int ee = 0; ee < 2; ++ee) {          // pixels k = 2 ee, 2 ee + 1
+                    const f32x2 x2 = {xc[r][hh][2 * ee], xc[r][hh][2 * ee + 1]};
+                    f32x2 xcen, z;
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(xcen) : "v"(x2), "v"(mr));              // x - mean
+                    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(z) : "v"(xcen), "v"(sb));                     // xcen * scale + beta
+                    const f32x2 dz = {z[0] > 0.f ? d[r][0][ee] : 0.f, z[1] > 0.f ? d[r][1][ee] : 0.f};
+                    s1v += dz;
+                    s2v = __builtin_elementwise_fma(dz, xcen, s2v);
+                    f32x2 t2 = {total[r][hh][2 * ee], total[r][hh][2 * ee + 1]};
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(t2) : "v"(dz), "v"(sb));                                    // total += dz * scale
+                    total[r][hh][2 * ee] = t2[0];
+                    total[r][hh][2 * ee + 1] = t2[1];
                 }
+            }
         }
+        float s1 = s1v[0] + s1v[1], s2 = s2v[0] + s2v[1];
         s2 *= rstd;
         s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);

@@ -165,6 +165,7 @@ struct endo_net {
     int64_t wg_scratch_off;   // float offset in gradws of the weight-gradient partial sums (wgrad_nsplit_kernels.h)
     int64_t tuw_scratch_off;  // float offset in gradws of the transition-up data-gradient weights (tu_subpix_dgrad_weights_kernel)
     int64_t wd_off;           // float offset in gradws of the Winograd-domain data-gradient weights (group 0's copy serves all groups)
+    int64_t gplane_off;       // float offset in gradws of g = grad_out * sign(pre), one plane per sample (final_g_kernel)
     int64_t gradws_floats;
     // Weight gradients run on a side stream: a layer's wgrad depends only on its prepared dY and the forward tape, nothing on the
     // backward chain depends on it (it only adds into the flat gradient), so it overlaps the data-gradient chain -- which at the
@@ -198,10 +199,13 @@ struct BnFin4 {
 // their deferred terms are not in P, Q yet: every block derives them from the pass's sums (the arithmetic of
 // bn_bwd_finalize4_kernel, term by term), and the first block of a (channel, group) also adds the BN parameter gradients.
 // This takes the separate finalize launch between the pass and this kernel off the backward chain.
+// vg: the range's raw gradient is not in dbuf but is the final convolution's rank-one data gradient g(pixel) * vw[channel]
+// (DgradBlockParams::vg): read the one plane g instead (first writer of the range).
 __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, const float* __restrict__ x, int64_t ns, int plane,
                                                       const float* __restrict__ pq_p, const float* __restrict__ pq_q,
                                                       float* bias_grad, int group_n, int64_t gs, const BnFin4 fin, int nl,
-                                                      double count, int training, int64_t slot_stride) {
+                                                      double count, int training, int64_t slot_stride,
+                                                      const float* __restrict__ vg, const float* __restrict__ vw) {
     __shared__ double scratch[4];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
@@ -230,10 +234,18 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
         qc += static_cast<float>(dq);
     }
     const int64_t base = grp * gs + n * ns + static_cast<int64_t>(c) * plane;
+    const float* vg_n = vg ? vg + grp * gs + static_cast<int64_t>(n) * plane : nullptr;          // (block-uniform)
+    const float wf = vg ? vw[c] : 0.f;
     float part = 0.f;
     if ((plane & 3) == 0) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(dbuf + base + i);
+            f32x4 g;
+            if (vg_n) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(vg_n + i);
+                g = f32x4{gv[0] * wf, gv[1] * wf, gv[2] * wf, gv[3] * wf};
+            } else {
+                g = *reinterpret_cast<const f32x4*>(dbuf + base + i);
+            }
             const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { g[e] += fmaf(pc, xv[e], qc); part += g[e]; }
@@ -241,7 +253,7 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
         }
     } else {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
-            const float g = dbuf[base + i] + fmaf(pc, x[base + i], qc);
+            const float g = (vg_n ? vg_n[i] * wf : dbuf[base + i]) + fmaf(pc, x[base + i], qc);
             dbuf[base + i] = g;
             part += g;
         }
@@ -386,9 +398,10 @@ __global__ void __launch_bounds__(256) finalize_partial_kernel(const float* __re
 }
 
 // final 1x1 conv 192 -> 1 and |.| (reference models.py:186).  HBM-bound: reads each plane once.
+// c_first > 0: `pre` already holds the sum over channels [0, c_first) (wino4_fwd_kernel<true>, the last dense layer's launch) and only the rest is read
 __global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict__ u, int64_t ns, int plane, int cin,
                                                         const float* __restrict__ wgt, const float* __restrict__ bias,
-                                                        float* __restrict__ pre, float* __restrict__ out, int group_n, int64_t gs) {
+                                                        float* __restrict__ pre, float* __restrict__ out, int group_n, int64_t gs, int c_first) {
     __shared__ float s_w[192];
     for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
     __syncthreads();
@@ -401,8 +414,9 @@ __global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict_
     if (vec) {
         for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < plane; i += gridDim.x * blockDim.x * 4) {
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (c_first > 0) acc = *reinterpret_cast<const f32x4*>(pre + static_cast<int64_t>(n) * plane + i);
             const float* src = u + n * ns + i;
-            for (int c = 0; c < cin; ++c) {
+            for (int c = c_first; c < cin; ++c) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(src + static_cast<int64_t>(c) * plane);
                 const float wc = s_w[c];
                 acc[0] = fmaf(v[0], wc, acc[0]); acc[1] = fmaf(v[1], wc, acc[1]);
@@ -416,8 +430,8 @@ __global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict_
         }
     } else {
         for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
-            float acc = 0.f;
-            for (int c = 0; c < cin; ++c) acc = fmaf(u[n * ns + static_cast<int64_t>(c) * plane + i], s_w[c], acc);
+            float acc = c_first > 0 ? pre[static_cast<int64_t>(n) * plane + i] : 0.f;
+            for (int c = c_first; c < cin; ++c) acc = fmaf(u[n * ns + static_cast<int64_t>(c) * plane + i], s_w[c], acc);
             acc += bias[0];
             if (pre) pre[static_cast<int64_t>(n) * plane + i] = acc;
             out[static_cast<int64_t>(n) * plane + i] = fabsf(acc);
@@ -427,10 +441,19 @@ __global__ void __launch_bounds__(256) final_fwd_kernel(const float* __restrict_
 
 __device__ __forceinline__ float sign_of(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
 
-// dbuf[c] = (gout * sign(pre)) * w[c] for all 192 planes (first writer of the level-0 gradient buffer)
+// g = gout * sign(pre): the one plane the final convolution's data gradient g * w[c] is made of (DgradBlockParams::vg) -- the kernels of the
+// last up block form the 192 products themselves instead of reading them back from 192 planes
+__global__ void __launch_bounds__(256) final_g_kernel(const float* __restrict__ gout, const float* __restrict__ pre, float* __restrict__ g,
+                                                      int plane, int group_n, int64_t gs) {
+    const int grp = blockIdx.y / group_n, n = blockIdx.y - grp * group_n;
+    gout += static_cast<int64_t>(blockIdx.y) * plane; pre += grp * gs + static_cast<int64_t>(n) * plane; g += grp * gs + static_cast<int64_t>(n) * plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) g[i] = gout[i] * sign_of(pre[i]);
+}
+
+// dbuf[c] = (gout * sign(pre)) * w[c] for planes [c_first, cin) (first writer of the level-0 gradient buffer)
 __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                              const float* __restrict__ wgt, float* __restrict__ dbuf,
-                                                             int64_t ns, int plane, int cin, int group_n, int64_t gs) {
+                                                             int64_t ns, int plane, int cin, int group_n, int64_t gs, int c_first) {
     __shared__ float s_w[192];
     for (int c = threadIdx.x; c < cin; c += blockDim.x) s_w[c] = wgt[c];
     __syncthreads();
@@ -438,7 +461,7 @@ __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __rest
     gout += static_cast<int64_t>(grp) * group_n * plane; pre += grp * gs; dbuf += grp * gs;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < plane; i += gridDim.x * blockDim.x) {
         const float g = gout[static_cast<int64_t>(n) * plane + i] * sign_of(pre[static_cast<int64_t>(n) * plane + i]);
-        for (int c = 0; c < cin; ++c) dbuf[n * ns + static_cast<int64_t>(c) * plane + i] = g * s_w[c];
+        for (int c = c_first; c < cin; ++c) dbuf[n * ns + static_cast<int64_t>(c) * plane + i] = g * s_w[c];
     }
 }
 
@@ -568,6 +591,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_MFMA_X3         bit mask of the kernel families (1 wgrad, 2 forward, 4 dgrad) that evaluate fp32 products as three-term bf16 splits (common.h)
 //   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
 //   ENDO_OPT_WGRAD_F34       1 = dense weight gradients of the fine levels in the Winograd domain F(3x3, 4x4) (wgrad_f34_kernels.h)
+//   ENDO_OPT_FINAL_VIRTUAL   1 = the final convolution's data gradient is not written out: the last up block's kernels form g * w[c] (FinalVirt)
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
     opt[ENDO_OPT_WINO_DGRAD] = 1;
@@ -577,6 +601,7 @@ static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
     opt[ENDO_OPT_MFMA_X3] = 0;
     opt[ENDO_OPT_WGRAD_F34] = 1;
+    opt[ENDO_OPT_FINAL_VIRTUAL] = 1;
 }
 static int wino_fwd_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_FWD]; }
 static bool wino_fwd_enabled(const Ctx& c) { return wino_fwd_mode(c) != 0; }
@@ -592,7 +617,10 @@ static bool mfma_bf16_fwd(const Ctx& c) { return (mfma_bf16_mask(c) & 2) != 0; }
 static bool mfma_bf16_dgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 4) != 0; }
 
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
-static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
+// fin_w / fin_pre / fused_final: the network's last dense layer may also form the final convolution's sum over its input channels
+// (ConvParams::fin_w); *fused_final says whether the kernel form that ran did
+static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv, const float* fin_w = nullptr, float* fin_pre = nullptr,
+                     bool* fused_final = nullptr) {
     const auto& lv = c.net->lv[level];
     ConvParams p{};
     fill_grid(c, p, level);
@@ -609,7 +637,10 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         ConvParams p4 = p;
         p4.wgt = c.tape + c.net->wino4_off + cv.u / kWinoUStride * kW4UStride;
         const long t4 = static_cast<long>((lv.w + 63) / 64) * ((lv.h + 15) / 16) * c.nt();
-        if (wino4_fwd_ok(p4) && 2 * t4 >= c.net->opt[ENDO_OPT_WINO_MIN_TILES]) return launch_wino4_fwd(p4, c.stream);          // (level 0 of configs[1]: at level 1 the 64 x 16 blocks no longer fill the chip, measured slower)
+        if (wino4_fwd_ok(p4) && 2 * t4 >= c.net->opt[ENDO_OPT_WINO_MIN_TILES]) {          // (level 0 of configs[1]: at level 1 the 64 x 16 blocks no longer fill the chip, measured slower)
+            if (fin_w && fused_final && c.net->opt[ENDO_OPT_FINAL_VIRTUAL]) { p4.fin_w = fin_w + ic0; p4.fin_out = fin_pre; *fused_final = true; }
+            return launch_wino4_fwd(p4, c.stream);
+        }
     }
     if (wino_fwd_enabled(c) && cv.u >= 0 && !mfma_bf16_fwd(c)) {
         ConvParams pw = p;
@@ -741,7 +772,12 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     return launch_conv_dma_auto<3, 4, 3, IN_UPSAMPLE, EPI_FWD>(p, c.stream);
 }
 
-static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad, const BnFin4* fin = nullptr, int nl = 0) {
+// The final convolution's data gradient as the "virtual" content of the level-0 gradient buffer (DgradBlockParams::vg): vg = the plane
+// g = grad_out * sign(pre) in the gradient workspace, vw = the 192 final-conv weights; base: the base-channel pass forms it too
+// (otherwise final_bwd_data_kernel has materialised the block's base channels)
+struct FinalVirt { const float* vg; const float* vw; bool base; };
+
+static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad, const BnFin4* fin = nullptr, int nl = 0, const FinalVirt* fv = nullptr) {
     const auto& lv = c.net->lv[level];
     BnFin4 none{};
     int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
@@ -750,7 +786,8 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad,
     prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
                                                                      c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs, fin ? *fin : none, fin ? nl : 0,
-                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->slot_stride);
+                                                                     static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->slot_stride,
+                                                                     fv ? fv->vg : nullptr, fv ? fv->vw + c0 : nullptr);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -833,7 +870,19 @@ static int dense_bwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
 //                 reads (they carry the layer-to-layer dependency); then ONE fused dgrad for the base channels
 //                 of all four layers (dgrad_block_kernels.h) -- 3x less HBM traffic than four full dgrads
 //   coarse levels: the per-layer path (few tiles: parallelism comes from splitting channels over blocks)
-static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* bn, const ConvP* cv, bool base_overwrite) {
+// Which base-channel kernel the fused path takes (0 = dgrad_block8, 1 = phase-skewed Winograd, 2 = round-2 Winograd)
+static int base_pass_form(const Ctx& c, int level, const DgradBlockParams& p, const ConvP* cv) {
+    const auto& lv = c.net->lv[level];
+    const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
+    if (mfma_bf16_dgrad(c)) return 0;
+    if (wino_dgrad_enabled(c) && dgrad_wino_ok(p) && wtiles >= c.net->opt[ENDO_OPT_WINO_MIN_TILES] && cv[0].ud >= 0)
+        return (wino_dgrad_mode(c) == 1 && dgrad_wino3_ok(p)) ? 1 : 2;
+    return 0;
+}
+
+// fv: the block's gradient-buffer range starts out as the final convolution's rank-one data gradient (the last up block, level 0), which
+// is never written: the first touch of every channel forms it (FinalVirt)
+static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* bn, const ConvP* cv, bool base_overwrite, const FinalVirt* fv = nullptr) {
     const auto& lv = c.net->lv[level];
     const int new0 = ic0 + c0;
     DgradBlockParams probe{};
@@ -858,7 +907,9 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     BnFin4 pending{};          // BN layers whose sums over the next prepared maps the last new-channel pass produced (folded into prep_dy)
     int pending_nl = 0;
     for (int j = kLayers - 1; j >= 0; --j) {
-        int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b, &pending, pending_nl);
+        // (with fv: layer 3's maps have no gradient in the buffer yet -- prep_dy is their first writer; the maps of layers 2..0 were
+        // written, from the virtual content, by the new-channel passes below)
+        int rc = prep_dy(c, level, new0 + kGrowth * j, kGrowth, c.grads + cv[j].b, &pending, pending_nl, (fv && j == kLayers - 1) ? fv : nullptr);
         if (rc) return rc;
         // ENDO_OPT_WGRAD_OVERLAP 1: fork after every prep_dy; 2: ONE fork per dense block, after its last prep_dy (nothing rewrites a
         // prepared G before the join, so the four weight gradients may start late; 55 -> 22 event record / wait pairs per backward pass)
@@ -885,6 +936,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             p.out = c.gbuf(level) + (ic0 + t0) * lv.plane;
             p.count = kGrowth;
             p.acc_from = 0;          // a later consumer (next block / transition) wrote these maps first
+            if (fv) { p.vg = fv->vg; p.vw = fv->vw + ic0 + t0; }          // ... or nobody: the final convolution's gradient is formed here
             p.w_ci_off = t0;
             BnFin4 a{};
             for (int l = 0; l < nl; ++l) {
@@ -930,15 +982,19 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
         ProfScope prof(kProfDgradDense, c.stream, 2.0 * c.nt() * lv.plane * c0 * kGrowth * 9 * kLayers,
                        4.0 * c.nt() * lv.plane * (3.0 * c0 + kGrowth * kLayers));
         int rc;
-        const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
+        const int form = base_pass_form(c, level, p, cv);
+        if (fv && fv->base) {
+            if (form != 1) return ENDO_E_BADARG;          // endo_net_bwd asked for a virtual base only where the phase-skewed kernel runs
+            p.vg = fv->vg; p.vw = fv->vw + ic0;
+        }
         if (mfma_bf16_dgrad(c)) {
             rc = launch_dgrad_block8<4, 1>(p, c.stream);
-        } else if (wino_dgrad_enabled(c) && dgrad_wino_ok(p) && wtiles >= c.net->opt[ENDO_OPT_WINO_MIN_TILES] && cv[0].ud >= 0) {
+        } else if (form != 0) {
             // fine levels: Winograd F(2x2, 3x3), 48 instead of 108 MFMAs per 64 pixels and step (dgrad_wino_kernels.h)
             const float* ub = c.gradws + c.net->wd_off;
             const float* const u[4] = {ub + cv[0].ud, ub + cv[1].ud, ub + cv[2].ud, ub + cv[3].ud};
-            // mode 1: the phase-skewed kernel (its U layout; endo_net_bwd transforms the weights to match), 2: the round-2 kernel
-            rc = (wino_dgrad_mode(c) == 1 && dgrad_wino3_ok(p)) ? run_dgrad_wino3_nl4(p, u, c.stream) : launch_dgrad_wino8<4>(p, u, c.stream);
+            // form 1: the phase-skewed kernel (its U layout; endo_net_bwd transforms the weights to match), 2: the round-2 kernel
+            rc = form == 1 ? run_dgrad_wino3_nl4(p, u, c.stream) : launch_dgrad_wino8<4>(p, u, c.stream);
         } else {
             rc = launch_dgrad_block8<4>(p, c.stream);       // 512-thread blocks: +15 % over the 4-wave kernel (tools/conv_bench)
         }
@@ -1100,7 +1156,8 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
     net->tuw_scratch_off = net->wg_scratch_off + std::max(std::max(kNsScratchFloats, kSpScratchFloats), kF34ScratchFloats);
     net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
-    net->gradws_floats = net->wd_off + tb.wino_dgrad_floats;
+    net->gplane_off = align_up(net->wd_off + tb.wino_dgrad_floats, 64);
+    net->gradws_floats = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
@@ -1178,6 +1235,7 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
         ENDO_LAUNCH_CHECK();
     }
     int rc;
+    bool fused_final = false;
     {   // first conv 3 -> 48 into level-0 channels [48, 96)
         ConvParams p{};
         fill_grid(c, p, 0);
@@ -1209,18 +1267,21 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
         rc = tu_fwd(c, l, src, src_c0, tb.tu_conv[i]);
         if (rc) return rc;
         for (int j = 0; j < kLayers; ++j) {
-            rc = dense_fwd(c, l, 0, 96 + down_in(l) + kGrowth * j, tb.up_bn[i][j], tb.up_conv[i][j]);
+            const bool last = l == 0 && j == kLayers - 1;          // the layer whose 180 input channels are all but 12 of the final convolution's
+            rc = dense_fwd(c, l, 0, 96 + down_in(l) + kGrowth * j, tb.up_bn[i][j], tb.up_conv[i][j], last ? params + tb.final_.w : nullptr,
+                           last ? tape + net->pre_off : nullptr, last ? &fused_final : nullptr);
             if (rc) return rc;
         }
     }
     {
         const auto& lv = net->lv[0];
-        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * 194);
+        const int c_first = fused_final ? 96 + down_in(0) + kGrowth * (kLayers - 1) : 0;          // 180: the last layer's launch has summed channels [0, 180) into `pre`
+        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (194 - c_first));
         int bx = static_cast<int>((lv.plane / 4 + 255) / 256);
         bx = bx < 1 ? 1 : bx;
         final_fwd_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(c.act(0), lv.t * lv.plane, static_cast<int>(lv.plane), 192,
                                                                  params + tb.final_.w, params + tb.final_.b, tape + net->pre_off, out,
-                                                                 net->n, net->gs);
+                                                                 net->n, net->gs, c_first);
         ENDO_LAUNCH_CHECK();
     }
     return 0;
@@ -1248,6 +1309,8 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         ENDO_LAUNCH_CHECK();
     }
     int rc;
+    FinalVirt virt{};
+    bool use_virt = false;
     {
         const auto& lv = net->lv[0];
         {   // final conv weight / bias gradient: reads only grad_out and the tape, so it goes to the side stream first
@@ -1262,15 +1325,37 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
                                                                          grads + tb.final_.b);
             ENDO_LAUNCH_CHECK();
         }
-        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (192 + 2));
-        int bx = static_cast<int>((lv.plane + 255) / 256);
-        final_bwd_data_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
-                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), 192, net->n, net->gs);
-        ENDO_LAUNCH_CHECK();
+        // The final convolution's data gradient is rank one: dX[c] = g * w[c], g = grad_out * sign(pre).  Writing it out (192 planes, 1 GB
+        // at 16 x 256 x 320) only for the last up block to read it back costs two passes over the level-0 buffer; instead g goes to one
+        // plane and that block's kernels form the products where they first touch a channel (FinalVirt) -- where the block takes the
+        // fused path, and for its base channels where the phase-skewed Winograd kernel runs; what is left is materialised as before.
+        DgradBlockParams probe{};
+        probe.n = c.nt(); probe.h = lv.h; probe.w = lv.w; probe.count = 96 + down_in(0);
+        probe.cs = static_cast<int>(lv.plane); probe.ns = lv.t * lv.plane;
+        probe.x = c.act(0); probe.out = c.gbuf(0);
+        virt.vg = gradws + net->gplane_off; virt.vw = params + tb.final_.w; virt.base = false;
+        int materialise = 192;          // channels [0, materialise) are written by final_bwd_data_kernel
+        if (c.net->opt[ENDO_OPT_FINAL_VIRTUAL] && dgrad_block_ok(probe)) {
+            use_virt = true;
+            virt.base = base_pass_form(c, 0, probe, tb.up_conv[kLevels - 1]) == 1;
+            materialise = virt.base ? 0 : 96 + down_in(0);
+        }
+        ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (materialise + 2));
+        if (use_virt) {
+            int bx = static_cast<int>((lv.plane + 1023) / 1024);
+            final_g_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, gradws + net->gplane_off, static_cast<int>(lv.plane), net->n, net->gs);
+            ENDO_LAUNCH_CHECK();
+        }
+        if (materialise > 0) {
+            int bx = static_cast<int>((lv.plane + 255) / 256);
+            final_bwd_data_kernel<<<dim3(bx, c.nt()), 256, 0, c.stream>>>(grad_out, tape + net->pre_off, params + tb.final_.w, c.gbuf(0),
+                                                                          lv.t * lv.plane, static_cast<int>(lv.plane), materialise, net->n, net->gs, 0);
+            ENDO_LAUNCH_CHECK();
+        }
     }
     for (int i = kLevels - 1; i >= 0; --i) {
         const int l = kLevels - 1 - i;
-        rc = dense_block_bwd(c, l, 0, 96 + down_in(l), tb.up_bn[i], tb.up_conv[i], l > 0);
+        rc = dense_block_bwd(c, l, 0, 96 + down_in(l), tb.up_bn[i], tb.up_conv[i], l > 0, (l == 0 && use_virt) ? &virt : nullptr);
         if (rc) return rc;
         const int src = l + 1;
         const int src_c0 = (i == 0) ? 288 : 96 + down_in(src);
@@ -1286,8 +1371,6 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         if (rc) return rc;
     }
     {   // first conv: bias grad + weight grad (the image needs no gradient)
-        rc = prep_dy(c, 0, 48, kFirst, grads + tb.first.b);
-        if (rc) return rc;
         const auto& lv = net->lv[0];
         WgradParams p{};
         fill_wgrad_grid(c, p, 0);
@@ -1295,6 +1378,18 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         p.in_gs = net->n * p.in_ns;                 // the caller's image tensor
         p.dy = c.gbuf(0) + 48 * lv.plane; p.dy_ns = lv.t * lv.plane; p.dy_cs = static_cast<int>(lv.plane); p.dy_w = lv.w; p.cout = kFirst;
         p.dw = grads + tb.first.w;
+        // The F(3x3, 4x4) form prepares the gradient itself (G = d + P x + Q, bias gradient = sum G: WgradParams::prep_x): this is the LAST kernel
+        // of the backward pass, nothing else is on the chip, and prep_dy's own pass over 3 x 48 planes would be 0.1 ms of the step
+        const bool f34 = c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_raw_ok(p, c.net->opt[ENDO_OPT_WINO_MIN_TILES] / 4l);
+        const bool fuse_prep = f34 && c.net->opt[ENDO_OPT_FINAL_VIRTUAL];
+        if (fuse_prep) {
+            p.prep_x = c.act(0) + 48 * lv.plane;
+            p.prep_p = c.pq_p(0) + 48; p.prep_q = c.pq_q(0) + 48;
+            p.prep_bias = grads + tb.first.b;
+        } else {
+            rc = prep_dy(c, 0, 48, kFirst, grads + tb.first.b);
+            if (rc) return rc;
+        }
         Ctx cw;
         rc = c.fork_wgrad(cw, 0);
         if (rc) return rc;
@@ -1302,7 +1397,9 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
             ProfScope prof(kProfWgradOther, cw.stream, conv_flops(net, 0, 3, kFirst, 3), 4.0 * c.nt() * lv.plane * (3 + kFirst));
             // 3 -> 48 channels: in the F(3x3, 4x4) form the four sets of 12 output channels share one launch (the tap-folded kernel runs a
             // 108-row GEMM with 3 of 16 columns in use, four times: 216 us alone on the chip at the very end of the backward)
-            if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_raw_ok(p, c.net->opt[ENDO_OPT_WINO_MIN_TILES] / 4l))
+            if (fuse_prep)
+                rc = launch_wgrad_f34<0, true, true>(p, c.gradws + c.net->wg_scratch_off, cw.stream);
+            else if (f34)
                 rc = launch_wgrad_f34<0, true>(p, c.gradws + c.net->wg_scratch_off, cw.stream);
             else
             rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, cw.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, cw.stream);

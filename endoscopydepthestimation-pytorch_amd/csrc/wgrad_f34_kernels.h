@@ -103,7 +103,8 @@ __device__ __forceinline__ float f34_ld1(__amdgpu_buffer_rsrc_t r, unsigned voff
 // RAW: the convolution reads its input as it is (the network's first convolution: the image, 3 channels, no BatchNorm, no ReLU) and has
 // 12 * plan.groups output channels: a wave's "group" is then a SET OF 12 OUTPUT CHANNELS (its 12 gradient planes), every wave transforms the
 // same (<= 16) input channels
-template <int EXP = 0, bool RAW = false>
+// PREP (with RAW): `dy` is the raw gradient and the kernel prepares it (WgradParams::prep_x): four more 16-byte loads per step, counted in the waits
+template <int EXP = 0, bool RAW = false, bool PREP = false>
 __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradParams p, float* __restrict__ partial, const F34Plan plan) {
     extern __shared__ __attribute__((aligned(16))) float smem[];          // [wave][2 images]: the rows of the next two steps
     const int tid = threadIdx.x;
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 
     float sc = 0.f, sh = 0.f;          // BN + ReLU as relu(sc * x + sh), constants of the current sample group
     int cst_grp = -1;
+    float prep_pc = 0.f, prep_qc = 0.f, prep_sum = 0.f;          // RAW with p.prep_x: G = d + P x + Q formed here; sum G of this lane's tiles
     float keep[2][6];                  // activated image rows 4 ty - 1, 4 ty of the step to come, columns in the order (0, 5, 1, 2, 3, 4)
 
     // BN + ReLU of one row in the column order (0, 5 | 1, 2 | 3, 4): three packed fmas, six max
@@ -186,6 +188,11 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         // group, the rows below the last plane) reads zeros
         const __amdgpu_buffer_rsrc_t xr = f34_rsrc(p.in + sm.in_off(p), p.cin * p.in_cs * 4);
         const __amdgpu_buffer_rsrc_t gr = f34_rsrc(p.dy + sm.dy_off(p) + (RAW ? static_cast<int64_t>(12 * group) * p.dy_cs : 0), 12 * p.dy_cs * 4);
+        const __amdgpu_buffer_rsrc_t pr = f34_rsrc((PREP ? p.prep_x : p.dy) + sm.dy_off(p) + (RAW ? static_cast<int64_t>(12 * group) * p.dy_cs : 0), 12 * p.dy_cs * 4);
+        if (PREP && sm.grp != cst_grp) {
+            prep_pc = li < 12 ? p.prep_p[sm.grp * p.gs + 12 * group + li] : 0.f;
+            prep_qc = li < 12 ? p.prep_q[sm.grp * p.gs + 12 * group + li] : 0.f;
+        }
         if (sm.grp != cst_grp) {
             sc = 0.f; sh = 0.f;
             if constexpr (RAW) {
@@ -226,17 +233,21 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 #pragma unroll 1
         for (int row = row_begin; row < row_end; row += 4) {          // one step: output rows row .. row + 3
             // G tile of the step (zeros for co >= 12)
-            f32x4 gt[4];
+            f32x4 gt[4], xa[4];
             {
                 const unsigned so = 4u * static_cast<unsigned>(row * p.dy_w + 16 * s);
                 const unsigned pitch = 4u * static_cast<unsigned>(p.dy_w);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gt[i] = f34_ld4(gr, g_vo, so + i * pitch);
+                if constexpr (PREP) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xa[i] = f34_ld4(pr, g_vo, so + i * pitch);
+                }
             }
-            // the step's x rows are in LDS once at most the next step's 8 DMAs and the four G loads are in flight
+            // the step's x rows are in LDS once at most the next step's 8 DMAs and the four (PREP: eight) G loads are in flight
             const int img = ((row - row_begin) >> 2) & 1;
-            if (row + 4 < row_end) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (row + 4 < row_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREP ? 16 : 12) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PREP ? 8 : 4) : "memory");
             __builtin_amdgcn_sched_barrier(0);
             float d[6][6];          // [row][column in the order 0, 5, 1, 2, 3, 4]
 #pragma unroll
@@ -266,6 +277,14 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 #pragma unroll
             for (int e = 0; e < 6; ++e) { keep[0][e] = d[4][e]; keep[1][e] = d[5][e]; }
 
+            if constexpr (PREP) {
+                // G = d + P x + Q; a tile right of the image / a lane co >= 12 has read zeros for d and x and must stay zero: no Q there
+                const float pc = g_vo != 0x80000000u ? prep_pc : 0.f, qc = g_vo != 0x80000000u ? prep_qc : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { gt[i][k] += fmaf(pc, xa[i][k], qc); prep_sum += gt[i][k]; }
+            }
             // G: column pass on the column pairs (0, 1), (2, 3) of the tile
             f32x2 va[6], vb[6];
             f34_s(f32x2{gt[0][0], gt[0][1]}, f32x2{gt[1][0], gt[1][1]}, f32x2{gt[2][0], gt[2][1]}, f32x2{gt[3][0], gt[3][1]}, va);
@@ -305,6 +324,14 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         }
     }
 
+    if constexpr (PREP) {
+        if (p.prep_bias) {          // bias gradient: sum G over every tile this wave prepared (each tile of a channel is prepared by exactly one wave)
+            float v = prep_sum;
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lk == 0 && li < 12) atomicAdd(p.prep_bias + 12 * group + li, v);
+        }
+    }
     // output transform with the scales of S folded in: out[a][b] = sum_ij C[a][i] M[i][j] C[b][j]
     const float C[3][6] = {{0.25f, -1.f / 6.f, -1.f / 6.f, 1.f / 24.f, 1.f / 24.f, 0.f},
                            {0.f, -1.f / 6.f, 1.f / 6.f, 1.f / 12.f, -1.f / 12.f, 0.f},
@@ -403,18 +430,19 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34Wave
 }
 
 // blocks: 512 = two per CU (the default), 256 = one per CU (in-job A/B: leaves half of every CU's registers to the other stream's kernels)
-template <int EXP = 0, bool RAW = false>
+template <int EXP = 0, bool RAW = false, bool PREP = false>
 inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream, int blocks = kF34Blocks) {
+    static_assert(!PREP || RAW, "the fused gradient preparation belongs to the first convolution's form");
     const F34Plan plan = wgrad_f34_plan(p, blocks / 2, RAW);
     constexpr int lds = 4 * 2 * kF34Xs * 4;          // 67,584 bytes per block, two blocks per CU
     static bool configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
     int dev = 0;
     (void)hipGetDevice(&dev);
     if (!configured_by_device[dev & 15]) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_f34_kernel<EXP, RAW, PREP>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured_by_device[dev & 15] = true;
     }
-    wgrad_f34_kernel<EXP, RAW><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
+    wgrad_f34_kernel<EXP, RAW, PREP><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
     ENDO_LAUNCH_CHECK();
     wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw, RAW ? 1 : 0);
     ENDO_LAUNCH_CHECK();

@@ -45,6 +45,14 @@ struct WgradParams {
     // dy / dy_idx / saved live gs floats further on and whose activations in_gs floats further on.  dw sums over all groups.
     int group_n;
     int64_t gs, in_gs;
+    // wgrad_f34_kernel<.., RAW> with prep_x set (the network's first convolution, the last kernel of the backward pass): `dy` holds the RAW
+    // gradient d of the convolution's output channels and the kernel forms the prepared gradient G = d + P x + Q itself (x = the channels'
+    // forward values, planes laid out as dy's; P, Q = the channels' deferred BatchNorm-backward terms, per group gs floats apart) and adds
+    // sum G into the bias gradient -- what prep_dy_kernel does in a pass of its own (3 x 48 planes of traffic with nothing else on the chip)
+    const float* prep_x;
+    const float* prep_p;
+    const float* prep_q;
+    float* prep_bias;
 };
 
 constexpr int kMaxGroups = 4;

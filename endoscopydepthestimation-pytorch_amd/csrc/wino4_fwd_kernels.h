@@ -86,7 +86,7 @@ struct Wino4Geom {
     static constexpr int kURounds = (kUUnits + kConvThreads - 1) / kConvThreads;          // 3 (the last one: 64 units)
     static constexpr int kBuf = kKC * kPlane + kKC * kW4UStride;          // floats per stage
     static constexpr int kTail = 4 * 16 * 2;                  // statistics scratch: [4 waves][16][2]
-    static size_t bytes(int bn_cap) { return sizeof(float) * (2 * kBuf + 3 * bn_cap + kTail); }
+    static size_t bytes(int bn_cap) { return sizeof(float) * (2 * kBuf + 4 * bn_cap + kTail); }          // 3 BN tables + the final-conv weights of FIN
 };
 
 // 6 -> 4 output transform A^T m: rows (1 1 1 1 1 0), (0 1 -1 2 -2 0), (0 1 1 4 4 0), (0 1 -1 8 -8 1)
@@ -99,6 +99,10 @@ __device__ __forceinline__ void w4_at(const float m0, const float m1, const floa
 }
 
 // p.wgt = this layer's U (kW4UStride floats per input channel), p.cout <= 16, p.w % 4 == 0, p.h % 4 == 0, p.cin % 4 == 0, 16-byte aligned planes
+// FIN: the launch is the network's LAST dense layer and also forms the final 1x1 convolution's sum over its input channels (ConvParams::fin_w,
+// fin_out): every raw input value passes through a lane's patch exactly once as an interior pixel of its tile, so the 180 of the final
+// convolution's 192 planes this kernel streams anyway are not read a second time (final_fwd_kernel then adds the 12 new maps and the bias).
+template <bool FIN = false>
 __global__ void __launch_bounds__(kConvThreads, 2) wino4_fwd_kernel(const ConvParams p0) {
     using G = Wino4Geom;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -125,7 +129,11 @@ __global__ void __launch_bounds__(kConvThreads, 2) wino4_fwd_kernel(const ConvPa
         s_aux[c] = scale;
         s_aux[cap + c] = mean;
         s_aux[2 * cap + c] = beta;
+        if constexpr (FIN) s_aux[3 * cap + G::kTail + c] = p.fin_w[c];
     }
+    f32x4 fin[4];          // FIN: sum over this lane's channels (4 chunk + lk) of w_final[c] * x_raw[c] at its tile's 4 x 4 pixels
+#pragma unroll
+    for (int r = 0; r < 4; ++r) fin[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     f32x4 acc[36];
 #pragma unroll
@@ -188,10 +196,18 @@ __global__ void __launch_bounds__(kConvThreads, 2) wino4_fwd_kernel(const ConvPa
         const f32x2 sc_m = {sc, sc}, sh_m = {sh, sh};
         const f32x2 sc_e = {l_out ? 0.f : sc, r_out ? 0.f : sc}, sh_e = {l_out ? 0.f : sh, r_out ? 0.f : sh};
         const float* a_base = s_in + lk * G::kPlane + (4 * wave) * G::kCols + 4 * li + 4;
+        float wfin = 0.f;
+        if constexpr (FIN) wfin = s_aux[3 * cap + G::kTail + ch];
         float d[6][6];          // [row][column in the order 0, 5, 1, 2, 3, 4]
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const f32x4 m = *reinterpret_cast<const f32x4*>(a_base + r * G::kCols);
+            if constexpr (FIN) {
+                if (r >= 1 && r <= 4) {          // patch rows 1..4, columns 1..4 = the tile's own pixels (raw values; zeros outside the image)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fin[r - 1][k] = fmaf(wfin, m[k], fin[r - 1][k]);
+                }
+            }
             const float hl = a_base[r * G::kCols - 1], hr = a_base[r * G::kCols + 4];
             const f32x2 e = __builtin_elementwise_fma(f32x2{hl, hr}, sc_e, sh_e);
             const f32x2 a = __builtin_elementwise_fma(f32x2{m[0], m[1]}, sc_m, sh_m);
@@ -252,6 +268,24 @@ __global__ void __launch_bounds__(kConvThreads, 2) wino4_fwd_kernel(const ConvPa
         compute(chunk, b);
     }
 
+    if constexpr (FIN) {
+        // the four channel lanes of a tile (lk) add up; lane lk then stores row lk of the tile's 4 x 4 pixels
+        f32x4 mine = fin[0];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = fin[r][k];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (r == lk) mine[k] = v;
+            }
+        }
+        const int fx = x0 + 4 * li, fy = y0 + 4 * wave + lk;
+        if (fx < p.w && fy < p.h)
+            *reinterpret_cast<f32x4*>(p.fin_out + static_cast<int64_t>(grp) * p0.gs + static_cast<int64_t>(n) * p.h * p.w + static_cast<int64_t>(fy) * p.w + fx) = mine;
+    }
+
     // ---- output transform A^T M A per lane: tiles 4 lk + e (e = 0..3) of the wave's tile row, output channel li ----
     float* s_red = s_aux + 3 * cap;
     const int co = li;
@@ -305,7 +339,8 @@ inline bool wino4_fwd_ok(const ConvParams& p) {
     return wino_fwd_ok(p) && (p.h % 4 == 0) && static_cast<int64_t>(p.cin) * p.in_cs * 4 < (1ll << 31);
 }
 
-inline int launch_wino4_fwd(ConvParams p, hipStream_t stream) {
+template <bool FIN>
+inline int launch_wino4_fwd_t(ConvParams p, hipStream_t stream) {
     using G = Wino4Geom;
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = (p.cin + 15) / 16 * 16;
@@ -316,12 +351,16 @@ inline int launch_wino4_fwd(ConvParams p, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     size_t& configured = configured_by_device[dev & 15];
     if (smem > configured) {
-        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
+        ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_fwd_kernel<FIN>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(smem)));
         configured = smem;
     }
-    wino4_fwd_kernel<<<dim3(p.tiles_x * tiles_y, 1, p.n), kConvThreads, smem, stream>>>(p);
+    wino4_fwd_kernel<FIN><<<dim3(p.tiles_x * tiles_y, 1, p.n), kConvThreads, smem, stream>>>(p);
     ENDO_LAUNCH_CHECK();
     return 0;
+}
+// with p.fin_w / p.fin_out set: the launch also forms the final convolution's sum over its input channels (wino4_fwd_kernel<true>)
+inline int launch_wino4_fwd(const ConvParams& p, hipStream_t stream) {
+    return p.fin_w ? launch_wino4_fwd_t<true>(p, stream) : launch_wino4_fwd_t<false>(p, stream);
 }
 
 }  // namespace endo

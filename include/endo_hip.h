@@ -231,7 +231,11 @@ int endo_net_groups(const endo_net* net);
  *   ENDO_OPT_WGRAD_F34       dense-layer weight gradient where the height is a multiple of 16 and the width of 4 (levels 0-4 at 256 x 320): 1 (default) = in the
  *                            Winograd domain, F(3x3, 4x4) -- 36 multiplications per 4 x 4 tile of the output gradient instead of 144,
  *                            fp32 throughout (csrc/wgrad_f34_kernels.h); 0 = the direct kernels.  Ignored where ENDO_OPT_MFMA_BF16 or
- *                            ENDO_OPT_MFMA_X3 select another operand form for the weight gradients. */
+ *                            ENDO_OPT_MFMA_X3 select another operand form for the weight gradients.
+ *   ENDO_OPT_FINAL_VIRTUAL   1 (default) = the data gradient of the final 1x1 convolution (models.py:167, 186), g(pixel) * w[channel] with
+ *                            g = grad_out * sign(pre), is not written to the 192 level-0 gradient planes: g goes to one plane and the last up
+ *                            block's backward kernels form the product where they first touch a channel (two passes over 1 GB less per
+ *                            step at 16 x 256 x 320); 0 = written out by final_bwd_data_kernel as before.  Same function up to one rounding. */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2
@@ -240,7 +244,8 @@ int endo_net_groups(const endo_net* net);
 #define ENDO_OPT_WGRAD_OVERLAP 5
 #define ENDO_OPT_MFMA_X3 6
 #define ENDO_OPT_WGRAD_F34 7
-#define ENDO_OPT_COUNT 8
+#define ENDO_OPT_FINAL_VIRTUAL 8
+#define ENDO_OPT_COUNT 9
 int endo_net_set_option(endo_net* net, int option_id, int value);
 int endo_net_get_option(const endo_net* net, int option_id);
 int64_t endo_net_group_stride(const endo_net* net);

@@ -289,21 +289,23 @@ def checkpoint_case(ref, n, h, w, seed, path):
     out = {"n": n, "h": h, "w": w, "seed": seed, "base_lr": base_lr, "max_lr": max_lr, "step_size": step_size,
            "epoch": blob["epoch"], "step": blob["step"], "validation": blob["validation"],
            "model_keys": np.array(list(blob["model"].keys()))}
+    # (copies: torch.optim.SGD.load_state_dict below adopts the blob's tensors as its momentum buffers and iteration 3 updates them in place)
     for k, v in blob["model"].items():
-        out["model::" + k] = t2n(v)
+        out["model::" + k] = t2n(v).copy()
     group = blob["optimizer"]["param_groups"][0]
     out["opt_params"] = np.array(group["params"], dtype=np.int64)
     for key in ("lr", "momentum", "dampening", "weight_decay"):
         out["opt_" + key] = np.float64(group[key])
     out["opt_nesterov"] = np.bool_(group["nesterov"])
     for i, entry in blob["optimizer"]["state"].items():
-        out["opt_state::%d" % i] = t2n(entry["momentum_buffer"])
+        out["opt_state::%d" % i] = t2n(entry["momentum_buffer"]).copy()
     # what the reference does with its own file: fresh objects, reload, iteration 3
     net2 = torch.nn.DataParallel(ref["models"].FCDenseNet57(n_classes=1))
     net2.load_state_dict(blob["model"])
     net2.train()
     opt2 = torch.optim.SGD(net2.parameters(), lr=max_lr, momentum=0.9)
-    opt2.load_state_dict(blob["optimizer"])
+    import copy
+    opt2.load_state_dict(copy.deepcopy(blob["optimizer"]))
     sched2 = ref["scheduler"].CyclicLR(opt2, base_lr=base_lr, max_lr=max_lr, step_size=step_size)
     before = [p.detach().clone() for p in net2.parameters()]
     loss, gnorm = _reference_iteration(ref, net2, opt2, sched2, batches[2], 2, h, w)
@@ -645,7 +647,7 @@ def main():
         reader_case(ref, os.path.join(HERE, "reader_example.npz"))
         return
     if "--checkpoint-only" in sys.argv:
-        checkpoint_case(ref, 2, 64, 96, 41, os.path.join(HERE, "checkpoint_2x64x96.npz"))
+        checkpoint_case(ref, 2, 64, 96, 31, os.path.join(HERE, "checkpoint_2x64x96.npz"))          # seed 31: the two iterations of train_step_2x64x96.npz, continued (seed 41 left the random network with a depth crossing zero: fp32 and fp64 losses 30 % apart)
         return
     if "--full-only" in sys.argv:          # the benchmark-size case alone (minutes of CPU, ~25 GB with the fp64 yardstick)
         train_step_full_case(ref, 8, 256, 320, 32, os.path.join(HERE, "train_step_8x256x320.npz"))
@@ -657,7 +659,7 @@ def main():
     network_case(ref, 2, 32, 32, 21, os.path.join(HERE, "network_2x32x32.npz"))
     network_case(ref, 2, 64, 96, 22, os.path.join(HERE, "network_2x64x96.npz"))
     train_step_case(ref, 2, 64, 96, 31, os.path.join(HERE, "train_step_2x64x96.npz"))
-    checkpoint_case(ref, 2, 64, 96, 41, os.path.join(HERE, "checkpoint_2x64x96.npz"))
+    checkpoint_case(ref, 2, 64, 96, 31, os.path.join(HERE, "checkpoint_2x64x96.npz"))          # seed 31: the two iterations of train_step_2x64x96.npz, continued (seed 41 left the random network with a depth crossing zero: fp32 and fp64 losses 30 % apart)
     cyclic_lr_case(ref, os.path.join(HERE, "cyclic_lr.npz"))
     scatter_case(ref, os.path.join(HERE, "scatter_example.npz"))
     point_cloud_case(ref, os.path.join(HERE, "point_cloud.npz"))

