@@ -452,11 +452,11 @@ def test_network_backward_kernel_forms(shape, which):
     n, h, w = shape
     # "x3": the dense weight gradient with its fp32 products as three-term bf16 splits on the bf16 matrix cores (ENDO_OPT_MFMA_X3 bit 0,
     # csrc/wgrad_x3_kernels.h; DESIGN.md 4.15: not the default) -- the SAME function, held to the same fp32 bound
-    # "winograd4": the dense-layer forward in F(4x4, 3x3) form (ENDO_OPT_WINO_FWD = 5, csrc/wino4_fwd_kernels.h) wherever height and width allow.
-    # Its transforms carry factors up to 8: the depth is held to 2e-5 of its maximum (measured 4e-6 .. 6e-6; the other forms 1e-5, measured 1e-6),
-    # the gradients -- taken on the pass's own pattern, from activations that carry the forward's rounding -- to 1.6e-4 (measured 5.8e-5 .. 1.1e-4
-    # with EVERY level in this form, as forced here).  Since round 5 the default at the launches whose 64 x 16 blocks fill the chip (level 0 of
-    # configs[1]): the parity target is 1e-4 on loss / depth, this form sits at 5e-6.
+    # "winograd4": the dense-layer forward in F(4x4, 3x3) form (ENDO_OPT_WINO_FWD = 5, csrc/wino4_fwd_kernels.h; the default form of level 0 since
+    # round 5) forced onto EVERY level whose height and width allow it.  With the interpolation points 0, +-5/8, +-3/2, inf of round 5 the depth
+    # sits at 1.9e-6 .. 2.2e-6 of its maximum (round 4's textbook points: 4e-6 .. 6e-6; the other forms: 0.9e-6 .. 1.1e-6) and is held to the
+    # same 1e-5 as every form; the gradients -- taken on the pass's own pattern, from activations that carry the forward's rounding --
+    # measured 2.0e-5 .. 3.5e-5 (round 4: 5.8e-5 .. 1.1e-4; the other forms 0.7e-5 .. 2.2e-5) and are held to 5e-5 (round 4: 1.6e-4).
     opts = {OPT_WINO_MIN_TILES: 1, OPT_WINO_FWD: 1} if which == "winograd" else {OPT_WINO_MIN_TILES: 1, OPT_WINO_FWD: 5} if which == "winograd4" else ({OPT_MFMA_X3: 1} if which == "x3" else {OPT_WINO_FWD: 0, OPT_WINO_DGRAD: 0, OPT_DGRAD_VEC: 0, OPT_WGRAD_F34: 0})
     with kernel_options(opts):
         state, model = make_model(62)
@@ -471,8 +471,10 @@ def test_network_backward_kernel_forms(shape, which):
     params = dict(model.named_parameters())
     g64p = reference_grads(state, x, cot, torch.float64, pattern)
     y64 = onet.forward(state_as(state, torch.float64), x.double(), training=True, pattern=pattern)
-    assert_close(y, y64, 2e-5 if which == "winograd4" else 1e-5, "depth, %s kernels" % which)
-    assert_grads_on_pattern(params, g64p, None, 1.6e-4 if which == "winograd4" else GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
+    print("%s %s: depth max err / max |depth| = %.2e" % (which, shape, rel_err(y, y64)))
+    assert_close(y, y64, 1e-5, "depth, %s kernels" % which)
+    worst = assert_grads_on_pattern(params, g64p, None, 5e-5 if which == "winograd4" else GRAD_TOL, "network backward %s, %s kernels" % (shape, which))
+    print("%s %s: worst gradient tensor %.2e %s" % (which, shape, worst[0][0], worst[0][2]))
 
 
 def test_network_backward_eval_mode():
@@ -1147,14 +1149,12 @@ def test_pair_backward_on_pattern_512x640():
 @pytest.mark.parametrize("forward_form", ["default", "f23"])
 def test_train_step_full_size_golden(golden, forward_form):
     """forward_form: "default" = the kernel forms bench.py runs (since round 5 the level-0 dense layers' forward in F(4x4, 3x3), ENDO_OPT_WINO_FWD = 5);
-    "f23" = the same with F(2x2, 3x3) there (ENDO_OPT_WINO_FWD = 1), the form every bound below was set on in round 4 -- those bounds are
-    UNCHANGED for it.  The F(4x4, 3x3) forward is 5e-6 instead of 1e-6 from fp64 on the depth (both far inside the 1e-4 of the parity
-    target: the forward checks below are the same for both forms), which flips about five times as many of the 2 G ReLU / max-pool
-    decisions; the gradient of a 16 x 20 or 8 x 10 level moves by 1e-2 of its norm when ONE of its bits flips, so more coarse-level tensors
-    cross that line: measured 8 of 185 (round 4: 8; the reference's own fp32 evaluation: 0, F(2x2, 3x3): 2-4).  For the default form the count
-    bound is 10 instead of 5 -- the ONE bound that differs, printed with the measurement; medians (<= 3x the reference's) and the 5e-2
-    per-tensor bound are the same, and the tight statement about these kernels stays test_full_size_pair_backward_on_pattern (same
-    launches, pattern taken from the pass: 1e-4 on every tensor).
+    "f23" = the same with F(2x2, 3x3) there (ENDO_OPT_WINO_FWD = 1), the form every bound below was set on in round 4.  The bounds are the
+    SAME for both and unchanged from round 4.  (With round 4's textbook interpolation points the F(4x4, 3x3) forward sat 5e-6 from fp64 on the
+    depth, flipped about five times as many ReLU / max-pool decisions and put 8 of the 185 gradient tensors further than 1e-2 from fp64 --
+    over the bound of 5 -- which is why it was not the default then.  With the points 0, +-5/8, +-3/2, inf of round 5 the same run gives:
+    depth 9.6e-7, 0 of 185 tensors beyond 1e-2, medians 8.7e-5 / 1.0e-3 against the reference's own 5.1e-5 / 6.2e-4; the F(2x2, 3x3) form:
+    7.1e-7, 1 of 185, 6.1e-5 / 8.2e-4.)
 
     One training iteration at the size and through the code path bench.py times -- TrainingStep(pair_forward=True):
     16 samples per launch, the 32x16 / split-K / n-split / 8-wave fused-dgrad variants that only these grids select --
@@ -1234,7 +1234,7 @@ def test_train_step_full_size_golden(golden, forward_form):
         check(e_probe <= 5e-2, "grad projection %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_probe, r_probe))
     beyond = [r[1] for r in report if r[0] > 1e-2]
     print("forward form %s: %d of %d tensors further than 1e-2 from fp64" % (forward_form, len(beyond), len(report)))
-    check(len(beyond) <= (5 if forward_form == "f23" else 10), "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:10]))
+    check(len(beyond) <= 5, "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:10]))
     med = [float(np.median([r[k] for r in report])) for k in (2, 3, 4, 5)]
     print("median over %d tensors: norm err hip %.2e / reference %.2e, projection err hip %.2e / reference %.2e" % (len(report), *med))
     check(med[0] <= max(3.0 * med[1], 1e-4), "median gradient-norm distance from fp64: hip %.3e, reference %.3e" % (med[0], med[1]))
