@@ -735,7 +735,7 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
     if (mfma_bf16_fwd(c)) return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 2, 1, 1>(p, c.stream);
-    return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower)
+    return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower; round 5: K-chunks of 16 channels +-0, of 32 +40 % on the family, Q = 6 with 16 +14 %)
 }
 
 // transition up: nearest x2 -> conv3x3 48->48 into channels [0,48) of the finer level (models.py:70-80)

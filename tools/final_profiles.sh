@@ -1,6 +1,6 @@
 # The profile set committed under profiles/ (run on an MI355X box through gpurun): tools/final_profiles.sh <tag>, e.g. r03_f
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -10,6 +10,11 @@ rocprofv3 --kernel-trace --stats -d /tmp/kt -o kt -- python3 $R/bench.py --steps
 python3 $R/tools/summarize_rocprof.py /tmp/kt/kt_results.db $O/${TAG}_kernel_stats.txt "$CMD" 7
 python3 $R/tools/summarize_rocprof.py --by-grid /tmp/kt/kt_results.db $O/${TAG}_kernel_stats_by_grid.txt
 python3 $R/tools/gpu_busy.py /tmp/kt/kt_results.db > $O/${TAG}_gpu_busy.txt 2>&1
+python3 $R/tools/chain_trace.py /tmp/kt/kt_results.db 2 > $O/${TAG}_chain_trace.txt 2>&1
+python3 $R/tools/stream_timeline.py /tmp/kt/kt_results.db > $O/${TAG}_stream_timeline.txt 2>&1
+# the same trace with the weight gradients in line (every kernel alone on the chip): stand-alone kernel times
+rocprofv3 --kernel-trace --stats -d /tmp/kts -o kt -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel-option 5=0 > /dev/null 2> $O/kts.err
+python3 $R/tools/summarize_rocprof.py /tmp/kts/kt_results.db $O/${TAG}_kernel_stats_serial.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel-option 5=0   (ENDO_OPT_WGRAD_OVERLAP = 0: weight gradients in line, every kernel alone on the chip)" 7
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pf -o f -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pf.err
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pw -o w -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $O/pw.err
 python3 $R/tools/pmc_traffic.py /tmp/pf/f_results.db /tmp/pw/w_results.db $O/${TAG}_pmc_traffic.json 7 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline" > $O/pmc_traffic.log 2>&1
