@@ -219,8 +219,8 @@ class StepOutput(object):
         import weakref
         self._host = None
         self._slot = slot
-        if slot is None:          # host tensors (CPU tests of the glue)
-            self._vals = (losses, flag, norm)
+        if slot is None:          # host tensors (CPU tests of the glue): copies -- with world > 1 `flag` is a view of the gradient bucket's trailing slot, which the next step overwrites before a one-step-late read
+            self._vals = (losses.detach().clone(), flag.detach().clone(), norm.detach().clone())
         else:
             slot.losses.copy_(losses, non_blocking=True)
             slot.flag.copy_(flag.reshape(1), non_blocking=True)

@@ -235,7 +235,11 @@ int endo_net_groups(const endo_net* net);
  *   ENDO_OPT_FINAL_VIRTUAL   1 (default) = the data gradient of the final 1x1 convolution (models.py:167, 186), g(pixel) * w[channel] with
  *                            g = grad_out * sign(pre), is not written to the 192 level-0 gradient planes: g goes to one plane and the last up
  *                            block's backward kernels form the product where they first touch a channel (two passes over 1 GB less per
- *                            step at 16 x 256 x 320); 0 = written out by final_bwd_data_kernel as before.  Same function up to one rounding. */
+ *                            step at 16 x 256 x 320); the forward sum of that convolution over the 180 input channels of the network's last dense
+ *                            layer is formed by that layer's F(4x4,3x3) launch (final_fwd_kernel reads 12 planes instead of 192), and the first
+ *                            convolution's gradient preparation (G = d + P x + Q, bias gradient) is folded into its weight-gradient kernel;
+ *                            0 = the separate kernels (final_bwd_data_kernel, the full final_fwd_kernel, prep_dy) as before.  Same function up
+ *                            to summation order. */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2

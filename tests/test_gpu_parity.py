@@ -516,7 +516,7 @@ BF16_GRAD_TOL = 1e-1      # ... and every parameter gradient, max error / the te
                           # bottleneck and first up block, whose BN normalises over 2 x (2 x 3) ... 2 x (16 x 20) values)
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 96)])          # (a development mode, bench.py --config 5: the BASELINE workloads are the fp32 and the 16-bit-STORAGE paths)
+@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 128, 160)])          # (a development mode, bench.py --config 5; the second shape has the >= 2048 row chunks at level 0 that select the n-split weight-gradient kernel's bf16 branch, which bench.py --config 5 runs)
 def test_bf16_operand_mode_on_pattern(shape):
     """ENDO_OPT_MFMA_BF16 = 1 (the mixed-precision mode behind bench.py --config 5): the dense layers' forward, data-gradient and
     weight-gradient kernels round their MFMA operands to bf16 and accumulate in fp32; tensors in memory, BN statistics, the
