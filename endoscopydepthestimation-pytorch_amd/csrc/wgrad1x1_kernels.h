@@ -65,44 +65,79 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
 #pragma unroll
         for (int b = 0; b < 3; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // per-lane parts of the DMA sources
+    // ---- DMA sources through buffer descriptors (round 5) ----
+    // A DMA instruction's address is descriptor base (the sample's planes) + a per-lane byte offset that never changes + ONE scalar byte
+    // offset (chunk position + channel plane), advanced by a constant per instruction: one scalar add per DMA instead of the 64-bit
+    // multiply-add, range compare and pad-pointer select of the pointer form -- its scalar instructions were 18 % of the wave's issue time.
+    // Channels past cin / cout lie past the descriptor's range and read zeros (the BN constants of such rows are zero too, load_consts),
+    // a pixel right of the image gets a per-lane offset past the range: zeros on the gradient side, which is what makes its product vanish.
     const int arow = lane >> 5, ax = lane & 31;
-    const bool dy_is_code = lane >= 16;
-    const int dcol = dy_is_code ? 4 * (lane - 16) : lane;              // pooled column inside the segment
-    const int64_t dstride = dy_is_code ? static_cast<int64_t>(p.dy_cs) : 4 * static_cast<int64_t>(p.dy_cs);   // bytes per channel
-    const char* pad_nan = reinterpret_cast<const char*>(g_pad_consts);
-    const char* pad_zero = reinterpret_cast<const char*>(g_pad_consts + 4);
+    const unsigned kOob = 0x80000000u;
+    const unsigned x_lane = 4u * static_cast<unsigned>(arow * p.in_w + ax);
+    const bool is_dy = lane < kP1Seg / 2, is_code = lane >= kP1Seg / 2 && lane < kP1Seg / 2 + kP1Seg / 8;
+    const int dcol = is_dy ? lane : 4 * (lane - kP1Seg / 2);              // pooled column inside the segment
+    const unsigned d_lane = is_dy ? 4u * static_cast<unsigned>(lane) : 4u * static_cast<unsigned>(lane - kP1Seg / 2);
+    const unsigned x_cs = 4u * static_cast<unsigned>(p.in_cs), dy_csb = 4u * static_cast<unsigned>(p.dy_cs), code_csb = static_cast<unsigned>(p.dy_cs);
+    const unsigned x_ch0 = static_cast<unsigned>(ci_base + wave * (kP1Tile / 4)) * x_cs;
+    const unsigned dy_ch0 = static_cast<unsigned>(co_base + wave * (kP1Tile / 4)) * dy_csb;
+    const unsigned code_ch0 = static_cast<unsigned>(co_base + wave * (kP1Tile / 4)) * code_csb;
 
-    auto issue = [&](int chunk, int buf) {
-        const int n = chunk / chunks_per_sample;
-        const int rem = chunk - n * chunks_per_sample;
-        const int y2 = rem / segs;
-        const int xs = (rem - y2 * segs) * kP1Seg;
+    // the chunk walk (sample, pooled row, segment) advances by gridDim.x chunks per iteration: carried digit by digit, no division in the loop
+    const int rows2 = p.h >> 1;
+    int c_n, c_y2, c_seg;
+    {
+        const int c0 = blockIdx.x;
+        c_n = c0 / chunks_per_sample;
+        const int rem = c0 - c_n * chunks_per_sample;
+        c_y2 = rem / segs;
+        c_seg = rem - c_y2 * segs;
+    }
+    const int st = static_cast<int>(gridDim.x);
+    const int st_n = st / chunks_per_sample, st_rem = st - st_n * chunks_per_sample;
+    const int st_y2 = st_rem / segs, st_seg = st_rem - st_y2 * segs;
+    auto advance = [&]() {
+        c_seg += st_seg; c_y2 += st_y2; c_n += st_n;
+        if (c_seg >= segs) { c_seg -= segs; ++c_y2; }
+        if (c_y2 >= rows2) { c_y2 -= rows2; ++c_n; }
+    };
+
+    // issue the DMAs of the chunk the walk stands on into buffer `buf`
+    auto issue = [&](int buf) {
+        const int n = c_n, y2 = c_y2, xs = c_seg * kP1Seg;
         const WgSample sm(p, n);
         float* s_act = smem + buf * kP1Buf;
         float* s_dy = s_act + kP1Tile * kP1ActStride;
-        const bool a_ok = xs + ax < p.w;
-        const float* abase = p.in + sm.in_off(p) + static_cast<int64_t>(2 * y2 + arow) * p.in_w + xs + ax;
-#pragma unroll 4
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + sm.in_off(p)), 0, p.cin * p.in_cs * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t gr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy + sm.dy_off(p)), 0, p.cout * p.dy_cs * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t cr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.dy_idx + sm.idx_off(p)), 0, p.cout * p.dy_cs, 0x00020000);
+        const unsigned x_vo = xs + ax < p.w ? x_lane : kOob;
+        unsigned so = x_ch0 + 4u * static_cast<unsigned>(2 * y2 * p.in_w + xs);
+#pragma unroll
         for (int t = 0; t < kP1Tile / 4; ++t) {
             const int r = wave * (kP1Tile / 4) + t;
-            const int ch = ci_base + r;
-            const void* src = (a_ok && ch < p.cin) ? static_cast<const void*>(abase + static_cast<int64_t>(ch) * p.in_cs)
-                                                   : static_cast<const void*>(pad_nan);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_act + r * kP1ActStride), 4, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(s_act + r * kP1ActStride), 4, x_vo, so, 0, 0);
+            so += x_cs;
         }
         const int pxs = xs >> 1;
-        const bool d_ok = pxs + dcol < (p.w >> 1);
-        const int64_t poff = static_cast<int64_t>(y2) * p.dy_w + pxs + dcol;
-        const char* dbase = dy_is_code ? reinterpret_cast<const char*>(p.dy_idx + sm.idx_off(p) + poff)
-                                       : reinterpret_cast<const char*>(p.dy + sm.dy_off(p) + poff);
-#pragma unroll 4
-        for (int t = 0; t < kP1Tile / 4; ++t) {
-            const int r = wave * (kP1Tile / 4) + t;
-            const int co = co_base + r;
-            const char* src = (d_ok && co < p.cout) ? dbase + co * dstride : pad_zero;
-            if (lane < kP1Seg / 2 + kP1Seg / 8)
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_dy + r * kP1DyStride), 4, 0, 0);
+        const unsigned d_vo = pxs + dcol < (p.w >> 1) ? d_lane : kOob;
+        const unsigned ppos = static_cast<unsigned>(y2 * p.dy_w + pxs);
+        if (is_dy) {          // lanes 0 .. 15: the pooled gradient row segment
+            unsigned sg = dy_ch0 + 4u * ppos;
+#pragma unroll
+            for (int t = 0; t < kP1Tile / 4; ++t) {
+                const int r = wave * (kP1Tile / 4) + t;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(gr, (lptr_t)(s_dy + r * kP1DyStride), 4, d_vo, sg, 0, 0);
+                sg += dy_csb;
+            }
+        }
+        if (is_code) {        // lanes 16 .. 19: its argmax codes, four pooled pixels per dword; they land behind the 16 gradient dwords
+            unsigned sc2 = code_ch0 + ppos;
+#pragma unroll
+            for (int t = 0; t < kP1Tile / 4; ++t) {
+                const int r = wave * (kP1Tile / 4) + t;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(cr, (lptr_t)(s_dy + r * kP1DyStride), 4, d_vo, sc2, 0, 0);
+                sc2 += code_csb;
+            }
         }
     };
 
@@ -162,13 +197,14 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
     };
 
     int chunk = blockIdx.x;
-    if (chunk < chunks_total) issue(chunk, 0);
+    if (chunk < chunks_total) issue(0);
     int b = 0;
     for (; chunk < chunks_total; chunk += gridDim.x, b ^= 1) {
+        const int g = WgSample(p, c_n).grp;          // the group of the chunk about to be computed (the walk still stands on it)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (chunk + static_cast<int>(gridDim.x) < chunks_total) issue(chunk + gridDim.x, b ^ 1);
-        const int g = WgSample(p, chunk / chunks_per_sample).grp;
+        advance();
+        if (chunk + static_cast<int>(gridDim.x) < chunks_total) issue(b ^ 1);
         if (g != cur_grp) load_consts(g);
         compute(b);
     }
