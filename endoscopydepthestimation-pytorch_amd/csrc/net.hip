@@ -673,6 +673,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
             }
 #endif
             if (big) return launch_wino_fwd<2, 4, 2, 2>(pw, c.stream);
+            // (round 5, in-job A/B of the level-1 launch: K-chunks of 8 channels, 3 or 4 LDS stages, 4 blocks per CU -- all within +-0.2 % of this form)
             if (small) return launch_wino_fwd<1, 4, 3, 2>(pw, c.stream);
         }
     }
