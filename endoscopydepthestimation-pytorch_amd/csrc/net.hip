@@ -816,7 +816,8 @@ static void fill_wgrad_grid(const Ctx& c, WgradParams& p, int level) {
     p.tiles_y = (lv.h + kWgTileY - 1) / kWgTileY;
 }
 
-static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv) {
+// batch / slice: the F(3x3, 4x4) form leaves its partial sums in scratch slice `slice` and its reduction to the caller's batched launch
+static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv, F34ReduceBatch* batch = nullptr, int slice = 0) {
     const auto& lv = c.net->lv[level];
     WgradParams p{};
     fill_wgrad_grid(c, p, level);
@@ -826,7 +827,8 @@ static int dense_wgrad(const Ctx& c, int level, int ic0, int oc0, const BnP& b, 
     p.dw = c.grads + cv.w;
     ProfScope prof(kProfWgradDense, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3), 4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     if (c.net->opt[ENDO_OPT_WGRAD_F34] && wgrad_mfma_mode(c) == 0 && wgrad_f34_ok(p, c.net->opt[ENDO_OPT_WINO_MIN_TILES] / 4l))          // from 256 tiles of 4 x 4 pixels: levels 0-4 of configs[1] (level 5 is 8 x 10)
-        return launch_wgrad_f34(p, c.gradws + c.net->wg_scratch_off, c.stream, c.net->opt[ENDO_OPT_WGRAD_F34] == 2 ? 256 : kF34Blocks);          // Winograd F(3x3, 4x4)
+        return launch_wgrad_f34(p, c.gradws + c.net->wg_scratch_off + (batch ? slice : 0) * kF34ScratchFloats, c.stream,
+                                c.net->opt[ENDO_OPT_WGRAD_F34] == 2 ? 256 : kF34Blocks, batch);          // Winograd F(3x3, 4x4)
     if (wgrad_nsplit_ok(p)) {
         if (wgrad_mfma_mode(c) == 2) return launch_wgrad_x3(p, c.gradws + c.net->wg_scratch_off, c.stream);          // fp32 products as bf16 splits (wgrad_x3_kernels.h)
         return launch_wgrad_nsplit(p, c.gradws + c.net->wg_scratch_off, c.stream, wgrad_mfma_mode(c));
@@ -907,6 +909,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
     };
     BnFin4 pending{};          // BN layers whose sums over the next prepared maps the last new-channel pass produced (folded into prep_dy)
     int pending_nl = 0;
+    F34ReduceBatch red{};      // the block's F(3x3, 4x4) weight gradients reduce their partial sums in ONE launch behind the last of them
     for (int j = kLayers - 1; j >= 0; --j) {
         // (with fv: layer 3's maps have no gradient in the buffer yet -- prep_dy is their first writer; the maps of layers 2..0 were
         // written, from the virtual content, by the new-channel passes below)
@@ -922,7 +925,12 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             rc = c.fork_wgrad(cw, level);
             if (rc) return rc;
             for (int jj = defer ? kLayers - 1 : j; jj >= j; --jj) {
-                rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * jj, bn[jj], cv[jj]);
+                rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * jj, bn[jj], cv[jj], &red, jj);
+                if (rc) return rc;
+            }
+            if (j == 0) {          // (the side stream runs its launches in order: all four are ahead of this one)
+                ProfScope prof(kProfWgradDense, cw.stream, 0.0, 0.0);
+                rc = launch_wgrad_f34_reduce_batch(red, cw.stream);
                 if (rc) return rc;
             }
         }
@@ -1157,7 +1165,7 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->slot_stride = align_up(tb.bn_width_total * 2, 32);
     net->scratch_bytes = net->slot_stride * 8 * kBnSlots;
     net->wg_scratch_off = (net->scratch_off + align_up(net->scratch_bytes, 256)) / 4;
-    net->tuw_scratch_off = net->wg_scratch_off + std::max(std::max(kNsScratchFloats, kSpScratchFloats), kF34ScratchFloats);
+    net->tuw_scratch_off = net->wg_scratch_off + std::max(std::max(kNsScratchFloats, kSpScratchFloats), 4 * kF34ScratchFloats);          // four slices: the layers of a dense block reduce in one launch
     net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
     net->gplane_off = align_up(net->wd_off + tb.wino_dgrad_floats, 64);
     net->gradws_floats = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);

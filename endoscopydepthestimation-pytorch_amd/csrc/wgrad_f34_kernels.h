@@ -389,6 +389,46 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
     if (co < 12 && ci < cin) atomicAdd(dw + (static_cast<int64_t>(co + (raw ? 12 * group : 0)) * cin + ci) * 9 + tap, total);
 }
 
+// The same for up to four launches at once (the four layers of a dense block, each with its own scratch slice): grid (max groups * 9, slices, layers).
+// One launch instead of four 6-15 us ones whose time is mostly ramp-up and drain.
+struct F34ReduceBatch {
+    const float* partial[4];
+    float* dw[4];
+    int slots[4];
+    int cin[4];
+    int groups[4];
+    int count;
+};
+__global__ void __launch_bounds__(256) wgrad_f34_reduce_batch_kernel(const F34ReduceBatch a) {
+    __shared__ f32x4 s_part[4][64];
+    const int l = blockIdx.z;
+    const int gm = blockIdx.x;
+    if (gm >= a.groups[l] * 9) return;          // (block-uniform)
+    const int slots = a.slots[l], cin = a.cin[l];
+    const int group = gm / 9, tap = gm - group * 9;
+    const int per = (slots + gridDim.y - 1) / gridDim.y;
+    const int b0 = blockIdx.y * per, b1 = min(slots, b0 + per);
+    if (b0 >= b1) return;
+    const int q = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.partial[l] + (static_cast<int64_t>(gm) * slots) * 256) + q;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+    int b = b0 + sub;
+    for (; b + 4 < b1; b += 8) {
+        s0 += src[static_cast<int64_t>(b) * 64];
+        s1 += src[static_cast<int64_t>(b + 4) * 64];
+    }
+    if (b < b1) s0 += src[static_cast<int64_t>(b) * 64];
+    s_part[sub][q] = s0 + s1;
+    __syncthreads();
+    const int e = threadIdx.x;
+    const float* sp = reinterpret_cast<const float*>(s_part);
+    const float total = (sp[e] + sp[256 + e]) + (sp[512 + e] + sp[768 + e]);
+    const int lane = e & 63, r = e >> 6;
+    const int co = 4 * (lane >> 4) + r;
+    const int ci = 16 * group + (lane & 15);
+    if (co < 12 && ci < cin) atomicAdd(a.dw[l] + (static_cast<int64_t>(co) * cin + ci) * 9 + tap, total);
+}
+
 constexpr int kF34Blocks = 512;                      // two blocks of four waves per CU
 constexpr int kF34MinTiles = 256;            // 4 x 4 tiles per launch from which the kernel is chosen (a quad of 16 x 16 pixels = 16 tiles)
 // scratch: groups * 9 rows of `slots` x 256 floats, groups * slots <= 8 * 256 waves
@@ -430,8 +470,10 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34Wave
 }
 
 // blocks: 512 = two per CU (the default), 256 = one per CU (in-job A/B: leaves half of every CU's registers to the other stream's kernels)
+// batch: the launch leaves its partial sums in `scratch` and records what their reduction needs instead of reducing them
+// (launch_wgrad_f34_reduce_batch later, on the same stream; every launch of a batch needs its own scratch slice)
 template <int EXP = 0, bool RAW = false, bool PREP = false>
-inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream, int blocks = kF34Blocks) {
+inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t stream, int blocks = kF34Blocks, F34ReduceBatch* batch = nullptr) {
     static_assert(!PREP || RAW, "the fused gradient preparation belongs to the first convolution's form");
     const F34Plan plan = wgrad_f34_plan(p, blocks / 2, RAW);
     constexpr int lds = 4 * 2 * kF34Xs * 4;          // 67,584 bytes per block, two blocks per CU
@@ -444,8 +486,23 @@ inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t st
     }
     wgrad_f34_kernel<EXP, RAW, PREP><<<blocks, kConvThreads, lds, stream>>>(p, scratch, plan);
     ENDO_LAUNCH_CHECK();
+    if (batch && !RAW && batch->count < 4) {
+        const int k = batch->count++;
+        batch->partial[k] = scratch; batch->dw[k] = p.dw; batch->slots[k] = plan.slots; batch->cin[k] = p.cin; batch->groups[k] = plan.groups;
+        return 0;
+    }
     wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw, RAW ? 1 : 0);
     ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
+inline int launch_wgrad_f34_reduce_batch(F34ReduceBatch& batch, hipStream_t stream) {
+    if (batch.count == 0) return 0;
+    int gmax = 0;
+    for (int k = 0; k < batch.count; ++k) gmax = std::max(gmax, batch.groups[k]);
+    wgrad_f34_reduce_batch_kernel<<<dim3(gmax * 9, 8, batch.count), 256, 0, stream>>>(batch);
+    ENDO_LAUNCH_CHECK();
+    batch.count = 0;
     return 0;
 }
 
