@@ -48,7 +48,7 @@ def classify(name):
     if not CONV_LIKE.search(base):
         return None
     if base in ("wgrad_nsplit_kernel", "wgrad_nsplit_reduce_kernel", "wgrad_wino_kernel", "wgrad_wino_reduce_kernel", "wgrad_wino_finish_kernel",
-                "wgrad_f34_kernel", "wgrad_f34_reduce_kernel", "wgrad_x3_kernel"):
+                "wgrad_f34_kernel", "wgrad_f34_reduce_kernel", "wgrad_f34_reduce_batch_kernel", "wgrad_x3_kernel"):
         return "wgrad_dense"
     if base == "wgrad_taps_kernel":                       # <COUT, IN_MODE, BF>: IN_MODE 1 = BN + ReLU input (dense layer), 0 = raw (first conv), 2 = x2 gather (transition up)
         return "wgrad_dense" if a[1] == "1" else "other"
