@@ -974,6 +974,43 @@ def test_checkpoint_resume_matches_reference(golden):
     assert np.median(err_without) >= 0.2, "the check is not sensitive to the momentum (median %.3e without it)" % np.median(err_without)
 
 
+OPT_FINAL_VIRTUAL = 8
+
+
+@pytest.mark.parametrize("forced", [False, True], ids=["default-forms", "winograd-forms"])
+def test_final_conv_fusions_are_transparent(forced):
+    """ENDO_OPT_FINAL_VIRTUAL (round 5, default on): the final 1x1 convolution's forward sum over the last dense layer's 180 input channels is
+    formed by that layer's F(4x4,3x3) launch, its rank-one data gradient g * w[c] by the last up block's kernels (never written to the 192
+    level-0 planes), and the first convolution's prep_dy is folded into its weight-gradient kernel.  With the option off the separate kernels
+    run (final_fwd_kernel over 192 planes, final_bwd_data_kernel, prep_dy).  Same function: depth to 2e-6, all 210 gradients to 2e-5 of each
+    tensor's maximum, one grouped pair pass each.  "winograd-forms" forces the Winograd kernels on at this size (the forms the benchmark-size
+    launches take: the fused forward and the virtual BASE channels need them); "default-forms" leaves the new-map passes and prep_dy virtual
+    and the base channels materialised."""
+    n, h, w = 2, 64, 96
+    rng = np.random.default_rng(23)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    results = []
+    for virtual in (1, 0):
+        with kernel_options({OPT_WINO_MIN_TILES: 1} if forced else {}):
+            _, model = make_model(66)
+        model.set_kernel_option(OPT_FINAL_VIRTUAL, virtual)
+        model.train()
+        y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+        ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+        torch.cuda.synchronize()
+        results.append((y1.detach().clone(), y2.detach().clone(), {nm: p.grad.detach().clone() for nm, p in model.named_parameters()}))
+    (a1, a2, ga), (b1, b2, gb) = results
+    assert_close(a1, b1, 2e-6, "depth of frame 1, fused vs separate final convolution")
+    assert_close(a2, b2, 2e-6, "depth of frame 2, fused vs separate final convolution")
+    worst = 0.0
+    for nm in ga:
+        scale = max(float(gb[nm].abs().max()), 1e-3 * max(float(v.abs().max()) for v in gb.values()))
+        worst = max(worst, float((ga[nm] - gb[nm]).abs().max()) / scale)
+        assert float((ga[nm] - gb[nm]).abs().max()) <= 2e-5 * scale, "gradient of %s differs between the fused and the separate final-convolution kernels" % nm
+    print("final-conv fusions on vs off (%s): worst gradient difference %.2e" % ("winograd forms" if forced else "default forms", worst))
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])
 def test_wgrad_overlap_is_transparent(shape):
     """endo_net_bwd runs the weight gradients on a side stream, overlapped with the data-gradient chain.
