@@ -54,7 +54,7 @@ struct DgradWino3Geom {
 
 // p.w % 32 == 0, p.h % 8 == 0, p.count % 16 == 0, 32 <= p.count <= 192; u[l]: the layer's transformed weights (layout 1), group-major.
 // EXP: diagnostic bit mask for tools/wino_bench (0 in the library; timing only): 1 = no x / gradient loads, 2 = no stores,
-// 4 = no BN-sum atomics, 32 = no MFMAs
+// 4 = no BN-sum atomics, 8 = no dY tile load, 32 = no MFMAs
 // OPT (in-job A/B, tools/wino_bench; 0 in the library): 16 = weight DMA issued at the END of the V phases with a counted wait (M phases
 // then carry no memory instruction), 32 = s_setprio 1 around the MFMAs of an M phase.  Both measured neutral to slightly slower.
 template <int NL, int EXP = 0, int OPT = 0>
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3_kernel(const DgradBlockPar
         }
         const float* g_n = p.g + grp_off + n * p.g_ns;
         const int e0 = wave * 64;
-        if (e0 < G::kPlane) {
+        if (e0 < G::kPlane && !(EXP & 8)) {
             for (int c = 0; c < NL * 12; ++c) {
                 const float* src = ok ? g_n + static_cast<int64_t>(c) * p.g_cs + goff : g_pad_consts + 4;
                 if (e0 + lane < G::kPlane) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(s_g + c * G::kCS + e0), 4, 0, 0);

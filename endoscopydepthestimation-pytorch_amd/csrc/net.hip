@@ -19,6 +19,7 @@
 
 #include "dgrad_kernels.h"
 #include "dgrad_block_kernels.h"
+#include "dgrad_newmap_kernels.h"
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
@@ -607,7 +608,8 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //                            with 3 / 4 stages, 5 (default) = F(4x4, 3x3) for the launches that fill the chip with 64 x 16 blocks, F(2x2, 3x3) for the rest
 //   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
 //                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h)
-//   ENDO_OPT_DGRAD_VEC       new-channel passes: 16-byte (1) or dword (0) DMA of the gradient tiles
+//   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 (default) = persistent blocks (dgrad_newmap_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
+//                            DMA of the gradient tiles (dgrad_block_kernels.h)
 //   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
 //   ENDO_OPT_WINO_MIN_TILES  a Winograd kernel is used from this many tiles per launch on (default 1024: the levels whose launches fill
 //                            the chip several times; tests set 1 to reach the kernels at small sizes)
@@ -618,7 +620,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
     opt[ENDO_OPT_WINO_DGRAD] = 1;
-    opt[ENDO_OPT_DGRAD_VEC] = 1;
+    opt[ENDO_OPT_DGRAD_VEC] = 2;
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
     opt[ENDO_OPT_MFMA_BF16] = 0;
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
@@ -987,6 +989,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                 if (mfma_bf16_dgrad(c) && dgrad_block_vec_ok(p))
                     rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4, 1>(p, c.stream)
                        : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4, 1>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4, 1>(p, c.stream);
+                else if (dgrad_block_vec_ok(p) && c.net->opt[ENDO_OPT_DGRAD_VEC] >= 2 && dgrad_newmap_ok(p))
+                    rc = nl == 1 ? launch_dgrad_newmap<1>(p, c.stream) : nl == 2 ? launch_dgrad_newmap<2>(p, c.stream) : launch_dgrad_newmap<3>(p, c.stream);
                 else if (dgrad_block_vec_ok(p) && dgrad_vec_enabled(c))
                     rc = nl == 1 ? launch_dgrad_block<1, 2, 3, 1, 0, 1, 4>(p, c.stream)
                        : nl == 2 ? launch_dgrad_block<2, 2, 3, 1, 0, 1, 4>(p, c.stream) : launch_dgrad_block<3, 2, 3, 1, 0, 1, 4>(p, c.stream);

@@ -214,7 +214,8 @@ int endo_net_groups(const endo_net* net);
  *                            1e-4 of the parity target
  *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd with phase-skewed workers (default),
  *                            2 Winograd, the round-2 kernel
- *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 1 = 16-byte DMA of the gradient tiles (default), 0 = dword
+ *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 2 (default) = persistent blocks that walk a run of tiles (csrc/dgrad_newmap_kernels.h),
+ *                            1 = one block per tile with 16-byte DMA of the gradient tiles, 0 = the same with dword DMA
  *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024)
  *   ENDO_OPT_MFMA_BF16       NOT the same function: 1 = the dense layers' convolution kernels round their MFMA operands to bf16
  *                            (v_mfma_f32_16x16x16_bf16; fp32 accumulation, fp32 tensors in memory) -- the mixed-precision mode of

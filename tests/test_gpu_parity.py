@@ -1011,6 +1011,40 @@ def test_final_conv_fusions_are_transparent(forced):
     print("final-conv fusions on vs off (%s): worst gradient difference %.2e" % ("winograd forms" if forced else "default forms", worst))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (2, 96, 160), (3, 128, 160)], ids=lambda v: "x".join(str(i) for i in v))
+def test_persistent_new_map_passes_match_the_per_tile_blocks(shape):
+    """ENDO_OPT_DGRAD_VEC = 2 (round 5, default): the new-map passes of a dense block's backward run as persistent blocks that walk a run
+    of 32 x 6 tiles (csrc/dgrad_newmap_kernels.h) instead of one block per tile (= 1, csrc/dgrad_block_kernels.h).  Same MFMA order per
+    pixel, so the data gradients agree to the last bits; the BN-backward sums are added up in another order (fp32 per lane over the run,
+    fp64 across blocks).  Bound: 1e-5 of each tensor's maximum, with a floor of 1e-2 of the largest gradient for the tensors whose true
+    gradient is ZERO (the bias of a convolution that only BatchNorms read: what any kernel form returns there is the rounding residue of
+    sums of O(1e3) terms -- 2e-5 absolute here -- and it changes with every summation order; two runs of ONE form differ by 5e-6 there).
+    Shapes: 64 x 96 has a bottom rim at level 0 (64 = 10 * 6 + 4) and a right rim at level 1 (48 = 32 + 16); 96 x 160 tiles level 0 exactly and
+    has right rims at levels 1 and 2 (80, 40); 3 x 128 x 160 has runs that cross the samples of a group.  The last up block's passes
+    form the final convolution's virtual gradient (ENDO_OPT_FINAL_VIRTUAL) in both forms."""
+    n, h, w = shape
+    rng = np.random.default_rng(29)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    results = []
+    for form in (2, 1):
+        _, model = make_model(67)
+        model.set_kernel_option(OPT_DGRAD_VEC, form)
+        model.train()
+        y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+        ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+        torch.cuda.synchronize()
+        results.append({nm: p.grad.detach().clone() for nm, p in model.named_parameters()})
+    ga, gb = results
+    worst = 0.0
+    for nm in ga:
+        assert torch.isfinite(ga[nm]).all(), nm
+        scale = max(float(gb[nm].abs().max()), 1e-2 * max(float(v.abs().max()) for v in gb.values()))
+        worst = max(worst, float((ga[nm] - gb[nm]).abs().max()) / scale)
+        assert float((ga[nm] - gb[nm]).abs().max()) <= 1e-5 * scale, "gradient of %s differs between the persistent and the per-tile new-map passes" % nm
+    print("persistent vs per-tile new-map passes %s: worst gradient difference %.2e of the tensor's maximum" % (shape, worst))
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])
 def test_wgrad_overlap_is_transparent(shape):
     """endo_net_bwd runs the weight gradients on a side stream, overlapped with the data-gradient chain.

@@ -123,6 +123,9 @@ int main(int argc, char** argv) {
     vs.push_back({"dgrad_wino3<4> (library)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 0>(p, u1, s); }});
     vs.push_back({"dgrad_wino3<4> OPT16 (weight DMA at V end)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 16>(p, u1, s); }});
     vs.push_back({"dgrad_wino3<4> OPT32 (setprio 1 in M phases)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 32>(p, u1, s); }});
+    vs.push_back({"wino3 no dY tile load (8)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 8, 0>(p, u1, s); }});
+    vs.push_back({"wino3 no atomics (4)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 4, 0>(p, u1, s); }});
+    vs.push_back({"wino3 no tile load, no atomics (12)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 12, 0>(p, u1, s); }});
     vs.push_back({"wino3 no mem (7)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 7, 0>(p, u1, s); }});
     vs.push_back({"wino3 no mem, no V arithmetic (71)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 71, 0>(p, u1, s); }});
     vs.push_back({"wino3 no mem, no M phase (135)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 135, 0>(p, u1, s); }});
