@@ -167,6 +167,8 @@ struct endo_net {
     int64_t tuw_scratch_off;  // float offset in gradws of the transition-up data-gradient weights (tu_subpix_dgrad_weights_kernel)
     int64_t wd_off;           // float offset in gradws of the Winograd-domain data-gradient weights (group 0's copy serves all groups)
     int64_t gplane_off;       // float offset in gradws of g = grad_out * sign(pre), one plane per sample (final_g_kernel)
+    int64_t bias_parts_off;   // float offset in gradws (group 0's) of prep_dy's per-block sums of G (BiasParts), bias_parts_floats long
+    int64_t bias_parts_floats;
     int64_t gradws_floats;
     // Weight gradients run on a side stream: a layer's wgrad depends only on its prepared dY and the forward tape, nothing on the
     // backward chain depends on it (it only adds into the flat gradient), so it overlaps the data-gradient chain -- which at the
@@ -183,6 +185,22 @@ namespace endo {
 // ---------------------------------------------------------------------------------------------
 // small kernels
 // ---------------------------------------------------------------------------------------------
+
+// Conv-bias gradients (sum of the prepared G over pixels and samples, train.py's loss.backward() through models.py's convolutions): prep_dy's blocks
+// used to add their sums to bias_grad[c] with one float atomic each -- 3 840 atomics of a level-0 launch on the ONE cache line that holds a
+// layer's 12 bias gradients, served one after the other at ~8 ns: 31 of the launch's 57 us (tools/prep_bench: 24.7 us without them, the rate of a
+// plain read-2-write-1 pass).  Now a block stores its sum (plain store, its own slot) and ONE launch at the end of the backward pass adds up
+// the slots of every prep_dy launch in a fixed order (bias_reduce_kernel): no serialised atomics, and the same bits in every run.
+constexpr int kBiasPartChannels = 2048;          // channels prepared per backward pass: 1 776 at FC-DenseNet57 (all conv outputs but the final one)
+constexpr int kBiasPartLaunches = 64;
+struct BiasReduceTable {
+    int n;
+    struct Entry { const float* parts; float* bias; int count; int nparts; } e[kBiasPartLaunches];
+};
+struct BiasParts {          // owned by endo_net_bwd's frame, filled by prep_dy
+    BiasReduceTable table;
+    int64_t used;           // floats of the region handed out
+};
 
 // per BN layer (up to four): its backward sums, saved statistics, parameters and parameter gradients, offset to the first
 // channel of the range a launch works on
@@ -206,7 +224,7 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
                                                       const float* __restrict__ pq_p, const float* __restrict__ pq_q,
                                                       float* bias_grad, int group_n, int64_t gs, const BnFin4 fin, int nl,
                                                       double count, int training, int64_t slot_stride,
-                                                      const float* __restrict__ vg, const float* __restrict__ vw) {
+                                                      const float* __restrict__ vg, const float* __restrict__ vw, float* __restrict__ parts) {
     __shared__ double scratch[4];
     const int c = blockIdx.y;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;      // grouped batch: per-group buffers, shared bias gradient
@@ -286,7 +304,25 @@ __global__ void __launch_bounds__(256) prep_dy_kernel(float* __restrict__ dbuf, 
     double v = wave_sum(static_cast<double>(part));
     if (lane == 0) scratch[wave] = v;
     __syncthreads();
-    if (threadIdx.x == 0 && bias_grad) atomicAdd(bias_grad + c, static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]));
+    if (threadIdx.x == 0 && bias_grad) {
+        const float t = static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]);
+        // parts: [channel][sample of all groups][block]: added up by bias_reduce_kernel at the end of the backward pass (BiasParts)
+        if (parts) parts[(static_cast<int64_t>(c) * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = t;
+        else atomicAdd(bias_grad + c, t);
+    }
+}
+
+// bias[c] += sum of prep_dy's per-block sums, one wave per (launch, channel), fixed order
+__global__ void __launch_bounds__(256) bias_reduce_kernel(const BiasReduceTable tb) {
+    const BiasReduceTable::Entry& e = tb.e[blockIdx.x];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = blockIdx.y * 4 + wave; c < e.count; c += gridDim.y * 4) {
+        const float* src = e.parts + static_cast<int64_t>(c) * e.nparts;
+        double t = 0.0;
+        for (int i = lane; i < e.nparts; i += 64) t += static_cast<double>(src[i]);
+        t = wave_sum(t);
+        if (lane == 0) e.bias[c] += static_cast<float>(t);
+    }
 }
 
 // BN parameter gradients from the dgrad epilogue's sums, and the deferred dx terms:
@@ -537,6 +573,7 @@ struct Ctx {
     float* gradws;
     int training;
     hipStream_t stream;
+    BiasParts* bias_parts = nullptr;
 
     int nt() const { return net->n * net->groups; }      // samples of all groups
     // context of the weight-gradient side stream, ordered after everything issued so far on the main stream
@@ -808,12 +845,22 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad,
     BnFin4 none{};
     int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
     bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
+    float* parts = nullptr;
+    if (bias_grad && c.bias_parts) {          // (no room: the kernel falls back to its atomics)
+        BiasParts& bp = *c.bias_parts;
+        const int64_t need = static_cast<int64_t>(count) * c.nt() * bx;
+        if (bp.table.n < kBiasPartLaunches && bp.used + need <= c.net->bias_parts_floats) {
+            parts = c.gradws + c.net->bias_parts_off + bp.used;
+            bp.table.e[bp.table.n++] = {parts, bias_grad, count, c.nt() * bx};
+            bp.used += need;
+        }
+    }
     ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.nt() * lv.plane * count);
     prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
                                                                      lv.t * lv.plane, static_cast<int>(lv.plane), c.pq_p(level) + c0,
                                                                      c.pq_q(level) + c0, bias_grad, c.net->n, c.net->gs, fin ? *fin : none, fin ? nl : 0,
                                                                      static_cast<double>(c.net->n) * lv.h * lv.w, c.training, c.net->slot_stride,
-                                                                     fv ? fv->vg : nullptr, fv ? fv->vw + c0 : nullptr);
+                                                                     fv ? fv->vg : nullptr, fv ? fv->vw + c0 : nullptr, parts);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -1195,7 +1242,9 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->tuw_scratch_off = net->wg_scratch_off + std::max(std::max(kNsScratchFloats, kSpScratchFloats), 4 * kF34ScratchFloats);          // four slices: the layers of a dense block reduce in one launch
     net->wd_off = align_up(net->tuw_scratch_off + 4 * kNew * (4 * kNew + 16), 64);
     net->gplane_off = align_up(net->wd_off + tb.wino_dgrad_floats, 64);
-    net->gradws_floats = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);
+    net->bias_parts_off = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);
+    net->bias_parts_floats = static_cast<int64_t>(kBiasPartChannels) * n * groups * 32;
+    net->gradws_floats = net->bias_parts_off + align_up(net->bias_parts_floats, 64);
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
@@ -1330,6 +1379,8 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     if (!net || !params || !x || !tape || !grad_out || !grads || !gradws) return ENDO_E_BADARG;
     const Table& tb = table();
     Ctx c{net, params, nullptr, const_cast<float*>(tape), grads, gradws, training, static_cast<hipStream_t>(stream_)};
+    BiasParts bias_parts{};
+    c.bias_parts = &bias_parts;
     if (!net->wstream) {          // side stream of the weight gradients (see endo_net), created on first use on the caller's device
         ENDO_CHECK(hipStreamCreateWithFlags(&net->wstream, hipStreamNonBlocking));
         ENDO_CHECK(hipEventCreateWithFlags(&net->ev_fork, hipEventDisableTiming));
@@ -1443,6 +1494,11 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
             rc = wgrad_taps_ok(p) ? launch_wgrad_taps<12, IN_PLAIN>(p, cw.stream) : launch_wgrad<3, 3, IN_PLAIN, DY_PLAIN>(p, cw.stream);
             if (rc) return rc;
         }
+    }
+    if (bias_parts.table.n > 0) {          // the conv-bias gradients from prep_dy's per-block sums (BiasParts): one launch for the whole pass
+        ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * bias_parts.used);
+        bias_reduce_kernel<<<dim3(bias_parts.table.n, 8), 256, 0, c.stream>>>(bias_parts.table);
+        ENDO_LAUNCH_CHECK();
     }
     if (net->wstream) {          // join: the caller's stream continues only after every weight gradient has landed
         ENDO_CHECK(hipEventRecord(net->ev_join, net->wstream));

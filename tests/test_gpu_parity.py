@@ -1016,7 +1016,8 @@ def test_persistent_new_map_passes_match_the_per_tile_blocks(shape):
     """ENDO_OPT_DGRAD_VEC = 2 (round 5, default): the new-map passes of a dense block's backward run as persistent blocks that walk a run
     of 32 x 6 tiles (csrc/dgrad_newmap_kernels.h) instead of one block per tile (= 1, csrc/dgrad_block_kernels.h).  Same MFMA order per
     pixel, so the data gradients agree to the last bits; the BN-backward sums are added up in another order (fp32 per lane over the run,
-    fp64 across blocks).  Bound: 1e-5 of each tensor's maximum, with a floor of 1e-2 of the largest gradient for the tensors whose true
+    fp64 across blocks; sum of dz (x - mean) scaled by rstd once per tile instead of per term).  Bound: 5e-5 of each tensor's maximum (BatchNorm
+    weight gradients are such sums with cancellation: 1.4e-5 measured), with a floor of 1e-2 of the largest gradient for the tensors whose true
     gradient is ZERO (the bias of a convolution that only BatchNorms read: what any kernel form returns there is the rounding residue of
     sums of O(1e3) terms -- 2e-5 absolute here -- and it changes with every summation order; two runs of ONE form differ by 5e-6 there).
     Shapes: 64 x 96 has a bottom rim at level 0 (64 = 10 * 6 + 4) and a right rim at level 1 (48 = 32 + 16); 96 x 160 tiles level 0 exactly and
@@ -1036,12 +1037,15 @@ def test_persistent_new_map_passes_match_the_per_tile_blocks(shape):
         torch.cuda.synchronize()
         results.append({nm: p.grad.detach().clone() for nm, p in model.named_parameters()})
     ga, gb = results
-    worst = 0.0
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    rows = []
     for nm in ga:
         assert torch.isfinite(ga[nm]).all(), nm
-        scale = max(float(gb[nm].abs().max()), 1e-2 * max(float(v.abs().max()) for v in gb.values()))
-        worst = max(worst, float((ga[nm] - gb[nm]).abs().max()) / scale)
-        assert float((ga[nm] - gb[nm]).abs().max()) <= 1e-5 * scale, "gradient of %s differs between the persistent and the per-tile new-map passes" % nm
+        scale = max(float(gb[nm].abs().max()), 1e-2 * gmax)
+        rows.append((float((ga[nm] - gb[nm]).abs().max()) / scale, nm, float(gb[nm].abs().max())))
+    rows.sort(reverse=True)
+    worst = rows[0][0]
+    assert worst <= 5e-5, "gradients differ between the persistent and the per-tile new-map passes: " + "; ".join("%s %.2e (max %.2e)" % (nm, d, mx) for d, nm, mx in rows[:6])
     print("persistent vs per-tile new-map passes %s: worst gradient difference %.2e of the tensor's maximum" % (shape, worst))
 
 
