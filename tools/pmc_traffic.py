@@ -54,7 +54,7 @@ def classify(name):
         return "wgrad_dense" if a[1] == "1" else "other"
     if base == "wgrad_mfma_kernel":                       # <KS, IN_MODE, ...>: the register-staged fallback
         return "wgrad_dense" if a[0] == "3" and a[1] == "1" else "other"
-    if base in ("dgrad_block_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_dense_kernel"):
+    if base in ("dgrad_block_kernel", "dgrad_newmap_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_dense_kernel"):
         return "dgrad_dense"
     if base in ("wino_fwd_kernel", "wino4_fwd_kernel", "finalize_partial_kernel"):
         return "conv3x3_dense_fwd"
