@@ -109,6 +109,13 @@ int main(int argc, char** argv) {
         vs.push_back({"fwd dma4 KC4 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 4, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC8 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC16 2buf 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd KC16 16x8 only first chunk DMA'd (EXP 1)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0, 1>(f, s); }});
+        vs.push_back({"fwd KC16 16x8 no BN transform (EXP 2)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0, 2>(f, s); }});
+        vs.push_back({"fwd KC16 16x8 DMA not waited (EXP 4)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0, 4>(f, s); }});
+        vs.push_back({"fwd KC16 16x8 neither (EXP 3)", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0, 3>(f, s); }});
+        vs.push_back({"fwd dma4 KC16 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC8 2buf 16x4", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 1, 2, 1, 4, 0>(f, s); }});
+        vs.push_back({"fwd dma4 KC16 2buf 16x4", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 1, 2, 1, 4, 0>(f, s); }});
         bench(vs, f.out, (size_t)12 * plane, flops);      // compares sample 0's 12 planes
     }
 
