@@ -266,6 +266,22 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                     __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 4 * (u0 + lane)), (lptr_t)(s_w + 4 * u0), 16, 0, 0);
             }
         }
+        constexpr bool kChunked = KS == 3 && KC == 16 && Q == 1 && EPI == EPI_FWD && PH < 0 && IN != IN_SUBPIX && BF == 0;
+        bool gather = !(PH >= 0 || IN == IN_SUBPIX);
+        if constexpr (kChunked) {
+            if (p.wgt_chunks) {          // (block-uniform) the chunk's slice is one contiguous run in LDS order: 16-byte units, no index arithmetic
+                gather = false;
+                constexpr int kUnitsW = kWElems / 4;
+                const float* wsrc = p.wgt_chunks + static_cast<int64_t>(chunk) * kWElems;
+#pragma unroll
+                for (int k = 0; k < (kUnitsW + kConvThreads - 1) / kConvThreads; ++k) {
+                    const int u0 = k * kConvThreads + wave * 64;
+                    if (u0 < kUnitsW && u0 + lane < kUnitsW)
+                        __builtin_amdgcn_global_load_lds((gptr_t)(wsrc + 4 * (u0 + lane)), (lptr_t)(s_w + 4 * u0), 16, 0, 0);
+                }
+            }
+        }
+        if (gather)
 #pragma unroll
         for (int k = 0; k < ((PH >= 0 || IN == IN_SUBPIX) ? 0 : kWPre); ++k) {
             const int e0 = k * kConvThreads + wave * 64;

@@ -63,6 +63,10 @@ struct ConvParams {
     const float* wgt;
     const float* bias;
     int w_cout, w_cin;
+    // the same weights already in the K-chunk pipeline's LDS order, [chunk of 16 input channels][tap 9][channel 16][cout 16], zeros where a
+    // channel or an output does not exist (dense_fwd_weights: wino_fwd_kernels.h, mode 1): one contiguous 9 KB run per chunk instead of
+    // 2 304 four-byte gathers.  Only the KS = 3, KC = 16, Q = 1 forward instantiation of conv_dma_kernel looks at it; nullptr = gather from wgt
+    const float* wgt_chunks;
     // ---- output ----
     float* out;
     int64_t out_ns;

@@ -681,6 +681,25 @@ static bool mfma_bf16_dgrad(const Ctx& c) { return (mfma_bf16_mask(c) & 4) != 0;
 // dense layer forward: BN -> ReLU -> conv3x3 -> +12 channels (reference models.py:19-28, 44-52)
 // fin_w / fin_pre / fused_final: the network's last dense layer may also form the final convolution's sum over its input channels
 // (ConvParams::fin_w); *fused_final says whether the kernel form that ran did
+// The tile-count part of dense_fwd's choice of a Winograd form at a level (the kernels' own shape checks can still send a layer to the direct
+// kernel).  Where neither holds the level's dense layers run the direct kernel, and the forward pass prepares their weights in the K-chunk
+// pipeline's order instead of the Winograd domain (WinoWeightTable::mode 1, ConvParams::wgt_chunks).
+static bool dense_fwd_wino4_tiles(const Ctx& c, int level) {
+    const auto& lv = c.net->lv[level];
+    const long t4 = static_cast<long>((lv.w + 63) / 64) * ((lv.h + 15) / 16) * c.nt();
+    return wino_fwd_mode(c) == 5 && !mfma_bf16_fwd(c) && 2 * t4 >= c.net->opt[ENDO_OPT_WINO_MIN_TILES];
+}
+static bool dense_fwd_wino2_tiles(const Ctx& c, int level) {
+    const auto& lv = c.net->lv[level];
+    const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
+    const long t8 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 7) / 8) * c.nt();
+    const long min_tiles = c.net->opt[ENDO_OPT_WINO_MIN_TILES];
+    return wino_fwd_enabled(c) && !mfma_bf16_fwd(c) && (t16 >= min_tiles || t8 >= (min_tiles * 3) / 4);
+}
+static bool dense_fwd_chunk_weights(const Ctx& c, int level) {
+    return !mfma_bf16_fwd(c) && !dense_fwd_wino4_tiles(c, level) && !dense_fwd_wino2_tiles(c, level);
+}
+
 static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, const ConvP& cv, const float* fin_w = nullptr, float* fin_pre = nullptr,
                      bool* fused_final = nullptr) {
     const auto& lv = c.net->lv[level];
@@ -695,16 +714,15 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
                    4.0 * c.nt() * lv.plane * (cv.cin + cv.cout));
     // Fine levels: Winograd F(2x2, 3x3) on the matrix cores -- 4/9 of the multiply-accumulates (wino_fwd_kernels.h).
     // 32 x 16 pixel tiles while they fill the chip several times over, 32 x 8 below that.
-    if (wino_fwd_mode(c) == 5 && cv.u >= 0 && !mfma_bf16_fwd(c)) {          // F(4x4, 3x3): 36 instead of 64 products per 16 pixels (wino4_fwd_kernels.h)
+    if (cv.u >= 0 && dense_fwd_wino4_tiles(c, level)) {          // F(4x4, 3x3): 36 instead of 64 products per 16 pixels (wino4_fwd_kernels.h)
         ConvParams p4 = p;
         p4.wgt = c.tape + c.net->wino4_off + cv.u / kWinoUStride * kW4UStride;
-        const long t4 = static_cast<long>((lv.w + 63) / 64) * ((lv.h + 15) / 16) * c.nt();
-        if (wino4_fwd_ok(p4) && 2 * t4 >= c.net->opt[ENDO_OPT_WINO_MIN_TILES]) {          // (level 0 of configs[1]: at level 1 the 64 x 16 blocks no longer fill the chip, measured slower)
+        if (wino4_fwd_ok(p4)) {          // (level 0 of configs[1]: at level 1 the 64 x 16 blocks no longer fill the chip, measured slower)
             if (fin_w && fused_final && c.net->opt[ENDO_OPT_FINAL_VIRTUAL]) { p4.fin_w = fin_w + ic0; p4.fin_out = fin_pre; *fused_final = true; }
             return launch_wino4_fwd(p4, c.stream);
         }
     }
-    if (wino_fwd_enabled(c) && cv.u >= 0 && !mfma_bf16_fwd(c)) {
+    if (cv.u >= 0 && dense_fwd_wino2_tiles(c, level)) {
         ConvParams pw = p;
         pw.wgt = c.tape + c.net->wino_off + cv.u;          // group 0's tape: weights are shared by the groups
         const long t16 = static_cast<long>((lv.w + 31) / 32) * ((lv.h + 15) / 16) * c.nt();
@@ -746,6 +764,8 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     const long tiles_mid = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 15) / 16) * c.nt();
     const long tiles_small = static_cast<long>((lv.w + 15) / 16) * ((lv.h + 7) / 8) * c.nt();
     const int nchunks = (cv.cin + 15) / 16;
+    // both launches below that run on K-chunks of 16 channels take the chunk-ordered copy of the weights the pass prepared for this level
+    const float* chunk_weights = (cv.u >= 0 && dense_fwd_chunk_weights(c, level)) ? c.tape + c.net->wino_off + cv.u : nullptr;
     if (tiles_big < 512 && tiles_mid < 384 && tiles_small < 512 && nchunks >= 4) {
         int want = static_cast<int>(((tiles_small < 256 ? 512 : 768) + tiles_small - 1) / tiles_small);
         if (want > nchunks) want = nchunks;
@@ -756,6 +776,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
         p.split_stride = static_cast<int64_t>(c.net->n) * cv.cout * lv.plane;      // inside one group's tape
         p.out = partial; p.out_ns = static_cast<int64_t>(cv.cout) * lv.plane;
         p.bias = nullptr; p.out_sums = nullptr;
+        p.wgt_chunks = chunk_weights;
         int rc = mfma_bf16_fwd(c) ? launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream)
                              : launch_conv_dma<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
         if (rc) return rc;
@@ -779,6 +800,7 @@ static int dense_fwd(const Ctx& c, int level, int ic0, int oc0, const BnP& b, co
     }
     if (tiles_big < 1024 && tiles_wide >= 1024) return launch_conv_dma<3, 4, 1, IN_BNRELU, EPI_FWD, 2, 4, 2, 1>(p, c.stream);
     if (tiles_big < 1024 && tiles_small >= 768) return launch_conv_dma<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1>(p, c.stream);
+    p.wgt_chunks = chunk_weights;          // (only the KC = 16 instantiation the auto choice ends in for few tiles reads it)
     return launch_conv_dma_auto<3, 4, 1, IN_BNRELU, EPI_FWD, 8, 2, 1>(p, c.stream);
 }
 
@@ -1314,9 +1336,14 @@ extern "C" int endo_net_fwd(endo_net* net, const float* params, float* bn_runnin
     Ctx c{net, params, bn_running, tape, nullptr, nullptr, training, static_cast<hipStream_t>(stream_)};
     for (int g = 0; g < net->groups; ++g)
         ENDO_CHECK(hipMemsetAsync(reinterpret_cast<char*>(tape + g * net->gs) + net->sums_off, 0, net->sums_bytes, c.stream));
-    if (wino_fwd_enabled(c) && !mfma_bf16_fwd(c)) {          // dense-layer weights in Winograd form, all 44 layers in one launch
+    if (!mfma_bf16_fwd(c)) {          // dense-layer weights in Winograd form or in the direct kernel's chunk order, all 44 layers in one launch
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * (tb.wino_floats + tb.wino_floats * 9 / 16));
-        wino_fwd_weights_kernel<<<(tb.wino.start[tb.wino.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino, params, tape + net->wino_off);
+        WinoWeightTable wt = tb.wino;          // per pass: which layers want their weights in the direct kernel's chunk order (table order: down, bottleneck, up)
+        for (int l = 0; l < wt.layers; ++l) {
+            const int level = l < kLevels * kLayers ? l / kLayers : (l < (kLevels + 1) * kLayers ? kLevels : kLevels - 1 - (l - (kLevels + 1) * kLayers) / kLayers);
+            wt.mode[l] = dense_fwd_chunk_weights(c, level) ? 1 : 0;
+        }
+        wino_fwd_weights_kernel<<<(wt.start[wt.layers] + 255) / 256, 256, 0, c.stream>>>(wt, params, tape + net->wino_off);
         ENDO_LAUNCH_CHECK();
         if (wino_fwd_mode(c) == 5) wino4_fwd_weights_kernel<<<(tb.wino4.start[tb.wino4.layers] + 255) / 256, 256, 0, c.stream>>>(tb.wino4, params, tape + net->wino4_off);
         ENDO_LAUNCH_CHECK();

@@ -34,7 +34,12 @@ struct WinoWeightTable {
     int cout[kWinoMaxLayers];
     int64_t w_off[kWinoMaxLayers];          // floats from the parameter base
     int64_t u_off[kWinoMaxLayers];          // floats from the U base
+    // 0 = U as above; 1 = the layer runs the direct kernel on K-chunks of 16 channels this pass: its slot holds the ORIGINAL weights in that
+    // pipeline's LDS order instead, [chunk][tap 9][channel 16][cout 16] with zeros for missing channels / outputs (ConvParams::wgt_chunks;
+    // 144 floats per input channel fit the slot's 272)
+    int mode[kWinoMaxLayers];
 };
+constexpr int kDenseChunkFloats = 9 * 16 * 16;
 
 __global__ void __launch_bounds__(256) wino_fwd_weights_kernel(const WinoWeightTable t, const float* __restrict__ params, float* __restrict__ u) {
     const int total = t.start[t.layers];
@@ -54,6 +59,16 @@ __global__ void __launch_bounds__(256) wino_fwd_weights_kernel(const WinoWeightT
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) g[a][b] = src[a * 3 + b];
+        }
+        if (t.mode[l] == 1) {          // the direct kernel's chunk order (the last channel's thread also zeroes the channels that pad the last chunk)
+            float* dst = u + t.u_off[l] + static_cast<int64_t>(ci >> 4) * kDenseChunkFloats + (ci & 15) * 16 + j;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) dst[tap * 256] = g[tap / 3][tap % 3];
+            if (ci == t.cin[l] - 1)
+                for (int cz = (ci & 15) + 1; cz < 16; ++cz)
+#pragma unroll
+                    for (int tap = 0; tap < 9; ++tap) dst[tap * 256 + (cz - (ci & 15)) * 16] = 0.f;
+            continue;
         }
         float h[4][3];          // G g
 #pragma unroll
