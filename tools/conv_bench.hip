@@ -165,5 +165,41 @@ int main(int argc, char** argv) {
         vs.push_back({"wgrad nsplit<3> no loads, no barrier", [&](hipStream_t s) { zero(s); return launch_wgrad_nsplit_ng<3, 7>(g, wscratch, passes, s); }});
         bench(vs, dw, (size_t)12 * cin * 9, flops);
     }
+    // ---------------- transition down, forward: BN + ReLU -> conv1x1 C -> C -> 2x2 max-pool (+ argmax codes); cin of the command line = C ----------------
+    {
+        const int C = cin;
+        const int64_t pplane = plane / 4;
+        float* tin = dev_random((size_t)n * C * plane, -1.f, 1.f, 11);
+        float* tout; CK(hipMalloc(&tout, (size_t)n * C * pplane * sizeof(float)));
+        uint8_t* tidx; CK(hipMalloc(&tidx, (size_t)n * C * pplane));
+        float* twgt = dev_random((size_t)C * C, -0.1f, 0.1f, 12);
+        float* tbias = dev_random(C, -0.1f, 0.1f, 13);
+        double* tsums; CK(hipMalloc(&tsums, 2 * C * sizeof(double)));
+        { std::vector<double> hsm(2 * C); for (int c = 0; c < C; ++c) { hsm[2 * c] = 0.01 * (c % 5) * cnt; hsm[2 * c + 1] = (1.0 / 3.0 + 1e-4 * (c % 5) * (c % 5)) * cnt; }
+          CK(hipMemcpy(tsums, hsm.data(), hsm.size() * sizeof(double), hipMemcpyHostToDevice)); }
+        double* tosums; CK(hipMalloc(&tosums, 2 * C * sizeof(double))); CK(hipMemset(tosums, 0, 2 * C * sizeof(double)));
+        float* tg = dev_random(C, 0.8f, 1.2f, 14); float* tb = dev_random(C, -0.1f, 0.1f, 15);
+        ConvParams q{};
+        q.n = n; q.h = h; q.w = w;
+        q.in = tin; q.in_ns = C * plane; q.in_cs = (int)plane; q.in_w = w; q.cin = C;
+        q.in_sums = tsums; q.gamma = tg; q.beta = tb; q.running_mean = rm; q.running_var = rv; q.saved = nullptr;
+        q.count = cnt; q.eps = 1e-5f; q.momentum = 0.f; q.training = 1;
+        q.wgt = twgt; q.bias = tbias; q.w_cout = C; q.w_cin = C;
+        q.out = tout; q.out_ns = C * pplane; q.out_cs = (int)pplane; q.out_w = w / 2; q.cout = C; q.out_sums = tosums;
+        q.out_idx = tidx; q.idx_ns = C * pplane;
+        printf("transition down forward: N=%d %dx%d C=%d\n", n, h, w, C);
+        std::vector<Variant> vs;
+        vs.push_back({"td fwd KC8 Q3 32x8 (library)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd only first chunk DMA'd (EXP 1)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0, 1>(q, s); }});
+        vs.push_back({"td fwd no BN transform (EXP 2)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0, 2>(q, s); }});
+        vs.push_back({"td fwd DMA not waited (EXP 4)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0, 4>(q, s); }});
+        vs.push_back({"td fwd neither (EXP 3)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0, 3>(q, s); }});
+        vs.push_back({"td fwd KC16 Q3 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<1, 16, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q3 32x8, 2 blocks per SIMD wave bound (MINW 2)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 2, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q3 32x4 (R 2)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 2, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q3 64x4 (WX 4)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 4, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q2 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 2, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0>(q, s); }});
+        bench(vs, tout, (size_t)C * pplane, 2.0 * n * plane * C * C);
+    }
     return 0;
 }
