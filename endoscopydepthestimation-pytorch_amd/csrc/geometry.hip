@@ -628,6 +628,10 @@ __global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __rest
 // Same arithmetic per term as the kernels above; the three contributions of a gradient element arrive by fp32 atomics in any order
 // (the composed path added them in a fixed order: differences at fp32 rounding, test bound 1e-6).
 // ------------------------------------------------------------------------------------------
+// One cache line per (direction, sample) for the forward kernel's four sums: its 2 560 blocks add them with one 32-byte atomic each, and
+// atomics on one line are served one after the other (~8 ns) -- packed 4 doubles apart, four samples shared a line.
+constexpr int kStatStride = 16;          // doubles
+
 struct ConsistencyArgs {
     const float* depth[2];           // [0] frame 1, [1] frame 2
     const float* t[2];               // [0] 1-wrt-2, [1] 2-wrt-1
@@ -637,7 +641,7 @@ struct ConsistencyArgs {
     float* warped[2];                // direction z: depth[1 - z] warped into frame z
     float* inter[2];
     float* grad[2];                  // d loss / d depth[z]
-    double* stats;                   // [2][n][4]  sum m a, sum m, sum m |P - Pw|_1, sum m (a + |b|)   (zeroed by the caller)
+    double* stats;                   // [2][n][kStatStride], the first 4: sum m a, sum m, sum m |P - Pw|_1, sum m (a + |b|)   (zeroed by the caller)
     float* coef;                     // [2][n][2]  (d loss / d numerator, d loss / d denominator) of sample n in direction z
     float* loss;
     float c_dcl;                     // dcl_weight * 0.5
@@ -741,7 +745,7 @@ __global__ void __launch_bounds__(256) consistency_fwd_kernel(const ConsistencyA
         part[2] += mi * fabsf(ax * av - ax * b) + mi * fabsf(ay * av - ay * b) + mi * fabsf(av - b);
         part[3] += mi * (av + fabsf(b));
     }
-    block_sum_atomic<4>(part, a.stats + 4 * (z * a.n + n), scratch);
+    block_sum_atomic<4>(part, a.stats + kStatStride * (z * a.n + n), scratch);
 }
 
 // loss and the backward pass's per-sample coefficients from the 2 x n x 4 sums.  A kernel of its own, one wave: the "last block of the
@@ -751,7 +755,7 @@ __global__ void consistency_finalize_kernel(const ConsistencyArgs a) {
     // lane i < 2 n owns (direction, sample) i: its term and coefficients; a wave reduction adds the terms (n <= 32; larger batches loop)
     float term = 0.f;
     for (int i = threadIdx.x; i < 2 * a.n; i += 64) {
-        const double* st = a.stats + 4 * i;
+        const double* st = a.stats + kStatStride * i;
         const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
         const float mean_value = s0 / (1.0e-5f + s1);                  // norm_dist_den (losses.hip) with the module's eps
         const float den = 1.0e-5f * mean_value + s3;
@@ -785,7 +789,7 @@ __global__ void __launch_bounds__(256) consistency_bwd_kernel(const ConsistencyA
     // that kernel and block (0, 0, 0) writes the loss here)
     float cnum, cden;
     {
-        const double* st = a.stats + 4 * (z * a.n + n);
+        const double* st = a.stats + kStatStride * (z * a.n + n);
         const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
         const float den = 1.0e-5f * (s0 / (1.0e-5f + s1)) + s3;
         const float g = a.c_dcl / static_cast<float>(a.n);
@@ -795,7 +799,7 @@ __global__ void __launch_bounds__(256) consistency_bwd_kernel(const ConsistencyA
     if (a.loss_in_bwd && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < 64) {
         float term = 0.f;
         for (int i = threadIdx.x; i < 2 * a.n; i += 64) {
-            const double* st = a.stats + 4 * i;
+            const double* st = a.stats + kStatStride * i;
             const float s0 = static_cast<float>(st[0]), s1 = static_cast<float>(st[1]), s2 = static_cast<float>(st[2]), s3 = static_cast<float>(st[3]);
             term += 2.0f * s2 / (1.0e-5f * (s0 / (1.0e-5f + s1)) + s3);
         }
@@ -1060,7 +1064,7 @@ extern "C" int endo_mask_mul(const float* a, const float* mask, float* out, int 
 extern "C" int64_t endo_warp_consistency_workspace_floats(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return -1;
     const int64_t p = static_cast<int64_t>(n) * h * w;
-    return 4 * (p + 3) + 32 * n + 64;
+    return 4 * (p + 3) + (4 * kStatStride + 16) * n + 64;
 }
 
 // phase 1: memset + forward kernel (loss, coefficients, and -- zero_grads -- cleared gradients); phase 2: backward kernel (atomic adds
@@ -1080,7 +1084,7 @@ int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2
     a.warped[0] = take(p); a.warped[1] = take(p);
     a.inter[0] = take(p); a.inter[1] = take(p);
     a.grad[0] = grad_depth_1; a.grad[1] = grad_depth_2;
-    float* zeroed = take(2 * 2 * 4 * n);          // the sums (doubles), zeroed per call; the coefficients are written by the finalize kernel
+    float* zeroed = take(2 * 2 * kStatStride * n);          // the sums (doubles), zeroed per call; the coefficients are written by the finalize kernel
     a.stats = reinterpret_cast<double*>(zeroed);
     a.coef = take(4 * n);
     a.loss = loss;
@@ -1094,7 +1098,7 @@ int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2
     const int tiles_y = (h + TY - 1) / TY;
     const dim3 grid(a.tiles_x * tiles_y, n, 2);
     if (phase == 1) {
-        ENDO_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * (2 * 2 * 4 * n), stream));
+        ENDO_CHECK(hipMemsetAsync(zeroed, 0, sizeof(float) * (2 * 2 * kStatStride * n), stream));
         consistency_fwd_kernel<TY, TX><<<grid, 256, 0, stream>>>(a);
         if (!a.loss_in_bwd) consistency_finalize_kernel<<<1, 64, 0, stream>>>(a);          // the loss head reads the loss between the phases
     } else {

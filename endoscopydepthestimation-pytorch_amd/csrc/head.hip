@@ -55,7 +55,7 @@ using namespace endo;
 extern "C" int64_t endo_loss_head_workspace_floats(int n, int h, int w) {
     if (n <= 0 || h <= 0 || w <= 0) return -1;
     const int64_t p = static_cast<int64_t>(n) * h * w;
-    return 34 * p + 64 * n + 256;
+    return 34 * p + 128 * n + 256;
 }
 
 extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const float* boundaries, const float* sparse_depths_1,
@@ -79,7 +79,7 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     float* flow_1 = take(2 * p);    float* flow_2 = take(2 * p);          // raw, then masked in place
     float* msf_1 = take(2 * p);     float* msf_2 = take(2 * p);           // sparse flows * boundary
     float* msm_1 = take(p);         float* msm_2 = take(p);               // sparse flow masks * boundary
-    float* cons_ws = take(4 * (p + 3) + 32 * n + 64);                     // endo_consistency_phase's own carving (warped, intersect, sums)
+    float* cons_ws = take(endo_warp_consistency_workspace_floats(n, h, w));          // endo_consistency_phase's own carving (warped, intersect, sums)
     float* g_flow_1 = take(2 * p);  float* g_flow_2 = take(2 * p);        // d / d masked flow, then masked in place = d / d raw flow
     float* g_s1 = take(p);          float* g_s2 = take(p);                // d loss / d scaled depth: the flow terms, then += the consistency terms
     double* dstats = reinterpret_cast<double*>(take(2 * (2 * 8 * n + 2 * n + 2 * 2 * n + 2 * 4 * n)));
