@@ -175,14 +175,14 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize_kernel(const double* __r
                                                                const float* __restrict__ gamma, float* __restrict__ ggamma, float* __restrict__ gbeta,
                                                                float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum, int first,
                                                                int cnt, int rot, int rot_n, double count, int training, int64_t gs_sums, int64_t gs_saved,
-                                                               int64_t gs_pq, const float* __restrict__ gscale) {
+                                                               int64_t gs_pq, const float* __restrict__ gscale, int64_t slot_stride) {
     const double inv = gscale ? gscale[1] : 1.0;          // the parameter gradients leave without the gradient scale
     // blockIdx.y = sample group: its own sums, statistics and deferred terms; the parameter gradients add up over the groups
     sums += blockIdx.y * gs_sums; saved += blockIdx.y * gs_saved; pq_p += blockIdx.y * gs_pq; pq_q += blockIdx.y * gs_pq;
     for (int ci = first + blockIdx.x * blockDim.x + threadIdx.x; ci < first + cnt; ci += gridDim.x * blockDim.x) {
         const int pc = rot_index(ci, rot, rot_n);
         const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
-        const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
+        const double s1 = bn_slot_sum(sums + 2 * ci, slot_stride), s2 = rstd * (bn_slot_sum(sums + 2 * ci + 1, slot_stride) - mean * s1);
         atomicAdd(ggamma + pc, static_cast<float>(s2 * inv));
         atomicAdd(gbeta + pc, static_cast<float>(s1 * inv));
         const double scale = gamma[pc] * rstd;
@@ -208,7 +208,7 @@ struct BnFin16x4 {
 };
 __global__ void __launch_bounds__(128) bf16_bn_finalize4_kernel(const BnFin16x4 a, float* __restrict__ pq_p, float* __restrict__ pq_q, double* __restrict__ gsum,
                                                                 int cnt, double count, int training, int64_t gs_sums, int64_t gs_saved, int64_t gs_pq,
-                                                                const float* __restrict__ gscale) {
+                                                                const float* __restrict__ gscale, int64_t slot_stride) {
     const double inv = gscale ? gscale[1] : 1.0;
     pq_p += blockIdx.y * gs_pq; pq_q += blockIdx.y * gs_pq;
     for (int ci = blockIdx.x * blockDim.x + threadIdx.x; ci < cnt; ci += gridDim.x * blockDim.x) {
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(128) bf16_bn_finalize4_kernel(const BnFin16x4 
             const float* saved = a.saved[l] + blockIdx.y * gs_saved;
             const int pc = rot_index(ci, a.rot[l], a.rot_n[l]);
             const double mean = saved[2 * pc], rstd = saved[2 * pc + 1];
-            const double s1 = sums[2 * ci], s2 = rstd * (sums[2 * ci + 1] - mean * s1);
+            const double s1 = bn_slot_sum(sums + 2 * ci, slot_stride), s2 = rstd * (bn_slot_sum(sums + 2 * ci + 1, slot_stride) - mean * s1);
             atomicAdd(a.ggamma[l] + pc, static_cast<float>(s2 * inv));
             atomicAdd(a.gbeta[l] + pc, static_cast<float>(s1 * inv));
             const double scale = a.gamma[l][pc] * rstd;

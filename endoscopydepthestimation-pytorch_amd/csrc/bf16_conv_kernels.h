@@ -106,6 +106,10 @@ struct Conv16Params {
     // launch's first block with group 0's statistics first, then group 1's, as two consecutive calls would.
     int group_n;
     int64_t gs_in_sums, gs_saved, gs_out_sums;
+    // copies of out_sums this many doubles apart (common.h kBnSlots; 0 = one copy): a block adds to the copy its index selects -- the
+    // BatchNorm-BACKWARD sums of the data-gradient launches, whose thousands of blocks otherwise queue on the same few cache lines; the
+    // finalize kernels add the copies up.  The forward statistics keep one copy (every later launch's prologue reads them).
+    int64_t out_sums_slot_stride;
     unsigned sr_salt;                // gradient stores: per-launch salt of the stochastic rounding (pack_s16x2_sr)
     // UNPOOL input (transition down backward): `in` is the pooled-resolution gradient (ups = 1 addressing) and a full-resolution pixel
     // takes a channel's value only where in_idx ([n][h / 2][w / 2][cin] bytes, the forward pass's out_idx) names its position
@@ -635,7 +639,7 @@ __global__ void __launch_bounds__(64 * WAVES) __attribute__((amdgpu_waves_per_eu
             if (co_base + ch < p.cout) {
                 double tsum = 0.0;
                 for (int wv = 0; wv < WAVES; ++wv) tsum += static_cast<double>(s_red[(wv * NT * 16 + ch) * 2 + (e & 1)]);
-                atomicAdd(p.out_sums + grp * p.gs_out_sums + 2 * (p.co_off + co_base + ch) + (e & 1), tsum);
+                atomicAdd(p.out_sums + bn_slot_offset(p.out_sums_slot_stride) + grp * p.gs_out_sums + 2 * (p.co_off + co_base + ch) + (e & 1), tsum);
             }
         }
     }

@@ -49,6 +49,7 @@ struct DgradBlock16Params {
     unsigned sr_salt;                // stochastic rounding of the gradient stores (pack_s16x2_sr)
     int group_n;                     // sample groups (bf16_conv_kernels.h): group g's saved / sums start gs_saved / gs_sums elements later
     int64_t gs_saved, gs_sums;
+    int64_t sums_slot_stride;        // copies of the sums this many doubles apart (common.h kBnSlots; 0 = one copy)
 };
 
 __global__ void __launch_bounds__(kDbThreads) __attribute__((amdgpu_waves_per_eu(2))) bf16_dgrad_block_kernel(const DgradBlock16Params p) {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(kDbThreads) __attribute__((amdgpu_waves_per_eu
             const float* red = s_red + ((j - 1) & 1) * kDbWaves * 96;
             double tsum = 0.0;
             for (int wv = 0; wv < kDbWaves; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
-            atomicAdd(p.sums[j - 1] + grp * p.gs_sums + 2 * co_base + tid, tsum);
+            atomicAdd(p.sums[j - 1] + bn_slot_offset(p.sums_slot_stride) + grp * p.gs_sums + 2 * co_base + tid, tsum);
         }
         const int u0 = j < 2 ? 0 : 2;
         const unsigned char* wj = s_w;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(kDbThreads) __attribute__((amdgpu_waves_per_eu
         const float* red = s_red + ((kDbLayers - 1) & 1) * kDbWaves * 96;
         double tsum = 0.0;
         for (int wv = 0; wv < kDbWaves; ++wv) tsum += static_cast<double>(red[wv * 96 + tid]);
-        atomicAdd(p.sums[kDbLayers - 1] + grp * p.gs_sums + 2 * co_base + tid, tsum);
+        atomicAdd(p.sums[kDbLayers - 1] + bn_slot_offset(p.sums_slot_stride) + grp * p.gs_sums + 2 * co_base + tid, tsum);
     }
     // ---- one read-modify-write of the gradient buffer: all reads, then the sums and the writes ----
     u32x2_t old[NT][R][2];

@@ -307,7 +307,8 @@ struct endo_net16 {
     // per level channel, the BatchNorm backward sums per layer, the data-gradient weights, the weight-gradient partials
     int64_t ws_d[k16Levels + 1];          // bytes
     int64_t ws_pq[k16Levels + 1];         // bytes: floats [2][t]
-    int64_t ws_bnsums;                    // bytes: doubles, layer at its `saved` offset
+    int64_t ws_bnsums;                    // bytes: doubles, layer at its `saved` offset; kBnSlots copies, bn_slot_stride doubles apart
+    int64_t bn_slot_stride;
     int64_t ws_gsum[k16Levels + 1];       // bytes: doubles [t][2], pixel sums of the total gradient per level channel (bf16_prep_dy_kernel)
     int64_t ws_zero_begin, ws_zero_end;   // everything but the level-0 gradient buffer starts at zero
     int64_t ws_w16d;                      // bytes
@@ -351,7 +352,8 @@ extern "C" int N16(create)(endo_net16** out, int n_per_group, int h, int w, int 
         net->ws_zero_begin = o;
         for (int l = 1; l <= k16Levels; ++l) { net->ws_d[l] = o; o += align(static_cast<int64_t>(n) * net->lv[l].plane * net->lv[l].t * 2); }
         for (int l = 0; l <= k16Levels; ++l) { net->ws_pq[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 4 * groups); }
-        net->ws_bnsums = o; o += align(tb.saved_floats * 8 * groups);
+        net->bn_slot_stride = tb.saved_floats * groups;          // kBnSlots copies of the BatchNorm-backward sums (common.h), this many doubles apart
+        net->ws_bnsums = o; o += align(tb.saved_floats * 8 * groups * kBnSlots);
         for (int l = 0; l <= k16Levels; ++l) { net->ws_gsum[l] = o; o += align(static_cast<int64_t>(net->lv[l].t) * 2 * 8); }
         net->ws_zero_end = o;
         net->ws_w16d = o; o += align(tb.w16d_elems * 2);
@@ -616,7 +618,7 @@ int bn_finalize16(const Ctx16& c, const Bn16& b, const Conv16& cv, int level, in
     if (count == 0) return 0;
     bf16_bn_finalize_kernel<<<dim3((count + 127) / 128, c.net->groups), 128, 0, c.stream>>>(
         c.bnsums(b), c.saved(b), c.params + b.g, c.grads + b.g, c.grads + b.b, c.pq_p(level), c.pq_q(level), c.gsum(level), first, count, cv.rot, cv.rot_n,
-        static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved, 2 * lv.t, c.gscale());
+        static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved, 2 * lv.t, c.gscale(), c.net->bn_slot_stride);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -639,7 +641,7 @@ void fill_dgrad(const Ctx16& c, Conv16Params& p, int g_level, int gc0, int level
     p.wgt = c.w16d(cv);
     p.out = c.dbuf(level); p.out_t = lv.t; p.out_blk = k16Blk; p.out_ns = lv.plane * lv.t; p.oc0 = 0; p.cout = cv.cin;
     p.x = c.act(level); p.x_saved = c.saved(b); p.gamma = c.params + b.g; p.beta = c.params + b.b; p.rot = cv.rot; p.rot_n = cv.rot_n;
-    p.out_sums = c.bnsums(b);
+    p.out_sums = c.bnsums(b); p.out_sums_slot_stride = c.net->bn_slot_stride;
     p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_out_sums = c.net->gs_saved;
     p.sr_salt = static_cast<unsigned>(cv.w) * 2654435761u;          // a different rounding sequence per layer
 }
@@ -709,7 +711,7 @@ int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const C
         p.sums[j] = c.bnsums(bn[j]);
     }
     p.rot = cv[0].rot; p.rot_n = cv[0].rot_n;
-    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_sums = c.net->gs_saved;
+    p.group_n = c.net->groups > 1 ? c.net->gn : 0; p.gs_saved = c.net->gs_saved; p.gs_sums = c.net->gs_saved; p.sums_slot_stride = c.net->bn_slot_stride;
     p.sr_salt = static_cast<unsigned>(cv[0].w) * 2246822519u;
     {
         // per base channel and pixel: forward value 2 B, gradient read + written 4 B; the 48 gradient maps 2 B each
@@ -726,7 +728,7 @@ int dense_block_bwd16(const Ctx16& c, int level, int c0, const Bn16* bn, const C
     }
     bf16_bn_finalize4_kernel<<<dim3((c0 + 127) / 128, c.net->groups), 128, 0, c.stream>>>(
         fin, c.pq_p(level), c.pq_q(level), c.gsum(level), c0, static_cast<double>(c.net->gn) * lv.plane, c.training, c.net->gs_saved, c.net->gs_saved,
-        2 * lv.t, c.gscale());
+        2 * lv.t, c.gscale(), c.net->bn_slot_stride);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
