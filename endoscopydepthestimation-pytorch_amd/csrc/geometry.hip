@@ -403,7 +403,13 @@ __global__ void __launch_bounds__(256) warp_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------
 // blocks of the tiled kernels that took the gather path because their source box did not fit the staging buffers
 // (endo_warp_fallback_blocks: lets a test assert that a large-motion batch really exercised the fallback); [0] forward, [1] backward
-static __device__ unsigned long long g_warp_fallback[2] = {0ull, 0ull};
+// (64 counters per direction, one cache line each, a block adds to the one its index selects: with a large-motion or noisy batch most of a
+// launch's 2 560 blocks take the fallback, and that many atomics on ONE address are served one after the other at ~8 ns -- DESIGN.md 4.3)
+constexpr int kFallbackSlots = 64, kFallbackPad = 16;
+static __device__ unsigned long long g_warp_fallback[2][kFallbackSlots][kFallbackPad] = {};
+__device__ __forceinline__ void count_fallback(int which) {
+    atomicAdd(&g_warp_fallback[which][(blockIdx.x + 7 * blockIdx.y + 3 * blockIdx.z) & (kFallbackSlots - 1)][0], 1ull);
+}
 
 template <int TY, int TX>
 struct WarpTile {
@@ -476,7 +482,7 @@ __global__ void __launch_bounds__(256) warp_fwd_tiled_kernel(const float* __rest
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;          // block-uniform; bw <= 0: no pixel of the block has a tap in range
-    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[0], 1ull);
+    if (!staged && bw > 0 && threadIdx.x == 0) count_fallback(0);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -562,7 +568,7 @@ __global__ void __launch_bounds__(256) warp_bwd_tiled_kernel(const float* __rest
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
-    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[1], 1ull);
+    if (!staged && bw > 0 && threadIdx.x == 0) count_fallback(1);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -698,7 +704,7 @@ __global__ void __launch_bounds__(256) consistency_fwd_kernel(const ConsistencyA
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
-    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[0], 1ull);
+    if (!staged && bw > 0 && threadIdx.x == 0) count_fallback(0);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -841,7 +847,7 @@ __global__ void __launch_bounds__(256) consistency_bwd_kernel(const ConsistencyA
     int bx0, by0, bw, bh;
     block_tap_box(minx, miny, maxx, maxy, s_box, bx0, by0, bw, bh);
     const bool staged = bw <= T::BW && bh <= T::BH && bw > 0;
-    if (!staged && bw > 0 && threadIdx.x == 0) atomicAdd(&g_warp_fallback[1], 1ull);
+    if (!staged && bw > 0 && threadIdx.x == 0) count_fallback(1);
     if (staged) {
         for (int e = threadIdx.x; e < bh * T::BW; e += T::kThreads) {
             const int ry = e / T::BW, rx = e - ry * T::BW;
@@ -989,12 +995,15 @@ static int launch_warp_bwd_tiled(const float* gw, const float* d1, const float* 
 }
 
 extern "C" int endo_warp_fallback_blocks(long long* forward, long long* backward, int reset) {
-    unsigned long long host[2] = {0ull, 0ull};
+    static unsigned long long host[2][kFallbackSlots][kFallbackPad];
     ENDO_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_warp_fallback), sizeof(host)));          // synchronises with the device: a test hook
-    if (forward) *forward = static_cast<long long>(host[0]);
-    if (backward) *backward = static_cast<long long>(host[1]);
+    long long total[2] = {0, 0};
+    for (int k = 0; k < 2; ++k)
+        for (int i = 0; i < kFallbackSlots; ++i) total[k] += static_cast<long long>(host[k][i][0]);
+    if (forward) *forward = total[0];
+    if (backward) *backward = total[1];
     if (reset) {
-        const unsigned long long zero[2] = {0ull, 0ull};
+        static const unsigned long long zero[2][kFallbackSlots][kFallbackPad] = {};
         ENDO_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_warp_fallback), zero, sizeof(zero)));
     }
     return 0;

@@ -30,6 +30,29 @@ __global__ void __launch_bounds__(256) head_add_kernel(float* __restrict__ out, 
 
 // losses[0..2] = total, dcl, sfl as train.py:299-315 forms them (fp32), losses[3] = 1 when the total is NaN / Inf (train.py:317) else 0: sfl = w_sfl * 0.5 * (a + b), dcl likewise, total = dcl + sfl;
 // up[0] = d total / d (each sparse-flow term), up[1] = d total / d (each consistency term)
+// out_j = a_j * mask (per sample, broadcast over a_j's channels) for up to six tensors in ONE launch: blockIdx.z = job.  The arithmetic of
+// endo_mask_mul (geometry.hip mask_mul_kernel), which the head used to call once per tensor: six launches of ~5 us each, alone on the chip.
+struct MaskMulJobs {
+    const float* a[6];
+    float* out[6];
+    int c[6];
+};
+__global__ void __launch_bounds__(256) head_mask_mul_kernel(const MaskMulJobs jobs, const float* __restrict__ mask, int hw) {
+    const int n = blockIdx.y;
+    const float* __restrict__ a = jobs.a[0];
+    float* __restrict__ out = jobs.out[0];
+    int c = jobs.c[0];
+#pragma unroll
+    for (int j = 1; j < 6; ++j)
+        if (blockIdx.z == j) { a = jobs.a[j]; out = jobs.out[j]; c = jobs.c[j]; }          // (no dynamic index into the kernel argument)
+    const int64_t mbase = static_cast<int64_t>(n) * hw;
+    const int64_t abase = mbase * c;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += gridDim.x * blockDim.x) {
+        const float m = mask[mbase + i];
+        for (int k = 0; k < c; ++k) out[abase + static_cast<int64_t>(k) * hw + i] = a[abase + static_cast<int64_t>(k) * hw + i] * m;
+    }
+}
+
 __global__ void head_combine_kernel(const float* __restrict__ parts, float c_sfl, const float* __restrict__ dcl_weighted, float* __restrict__ losses,
                                     float* __restrict__ up) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -97,12 +120,14 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     HEAD(endo_depth_scale_fwd(pred_2, sparse_depths_2, sparse_depth_masks_2, scaled_2, ratio + 1, ds_stats_2, n, hw, eps, stream_));
     HEAD(endo_flow_from_depth_fwd(scaled_1, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, flow_1, n, h, w, stream_));
     HEAD(endo_flow_from_depth_fwd(scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, flow_2, n, h, w, stream_));
-    HEAD(endo_mask_mul(sparse_flow_masks_1, boundaries, msm_1, n, 1, hw, stream_));
-    HEAD(endo_mask_mul(sparse_flow_masks_2, boundaries, msm_2, n, 1, hw, stream_));
-    HEAD(endo_mask_mul(sparse_flows_1, boundaries, msf_1, n, 2, hw, stream_));
-    HEAD(endo_mask_mul(sparse_flows_2, boundaries, msf_2, n, 2, hw, stream_));
-    HEAD(endo_mask_mul(flow_1, boundaries, flow_1, n, 2, hw, stream_));
-    HEAD(endo_mask_mul(flow_2, boundaries, flow_2, n, 2, hw, stream_));
+    {
+        int bx = (hw + 255) / 256;
+        bx = bx > 1024 ? 1024 : bx;
+        MaskMulJobs jobs{{sparse_flow_masks_1, sparse_flow_masks_2, sparse_flows_1, sparse_flows_2, flow_1, flow_2},
+                         {msm_1, msm_2, msf_1, msf_2, flow_1, flow_2}, {1, 1, 2, 2, 2, 2}};
+        head_mask_mul_kernel<<<dim3(bx, n, 6), 256, 0, stream>>>(jobs, boundaries, hw);
+        ENDO_LAUNCH_CHECK();
+    }
     HEAD(endo_sparse_l1_fwd(msf_1, flow_1, msm_1, parts + 0, l1_stats_1, n, 2, hw, 1.0f, stream_));
     HEAD(endo_sparse_l1_fwd(msf_2, flow_2, msm_2, parts + 1, l1_stats_2, n, 2, hw, 1.0f, stream_));
     // depth warp both ways + depth-consistency loss: the two fused kernels of endo_warp_consistency (geometry.hip); the forward one
@@ -114,8 +139,13 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     // ---- backward ----
     HEAD(endo_sparse_l1_bwd(up + 0, msf_1, flow_1, msm_1, l1_stats_1, nullptr, g_flow_1, n, 2, hw, 1.0f, stream_));
     HEAD(endo_sparse_l1_bwd(up + 0, msf_2, flow_2, msm_2, l1_stats_2, nullptr, g_flow_2, n, 2, hw, 1.0f, stream_));
-    HEAD(endo_mask_mul(g_flow_1, boundaries, g_flow_1, n, 2, hw, stream_));
-    HEAD(endo_mask_mul(g_flow_2, boundaries, g_flow_2, n, 2, hw, stream_));
+    {
+        int bx = (hw + 255) / 256;
+        bx = bx > 1024 ? 1024 : bx;
+        MaskMulJobs jobs{{g_flow_1, g_flow_2}, {g_flow_1, g_flow_2}, {2, 2}};
+        head_mask_mul_kernel<<<dim3(bx, n, 2), 256, 0, stream>>>(jobs, boundaries, hw);
+        ENDO_LAUNCH_CHECK();
+    }
     // the flow terms initialise d loss / d scaled depth (every element written), the consistency kernel adds its own
     HEAD(endo_flow_from_depth_bwd(g_flow_1, scaled_1, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, g_s1, n, h, w, stream_));
     HEAD(endo_flow_from_depth_bwd(g_flow_2, scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_s2, n, h, w, stream_));
