@@ -11,6 +11,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def pytest_configure(config):
+    # The CPU oracle (plain PyTorch) is what most of the GPU suite's wall time goes to, and torch's default of one thread per logical CPU
+    # is the slowest choice on the GPU box's 2 x 128-thread host: bench.py's cpu_baseline measured its training iteration at 1.49 s with
+    # 32 threads against 12.4 s with 128 (batch 1).  At most 32 threads, as that leg uses; a container with fewer CPUs keeps its own count.
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
+    except Exception:
+        pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "bench: timing prints without assertions on speed (run by hand with -m bench on a GPU box; not part of -m gpu)")
 
