@@ -13,6 +13,7 @@
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_taps_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/wgrad_nsplit_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_block_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/wino_fwd_kernels.h"
 
 using namespace endo;
 
@@ -116,6 +117,22 @@ int main(int argc, char** argv) {
         vs.push_back({"fwd dma4 KC16 2buf 16x16", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 4, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC8 2buf 16x4", [&](hipStream_t s) { return launch_conv_dma_vec<3, 8, 1, IN_BNRELU, EPI_FWD, 1, 1, 2, 1, 4, 0>(f, s); }});
         vs.push_back({"fwd dma4 KC16 2buf 16x4", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 1, 2, 1, 4, 0>(f, s); }});
+        // what the BN statistics of the stored values cost (sum / sum^2 per channel: shuffles, LDS, and one fp64 atomic per value and block
+        // on the two cache lines of the layer's 12 pairs -- blocks of a single-round launch all end together)
+        ConvParams fns = f; fns.out_sums = nullptr;
+        vs.push_back({"fwd dma4 KC16 2buf 16x8, no output statistics", [&](hipStream_t s) { return launch_conv_dma_vec<3, 16, 1, IN_BNRELU, EPI_FWD, 1, 2, 2, 1, 4, 0>(fns, s); }});
+        {
+            WinoWeightTable wt{}; wt.layers = 1; wt.start[0] = 0; wt.start[1] = cin * 16; wt.cin[0] = cin; wt.cout[0] = 12; wt.w_off[0] = 0; wt.u_off[0] = 0;
+            float* ubuf; CK(hipMalloc(&ubuf, (size_t)cin * kWinoUStride * sizeof(float)));
+            wino_fwd_weights_kernel<<<(cin * 16 + 255) / 256, 256>>>(wt, wgt, ubuf);
+            CK(hipDeviceSynchronize());
+            static ConvParams fw, fwn;
+            fw = f; fw.wgt = ubuf; fwn = fw; fwn.out_sums = nullptr;
+            if (wino_fwd_ok(fw)) {
+                vs.push_back({"fwd Winograd F(2x2,3x3) 32x8 (level-1 form)", [&](hipStream_t s) { return launch_wino_fwd<1, 4, 3, 2>(fw, s); }});
+                vs.push_back({"fwd Winograd F(2x2,3x3) 32x8, no output statistics", [&](hipStream_t s) { return launch_wino_fwd<1, 4, 3, 2>(fwn, s); }});
+            }
+        }
         bench(vs, f.out, (size_t)12 * plane, flops);      // compares sample 0's 12 planes
     }
 
