@@ -158,6 +158,15 @@ __device__ __forceinline__ int xcd_remap(int b, int total) {
 
 }  // namespace endo
 
+// geometry.hip / losses.hip, used by head.hip: the public entry points with their reduction tables' memset optional (zero = 0: the caller has
+// zeroed them -- the loss head does so for all of its tables with one memset).  Not part of the C ABI.
+int endo_depth_scale_fwd_impl(const float* pred, const float* sparse_depth, const float* sparse_mask, float* scaled, float* ratio, double* stats,
+                              int n, int hw, float eps, int zero, hipStream_t stream);
+int endo_depth_scale_bwd_impl(const float* grad_scaled, const float* grad_ratio, const float* pred, const float* sparse_depth, const double* stats,
+                              float* grad_pred, double* work, int n, int hw, float eps, int zero, hipStream_t stream);
+int endo_sparse_l1_fwd_impl(const float* flows, const float* flows_hat, const float* mask, float* loss, double* stats, int n, int c, int hw,
+                            float eps, int zero, hipStream_t stream);
+
 // geometry.hip, used by head.hip: the fused depth-warp + consistency-loss kernels (endo_warp_consistency), forward (phase 1: memset,
 // forward kernel, and -- unless the caller asks for the loss only at the end -- the one-wave finalize) and backward (phase 2).  Not part
 // of the C ABI.  zero_grads: 1 = the forward kernel zeroes grad_depth_* and the backward kernel also writes the loss (the stand-alone

@@ -928,10 +928,15 @@ using namespace endo;
 
 extern "C" int endo_depth_scale_fwd(const float* pred, const float* sparse_depth, const float* sparse_mask, float* scaled,
                                     float* ratio, double* stats, int n, int hw, float eps, void* stream_) {
+    return endo_depth_scale_fwd_impl(pred, sparse_depth, sparse_mask, scaled, ratio, stats, n, hw, eps, 1, static_cast<hipStream_t>(stream_));
+}
+
+// zero = 0: the caller has zeroed `stats` (the loss head: one memset for all its reduction tables)
+int endo_depth_scale_fwd_impl(const float* pred, const float* sparse_depth, const float* sparse_mask, float* scaled, float* ratio, double* stats,
+                              int n, int hw, float eps, int zero, hipStream_t stream) {
     if (!pred || !sparse_depth || !sparse_mask || !scaled || !ratio || !stats || n <= 0 || hw <= 0) return ENDO_E_BADARG;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfGeometry, stream, 0.0, 6.0 * 4.0 * n * hw);
-    ENDO_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 8 * n, stream));
+    if (zero) ENDO_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 8 * n, stream));
     dim3 rgrid((hw + kRedThreads * kRedItems - 1) / (kRedThreads * kRedItems), n);
     depth_scale_pass1<<<rgrid, kRedThreads, 0, stream>>>(sparse_depth, sparse_mask, stats, hw);
     depth_scale_pass2<<<rgrid, kRedThreads, 0, stream>>>(pred, sparse_depth, stats, hw, eps);
@@ -944,10 +949,14 @@ extern "C" int endo_depth_scale_fwd(const float* pred, const float* sparse_depth
 extern "C" int endo_depth_scale_bwd(const float* grad_scaled, const float* grad_ratio, const float* pred,
                                     const float* sparse_depth, const double* stats, float* grad_pred, double* work, int n,
                                     int hw, float eps, void* stream_) {
+    return endo_depth_scale_bwd_impl(grad_scaled, grad_ratio, pred, sparse_depth, stats, grad_pred, work, n, hw, eps, 1, static_cast<hipStream_t>(stream_));
+}
+
+int endo_depth_scale_bwd_impl(const float* grad_scaled, const float* grad_ratio, const float* pred, const float* sparse_depth, const double* stats,
+                              float* grad_pred, double* work, int n, int hw, float eps, int zero, hipStream_t stream) {
     if (!pred || !sparse_depth || !stats || !grad_pred || !work || n <= 0 || hw <= 0) return ENDO_E_BADARG;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfGeometry, stream, 0.0, 6.0 * 4.0 * n * hw);
-    ENDO_CHECK(hipMemsetAsync(work, 0, sizeof(double) * n, stream));
+    if (zero) ENDO_CHECK(hipMemsetAsync(work, 0, sizeof(double) * n, stream));
     if (grad_scaled) {
         dim3 rgrid((hw + kRedThreads * kRedItems - 1) / (kRedThreads * kRedItems), n);
         depth_scale_bwd_reduce<<<rgrid, kRedThreads, 0, stream>>>(grad_scaled, pred, work, hw);

@@ -116,8 +116,10 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     int rc;
 #define HEAD(call) do { rc = (call); if (rc) return rc; } while (0)
     // ---- forward (train.py:279-315) ----
-    HEAD(endo_depth_scale_fwd(pred_1, sparse_depths_1, sparse_depth_masks_1, scaled_1, ratio, ds_stats_1, n, hw, eps, stream_));
-    HEAD(endo_depth_scale_fwd(pred_2, sparse_depths_2, sparse_depth_masks_2, scaled_2, ratio + 1, ds_stats_2, n, hw, eps, stream_));
+    // one memset for the reduction tables of both frames' depth scaling (forward sums, backward work) and sparse-flow losses: 22 n doubles
+    ENDO_CHECK(hipMemsetAsync(dstats, 0, sizeof(double) * (2 * 8 * n + 2 * n + 2 * 2 * n), stream));
+    HEAD(endo_depth_scale_fwd_impl(pred_1, sparse_depths_1, sparse_depth_masks_1, scaled_1, ratio, ds_stats_1, n, hw, eps, 0, stream));
+    HEAD(endo_depth_scale_fwd_impl(pred_2, sparse_depths_2, sparse_depth_masks_2, scaled_2, ratio + 1, ds_stats_2, n, hw, eps, 0, stream));
     HEAD(endo_flow_from_depth_fwd(scaled_1, boundaries, t_1_wrt_2, r_1_wrt_2, intrinsics, flow_1, n, h, w, stream_));
     HEAD(endo_flow_from_depth_fwd(scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, flow_2, n, h, w, stream_));
     {
@@ -128,8 +130,8 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
         head_mask_mul_kernel<<<dim3(bx, n, 6), 256, 0, stream>>>(jobs, boundaries, hw);
         ENDO_LAUNCH_CHECK();
     }
-    HEAD(endo_sparse_l1_fwd(msf_1, flow_1, msm_1, parts + 0, l1_stats_1, n, 2, hw, 1.0f, stream_));
-    HEAD(endo_sparse_l1_fwd(msf_2, flow_2, msm_2, parts + 1, l1_stats_2, n, 2, hw, 1.0f, stream_));
+    HEAD(endo_sparse_l1_fwd_impl(msf_1, flow_1, msm_1, parts + 0, l1_stats_1, n, 2, hw, 1.0f, 0, stream));
+    HEAD(endo_sparse_l1_fwd_impl(msf_2, flow_2, msm_2, parts + 1, l1_stats_2, n, 2, hw, 1.0f, 0, stream));
     // depth warp both ways + depth-consistency loss: the two fused kernels of endo_warp_consistency (geometry.hip); the forward one
     // leaves dcl_weight * 0.5 * (term_1 + term_2) in parts[4] and the backward coefficients in its workspace
     HEAD(endo_consistency_phase(1, scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, t_2_wrt_1, r_2_wrt_1, intrinsics, dcl_weight, eps,
@@ -151,8 +153,8 @@ extern "C" int endo_loss_head(const float* pred_1, const float* pred_2, const fl
     HEAD(endo_flow_from_depth_bwd(g_flow_2, scaled_2, boundaries, t_2_wrt_1, r_2_wrt_1, intrinsics, g_s2, n, h, w, stream_));
     HEAD(endo_consistency_phase(2, scaled_1, scaled_2, boundaries, t_1_wrt_2, r_1_wrt_2, t_2_wrt_1, r_2_wrt_1, intrinsics, dcl_weight, eps,
                                 parts + 4, g_s1, g_s2, cons_ws, n, h, w, 0, stream));
-    HEAD(endo_depth_scale_bwd(g_s1, nullptr, pred_1, sparse_depths_1, ds_stats_1, grad_pred_1, ds_work_1, n, hw, eps, stream_));
-    HEAD(endo_depth_scale_bwd(g_s2, nullptr, pred_2, sparse_depths_2, ds_stats_2, grad_pred_2, ds_work_2, n, hw, eps, stream_));
+    HEAD(endo_depth_scale_bwd_impl(g_s1, nullptr, pred_1, sparse_depths_1, ds_stats_1, grad_pred_1, ds_work_1, n, hw, eps, 0, stream));
+    HEAD(endo_depth_scale_bwd_impl(g_s2, nullptr, pred_2, sparse_depths_2, ds_stats_2, grad_pred_2, ds_work_2, n, hw, eps, 0, stream));
 #undef HEAD
     return 0;
 }

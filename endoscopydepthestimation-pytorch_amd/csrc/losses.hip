@@ -172,10 +172,15 @@ using namespace endo;
 
 extern "C" int endo_sparse_l1_fwd(const float* flows, const float* flows_hat, const float* mask, float* loss, double* stats, int n,
                                   int c, int hw, float eps, void* stream_) {
+    return endo_sparse_l1_fwd_impl(flows, flows_hat, mask, loss, stats, n, c, hw, eps, 1, static_cast<hipStream_t>(stream_));
+}
+
+// zero = 0: the caller has zeroed `stats` (the loss head)
+int endo_sparse_l1_fwd_impl(const float* flows, const float* flows_hat, const float* mask, float* loss, double* stats, int n, int c, int hw,
+                            float eps, int zero, hipStream_t stream) {
     if (!flows || !flows_hat || !mask || !loss || !stats || n <= 0 || c <= 0 || hw <= 0) return ENDO_E_BADARG;
-    hipStream_t stream = static_cast<hipStream_t>(stream_);
     ProfScope prof(kProfLoss, stream, 0.0, 4.0 * (2.0 * c + 1.0) * n * hw);
-    ENDO_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * n, stream));
+    if (zero) ENDO_CHECK(hipMemsetAsync(stats, 0, sizeof(double) * 2 * n, stream));
     sparse_l1_reduce<<<reduce_grid(hw, n), kLossThreads, 0, stream>>>(flows, flows_hat, mask, stats, c, hw);
     sparse_l1_finalize<<<1, 64, 0, stream>>>(stats, loss, n, eps);
     ENDO_LAUNCH_CHECK();
