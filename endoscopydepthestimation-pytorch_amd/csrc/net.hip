@@ -36,6 +36,8 @@
 namespace endo {
 
 int run_dgrad_wino3_nl4(const DgradBlockParams& p, const float* const* u, hipStream_t stream);          // dgrad_wino3.hip
+bool dgrad_wino3p_applies(const DgradBlockParams& p);
+int run_dgrad_wino3p_nl4(const DgradBlockParams& p, const float* const* u, int blocks, double* fw_parts, int* blocks_used, hipStream_t stream);
 
 constexpr int kGrowth = 12;
 constexpr int kLayers = 4;
@@ -168,6 +170,8 @@ struct endo_net {
     int64_t wd_off;           // float offset in gradws of the Winograd-domain data-gradient weights (group 0's copy serves all groups)
     int64_t gplane_off;       // float offset in gradws of g = grad_out * sign(pre), one plane per sample (final_g_kernel)
     int64_t bias_parts_off;   // float offset in gradws (group 0's) of prep_dy's per-block sums of G (BiasParts), bias_parts_floats long
+    int64_t fw_parts_off;     // float offset in gradws (group 0's) of the persistent base pass's final-conv weight partials (kFwPartBlocks x 192 doubles)
+    int cus;                  // compute units of the device the handle was created on: the persistent kernels launch one block per CU
     int64_t bias_parts_floats;
     int64_t gradws_floats;
     // Weight gradients run on a side stream: a layer's wgrad depends only on its prepared dY and the forward tape, nothing on the
@@ -193,6 +197,7 @@ namespace endo {
 // the slots of every prep_dy launch in a fixed order (bias_reduce_kernel): no serialised atomics, and the same bits in every run.
 constexpr int kBiasPartChannels = 2048;          // channels prepared per backward pass: 1 776 at FC-DenseNet57 (all conv outputs but the final one)
 constexpr int kBiasPartLaunches = 64;
+constexpr int kFwPartBlocks = 512;          // persistent blocks whose final-conv weight partials fit the workspace (dgrad_wino3p_kernels.h, FW)
 struct BiasReduceTable {
     int n;
     struct Entry { const float* parts; float* bias; int count; int nparts; } e[kBiasPartLaunches];
@@ -527,11 +532,12 @@ __global__ void __launch_bounds__(256) final_bwd_data_kernel(const float* __rest
 
 // dw[c] += sum g * u[c]; channel index cin is the bias (sum g).  grid (cin + 1, slices, n): float4 streaming,
 // two independent accumulators; g = gout * sign(pre) is recomputed from two L2-resident planes.
+// c_first: the channels below it are left to the last up block's persistent base pass (dgrad_wino3p_kernels.h, FW); grid.x = cin - c_first + 1
 __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __restrict__ gout, const float* __restrict__ pre,
                                                                const float* __restrict__ u, int64_t ns, int plane, int cin,
-                                                               int group_n, int64_t gs, float* __restrict__ gw, float* __restrict__ gb) {
+                                                               int group_n, int64_t gs, float* __restrict__ gw, float* __restrict__ gb, int c_first) {
     __shared__ double scratch[4];
-    const int c = blockIdx.x;
+    const int c = c_first + blockIdx.x;
     const int grp = blockIdx.z / group_n, n = blockIdx.z - grp * group_n;
     const float* gp = gout + static_cast<int64_t>(blockIdx.z) * plane;
     const float* pp = pre + grp * gs + static_cast<int64_t>(n) * plane;
@@ -559,6 +565,15 @@ __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __re
         const float t = static_cast<float>(scratch[0] + scratch[1] + scratch[2] + scratch[3]);
         if (c < cin) atomicAdd(gw + c, t); else atomicAdd(gb, t);
     }
+}
+
+// dW_final[c] += sum over the persistent base pass's blocks of its partial (fixed order, fp64)
+__global__ void __launch_bounds__(64) final_w_reduce_kernel(const double* __restrict__ parts, int nblocks, int count, float* __restrict__ gw) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= count) return;
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += parts[static_cast<int64_t>(b) * count + c];
+    atomicAdd(gw + c, static_cast<float>(t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -644,7 +659,8 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_WINO_FWD        dense-layer forward at the fine levels: 0 = direct convolution, 1 = Winograd F(2x2, 3x3) (2 LDS stages), 3 / 4 = the same
 //                            with 3 / 4 stages, 5 (default) = F(4x4, 3x3) for the launches that fill the chip with 64 x 16 blocks, F(2x2, 3x3) for the rest
 //   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
-//                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h)
+//                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h), 3 (default) = 1 as persistent blocks where that form applies
+//                            (dgrad_wino3p_kernels.h: at most 144 base channels), the per-tile kernel elsewhere
 //   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 (default) = persistent blocks (dgrad_newmap_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
 //                            DMA of the gradient tiles (dgrad_block_kernels.h)
 //   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
@@ -656,7 +672,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_FINAL_VIRTUAL   1 = the final convolution's data gradient is not written out: the last up block's kernels form g * w[c] (FinalVirt)
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
-    opt[ENDO_OPT_WINO_DGRAD] = 1;
+    opt[ENDO_OPT_WINO_DGRAD] = 3;
     opt[ENDO_OPT_DGRAD_VEC] = 2;
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
     opt[ENDO_OPT_MFMA_BF16] = 0;
@@ -860,7 +876,7 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
 // The final convolution's data gradient as the "virtual" content of the level-0 gradient buffer (DgradBlockParams::vg): vg = the plane
 // g = grad_out * sign(pre) in the gradient workspace, vw = the 192 final-conv weights; base: the base-channel pass forms it too
 // (otherwise final_bwd_data_kernel has materialised the block's base channels)
-struct FinalVirt { const float* vg; const float* vw; bool base; };
+struct FinalVirt { const float* vg; const float* vw; bool base; bool base_w; float* gw; };          // base_w: the base pass also forms the final convolution's weight gradient of its channels (gw: that tensor's gradient)
 
 static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad, const BnFin4* fin = nullptr, int nl = 0, const FinalVirt* fv = nullptr) {
     const auto& lv = c.net->lv[level];
@@ -973,7 +989,7 @@ static int base_pass_form(const Ctx& c, int level, const DgradBlockParams& p, co
     const long wtiles = static_cast<long>(lv.w / 32) * (lv.h / 8) * c.nt();
     if (mfma_bf16_dgrad(c)) return 0;
     if (wino_dgrad_enabled(c) && dgrad_wino_ok(p) && wtiles >= c.net->opt[ENDO_OPT_WINO_MIN_TILES] && cv[0].ud >= 0)
-        return (wino_dgrad_mode(c) == 1 && dgrad_wino3_ok(p)) ? 1 : 2;
+        return ((wino_dgrad_mode(c) == 1 || wino_dgrad_mode(c) == 3) && dgrad_wino3_ok(p)) ? 1 : 2;
     return 0;
 }
 
@@ -1101,7 +1117,19 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
             const float* ub = c.gradws + c.net->wd_off;
             const float* const u[4] = {ub + cv[0].ud, ub + cv[1].ud, ub + cv[2].ud, ub + cv[3].ud};
             // form 1: the phase-skewed kernel (its U layout; endo_net_bwd transforms the weights to match), 2: the round-2 kernel
-            rc = form == 1 ? run_dgrad_wino3_nl4(p, u, c.stream) : launch_dgrad_wino8<4>(p, u, c.stream);
+            if (form == 1 && wino_dgrad_mode(c) == 3 && dgrad_wino3p_applies(p)) {
+                // persistent blocks, one per CU; with fv->base_w they leave per-block partials of dW_final[ic0 .. ic0 + c0), added up here
+                double* fwp = (fv && fv->base && fv->base_w) ? reinterpret_cast<double*>(c.gradws + c.net->fw_parts_off) : nullptr;
+                int used = 0;
+                rc = run_dgrad_wino3p_nl4(p, u, c.net->cus < kFwPartBlocks ? c.net->cus : kFwPartBlocks, fwp, &used, c.stream);
+                if (rc == 0 && fwp) {
+                    final_w_reduce_kernel<<<(c0 + 63) / 64, 64, 0, c.stream>>>(fwp, used, c0, fv->gw + ic0);
+                    ENDO_LAUNCH_CHECK();
+                }
+            } else {
+                if (fv && fv->base && fv->base_w) return ENDO_E_BADARG;          // endo_net_bwd left these channels' final-conv weight gradient to the persistent kernel
+                rc = form == 1 ? run_dgrad_wino3_nl4(p, u, c.stream) : launch_dgrad_wino8<4>(p, u, c.stream);
+            }
         } else {
             rc = launch_dgrad_block8<4>(p, c.stream);       // 512-thread blocks: +15 % over the 4-wave kernel (tools/conv_bench)
         }
@@ -1266,7 +1294,13 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->gplane_off = align_up(net->wd_off + tb.wino_dgrad_floats, 64);
     net->bias_parts_off = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);
     net->bias_parts_floats = static_cast<int64_t>(kBiasPartChannels) * n * groups * 32;
-    net->gradws_floats = net->bias_parts_off + align_up(net->bias_parts_floats, 64);
+    net->fw_parts_off = net->bias_parts_off + align_up(net->bias_parts_floats, 64);
+    net->gradws_floats = net->fw_parts_off + 2 * static_cast<int64_t>(kFwPartBlocks) * 192;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        net->cus = cus;
+    }
     // one stride for both buffers keeps the kernels' group arithmetic to a single number; the caller allocates
     // groups * gs floats for each when groups > 1 (the two sizes differ by a few per cent)
     net->gs = align_up(net->tape_floats > net->gradws_floats ? net->tape_floats : net->gradws_floats, 64);
@@ -1421,7 +1455,7 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         ProfScope prof(kProfSmall, c.stream, 0.0, 4.0 * 2.0 * tb.wino_dgrad_floats);
         // mode 1: blocks the phase-skewed kernel takes (dgrad_wino3_ok: at most 12 base-channel groups) get its U layout
         dgrad_wino_weights_kernel<<<(tb.wino_dgrad.start[tb.wino_dgrad.layers] + 255) / 256, 256, 0, c.stream>>>(
-            tb.wino_dgrad, params, gradws + net->wd_off, wino_dgrad_mode(c) == 1 ? DgradWino3Geom<4>::kMaxCount / 16 : 0);
+            tb.wino_dgrad, params, gradws + net->wd_off, (wino_dgrad_mode(c) == 1 || wino_dgrad_mode(c) == 3) ? DgradWino3Geom<4>::kMaxCount / 16 : 0);
         ENDO_LAUNCH_CHECK();
     }
     int rc;
@@ -1429,18 +1463,6 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
     bool use_virt = false;
     {
         const auto& lv = net->lv[0];
-        {   // final conv weight / bias gradient: reads only grad_out and the tape, so it goes to the side stream first
-            Ctx cw;
-            rc = c.fork_wgrad(cw, 0);
-            if (rc) return rc;
-            int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
-            by = by < 1 ? 1 : (by > 16 ? 16 : by);
-            ProfScope prof(kProfConvFinal, cw.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (192 + 2));
-            final_bwd_weight_kernel<<<dim3(193, by, c.nt()), 256, 0, cw.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
-                                                                         static_cast<int>(lv.plane), 192, net->n, net->gs, grads + tb.final_.w,
-                                                                         grads + tb.final_.b);
-            ENDO_LAUNCH_CHECK();
-        }
         // The final convolution's data gradient is rank one: dX[c] = g * w[c], g = grad_out * sign(pre).  Writing it out (192 planes, 1 GB
         // at 16 x 256 x 320) only for the last up block to read it back costs two passes over the level-0 buffer; instead g goes to one
         // plane and that block's kernels form the products where they first touch a channel (FinalVirt) -- where the block takes the
@@ -1448,13 +1470,30 @@ extern "C" int endo_net_bwd(endo_net* net, const float* params, const float* x, 
         DgradBlockParams probe{};
         probe.n = c.nt(); probe.h = lv.h; probe.w = lv.w; probe.count = 96 + down_in(0);
         probe.cs = static_cast<int>(lv.plane); probe.ns = lv.t * lv.plane;
+        probe.g_cs = static_cast<int>(lv.plane);
         probe.x = c.act(0); probe.out = c.gbuf(0);
-        virt.vg = gradws + net->gplane_off; virt.vw = params + tb.final_.w; virt.base = false;
+        virt.vg = gradws + net->gplane_off; virt.vw = params + tb.final_.w; virt.base = false; virt.base_w = false; virt.gw = grads + tb.final_.w;
         int materialise = 192;          // channels [0, materialise) are written by final_bwd_data_kernel
         if (c.net->opt[ENDO_OPT_FINAL_VIRTUAL] && dgrad_block_ok(probe)) {
             use_virt = true;
             virt.base = base_pass_form(c, 0, probe, tb.up_conv[kLevels - 1]) == 1;
             materialise = virt.base ? 0 : 96 + down_in(0);
+            // ... and where that kernel runs as persistent blocks it also forms sum g * x[c] of the base channels it streams: the final
+            // convolution's weight gradient of those channels (round 6: final_bwd_weight_kernel then reads 48 + 1 instead of 192 + 1 planes)
+            virt.base_w = virt.base && wino_dgrad_mode(c) == 3 && dgrad_wino3p_applies(probe);
+        }
+        {   // final conv weight / bias gradient: reads only grad_out and the tape, so it goes to the side stream first
+            Ctx cw;
+            rc = c.fork_wgrad(cw, 0);
+            if (rc) return rc;
+            const int c_first = virt.base_w ? 96 + down_in(0) : 0;
+            int by = static_cast<int>((lv.plane + 256 * 16 - 1) / (256 * 16));       // 16 pixels per thread
+            by = by < 1 ? 1 : (by > 16 ? 16 : by);
+            ProfScope prof(kProfConvFinal, cw.stream, 2.0 * c.nt() * lv.plane * (192 - c_first), 4.0 * c.nt() * lv.plane * (192 - c_first + 2));
+            final_bwd_weight_kernel<<<dim3(192 - c_first + 1, by, c.nt()), 256, 0, cw.stream>>>(grad_out, tape + net->pre_off, c.act(0), lv.t * lv.plane,
+                                                                         static_cast<int>(lv.plane), 192, net->n, net->gs, grads + tb.final_.w,
+                                                                         grads + tb.final_.b, c_first);
+            ENDO_LAUNCH_CHECK();
         }
         ProfScope prof(kProfConvFinal, c.stream, 2.0 * c.nt() * lv.plane * 192, 4.0 * c.nt() * lv.plane * (materialise + 2));
         if (use_virt) {

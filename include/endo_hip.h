@@ -212,8 +212,10 @@ int endo_net_groups(const endo_net* net);
  *                            5 (default since round 5) = F(4x4,3x3) for the launches whose 64 x 16 blocks fill the chip (level 0 at 256 x 320; csrc/wino4_fwd_kernels.h)
  *                            and F(2x2,3x3) below: +3 % frame-pairs/s; the depth is 5e-6 of its maximum from fp64 instead of 1e-6, against the
  *                            1e-4 of the parity target
- *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd with phase-skewed workers (default),
- *                            2 Winograd, the round-2 kernel
+ *   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 direct, 1 Winograd with phase-skewed workers, one block per tile,
+ *                            2 Winograd, the round-2 kernel, 3 (default) = 1 as persistent blocks that walk a run of tiles where that form applies
+ *                            (csrc/dgrad_wino3p_kernels.h: at most 144 base channels; it also forms the final convolution's weight gradient of the
+ *                            last up block's base channels)
  *   ENDO_OPT_DGRAD_VEC       new-channel data-gradient passes: 2 (default) = persistent blocks that walk a run of tiles (csrc/dgrad_newmap_kernels.h),
  *                            1 = one block per tile with 16-byte DMA of the gradient tiles, 0 = the same with dword DMA
  *   ENDO_OPT_WINO_MIN_TILES  tiles per launch from which a Winograd kernel is chosen (default 1024)

@@ -1049,6 +1049,46 @@ def test_persistent_new_map_passes_match_the_per_tile_blocks(shape):
     print("persistent vs per-tile new-map passes %s: worst gradient difference %.2e of the tensor's maximum" % (shape, worst))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 96, 160), (8, 128, 160)], ids=lambda v: "x".join(str(i) for i in v))
+def test_persistent_base_pass_matches_the_per_tile_kernel(shape):
+    """ENDO_OPT_WINO_DGRAD = 3 (round 6, default): the fused base-channel data gradient of a dense block runs as persistent blocks that walk
+    a run of 32 x 8 tiles (csrc/dgrad_wino3p_kernels.h: dY maps by 16-byte LDS-DMA refilled layer by layer for the next tile, counted
+    waits, per-tile flush of the BN-backward sums) instead of one block per tile (= 1, csrc/dgrad_wino3_kernels.h), and for the last up block
+    it also forms the final convolution's weight gradient of the 144 base channels (final_bwd_weight_kernel reads the other 48).  Same
+    arithmetic per pixel; sums are added up in another order.  Bounds as for the persistent new-map passes: 5e-5 of each tensor's maximum
+    with a floor of 1e-2 of the largest gradient for the tensors whose true gradient is zero.  The Winograd forms are forced on
+    (ENDO_OPT_WINO_MIN_TILES = 1) so that the kernel runs at these sizes: blocks with 48, 96 and 144 base channels take it (odd and even
+    group counts), the 192-channel block keeps the per-tile kernel in both runs.  3 x 96 x 160: runs that cross the samples of a group;
+    8 x 128 x 160: several tiles per block (320 tiles per group on 128 blocks)."""
+    n, h, w = shape
+    rng = np.random.default_rng(31)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    results = []
+    for form in (3, 1):
+        with kernel_options({OPT_WINO_MIN_TILES: 1}):
+            _, model = make_model(68)
+        model.set_kernel_option(OPT_WINO_DGRAD, form)
+        model.train()
+        y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+        ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+        torch.cuda.synchronize()
+        results.append({nm: p.grad.detach().clone() for nm, p in model.named_parameters()})
+    ga, gb = results
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    rows = []
+    for nm in ga:
+        assert torch.isfinite(ga[nm]).all(), nm
+        scale = max(float(gb[nm].abs().max()), 1e-2 * gmax)
+        rows.append((float((ga[nm] - gb[nm]).abs().max()) / scale, nm, float(gb[nm].abs().max())))
+    rows.sort(reverse=True)
+    worst = rows[0][0]
+    fin = [r for r in rows if r[1] == "finalConv.weight"]
+    assert worst <= 5e-5, "gradients differ between the persistent and the per-tile base pass: " + "; ".join("%s %.2e (max %.2e)" % (nm, d, mx) for d, nm, mx in rows[:6])
+    print("persistent vs per-tile base pass %s: worst gradient difference %.2e of the tensor's maximum; final convolution's weight %.2e" % (
+        shape, worst, fin[0][0] if fin else float("nan")))
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])
 def test_wgrad_overlap_is_transparent(shape):
     """endo_net_bwd runs the weight gradients on a side stream, overlapped with the data-gradient chain.

@@ -11,6 +11,7 @@
 
 #include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_wino_kernels.h"
 #include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_wino3_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/dgrad_wino3p_kernels.h"
 
 using namespace endo;
 
@@ -32,7 +33,7 @@ struct Variant { std::string name; std::function<int(hipStream_t)> run; };
 
 static void bench(std::vector<Variant>& vs, float* out, size_t out_n, double* scratch, size_t scratch_n, double flops) {
     std::vector<float> ref, cur(out_n);
-    std::vector<double> sref, scur(scratch_n);
+    std::vector<double> sref, scur, sraw(scratch_n);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     for (auto& v : vs) {
         CK(hipMemset(out, 0, out_n * sizeof(float)));
@@ -42,11 +43,17 @@ static void bench(std::vector<Variant>& vs, float* out, size_t out_n, double* sc
         hipError_t e = hipDeviceSynchronize();
         if (e != hipSuccess) { printf("%-52s FAILED: %s\n", v.name.c_str(), hipGetErrorString(e)); exit(1); }
         CK(hipMemcpy(cur.data(), out, out_n * sizeof(float), hipMemcpyDeviceToHost));
-        CK(hipMemcpy(scur.data(), scratch, scratch_n * sizeof(double), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(sraw.data(), scratch, scratch_n * sizeof(double), hipMemcpyDeviceToHost));
         double maxdiff = 0, maxref = 0, sdiff = 0, smax = 0;
+        {   // the BN sums: [layer][slot copy][value] -> add the copies up
+            const size_t per_layer = scratch_n / 4, per_copy = per_layer / kBnSlots;
+            std::vector<double> folded(4 * per_copy, 0.0);
+            for (int l = 0; l < 4; ++l) for (int c = 0; c < kBnSlots; ++c) for (size_t i = 0; i < per_copy; ++i) folded[l * per_copy + i] += sraw[l * per_layer + c * per_copy + i];
+            scur = folded;
+        }
         if (ref.empty()) { ref = cur; sref = scur; }
         for (size_t i = 0; i < out_n; ++i) { maxdiff = fmax(maxdiff, fabs((double)cur[i] - ref[i])); maxref = fmax(maxref, fabs((double)ref[i])); }
-        for (size_t i = 0; i < scratch_n; ++i) { sdiff = fmax(sdiff, fabs(scur[i] - sref[i])); smax = fmax(smax, fabs(sref[i])); }
+        for (size_t i = 0; i < sref.size(); ++i) { sdiff = fmax(sdiff, fabs(scur[i] - sref[i])); smax = fmax(smax, fabs(sref[i])); }
         for (int i = 0; i < 3; ++i) v.run(0);
         CK(hipDeviceSynchronize());
         const int reps = 10;
@@ -70,7 +77,7 @@ int main(int argc, char** argv) {
     const int n = argc > 2 ? atoi(argv[2]) : 16;
     const int h = argc > 3 ? atoi(argv[3]) : 256;
     const int w = argc > 4 ? atoi(argv[4]) : 320;
-    const int mode = argc > 5 ? atoi(argv[5]) : 0;          // 0 = everything, 1 = product candidates only
+    int mode = argc > 5 ? atoi(argv[5]) : 0;          // 0 = everything, 1 = product candidates only, 2 = direct / wino3 / persistent forms compared over ALL samples
     const int64_t plane = (int64_t)h * w;
     const int cin_last = c0 + 36;
     printf("dense block base pass: N=%d %dx%d C0=%d, 4 layers x 12 dY maps\n", n, h, w, c0);
@@ -121,6 +128,65 @@ int main(int argc, char** argv) {
     vs.push_back({"dgrad_block8<4> direct (reference values)", [&](hipStream_t s) { return launch_dgrad_block8<4>(p, s); }});
     vs.push_back({"dgrad_wino8<4> (round-2 library)", [&](hipStream_t s) { return launch_dgrad_wino8<4>(p, u, s); }});
     vs.push_back({"dgrad_wino3<4> (library)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 0>(p, u1, s); }});
+    // persistent blocks (dgrad_wino3p_kernels.h): one block per CU walking a run of tiles
+    int cus = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus = prop.multiProcessorCount; }
+    vs.push_back({"dgrad_wino3p<4> persistent, one block per CU", [&](hipStream_t s) { return launch_dgrad_wino3p<4, false, 0>(p, u1, cus, nullptr, nullptr, s); }});
+    vs.push_back({"wino3p no atomics (4)", [&](hipStream_t s) { return launch_dgrad_wino3p<4, false, 4>(p, u1, cus, nullptr, nullptr, s); }});
+    vs.push_back({"wino3p no dY tile loads (8)", [&](hipStream_t s) { return launch_dgrad_wino3p<4, false, 8>(p, u1, cus, nullptr, nullptr, s); }});
+    vs.push_back({"wino3p no mem (15)", [&](hipStream_t s) { return launch_dgrad_wino3p<4, false, 15>(p, u1, cus, nullptr, nullptr, s); }});
+    if (mode == 5 || mode == 6) {
+        // phase lengths of the persistent kernel: block 0 stamps the clock behind every barrier of its third tile (EXP 16); mode 6: old gradient from the buffer
+        if (mode == 6) p.acc_from = 0;
+        unsigned long long* dbg; CK(hipMalloc(&dbg, 128 * 8)); CK(hipMemset(dbg, 0, 128 * 8));
+        auto dump = [&](const char* name) {
+            CK(hipDeviceSynchronize());
+            unsigned long long h[128]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            printf("%s\n", name);
+            for (int w = 0; w < 2; ++w) {
+                printf("  worker %d, cycles between barriers:", w);
+                for (int i = 1; i < 64 && h[w * 64 + i]; ++i) printf(" %llu", h[w * 64 + i] - h[w * 64 + i - 1]);
+                int last = 0; for (int i = 0; i < 64 && h[w * 64 + i]; ++i) last = i;
+                printf("  | total %llu over %d intervals\n", h[w * 64 + last] - h[w * 64], last);
+            }
+        };
+        CK(hipMemset(p.out, 0, (size_t)n * c0 * plane * sizeof(float)));
+        launch_dgrad_wino3p<4, false, 16>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, full");
+        launch_dgrad_wino3p<4, false, 16 + 8>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, no dY tile loads");
+        launch_dgrad_wino3p<4, false, 16 + 4>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, no sums");
+        launch_dgrad_wino3p<4, false, 16 + 1>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, no x / gradient loads");
+        launch_dgrad_wino3p<4, false, 16 + 2>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, no stores");
+        launch_dgrad_wino3p<4, false, 16 + 15>(p, u1, cus, reinterpret_cast<double*>(dbg), nullptr, 0); dump("persistent, no mem");
+        return 0;
+    }
+    if (mode == 4) { p.acc_from = 0; mode = 2; }          // the gradient buffer's content is the old gradient (zeroed before the compared run)
+    if (mode == 2) { vs.erase(vs.begin() + 1, vs.begin() + 2); bench(vs, p.out, (size_t)n * c0 * plane, scratch, scratch_n, flops); return 0; }
+    if (mode == 3) {
+        // the virtual final gradient (old gradient = g * vw[channel]) and, in the persistent kernel, the final convolution's weight gradient sum g * x
+        float* vg = dev_random((size_t)n * plane, -1.f, 1.f, 11);
+        float* vw = dev_random(c0, -1.f, 1.f, 12);
+        DgradBlockParams pv = p; pv.vg = vg; pv.vw = vw; pv.acc_from = 0;
+        double* fwp; CK(hipMalloc(&fwp, (size_t)cus * c0 * sizeof(double))); CK(hipMemset(fwp, 0, (size_t)cus * c0 * sizeof(double)));
+        int used = 0;
+        std::vector<Variant> v3;
+        v3.push_back({"dgrad_wino3<4> (library), virtual old gradient", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 0>(pv, u1, s); }});
+        v3.push_back({"dgrad_wino3p<4, FW> persistent, virtual old gradient", [&](hipStream_t s) { return launch_dgrad_wino3p<4, true, 0>(pv, u1, cus, fwp, &used, s); }});
+        bench(v3, p.out, (size_t)n * c0 * plane, scratch, scratch_n, flops);
+        std::vector<double> parts((size_t)used * c0);
+        CK(hipMemcpy(parts.data(), fwp, parts.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::vector<float> hx((size_t)n * c0 * plane), hg((size_t)n * plane);
+        CK(hipMemcpy(hx.data(), xbuf, hx.size() * sizeof(float), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hg.data(), vg, hg.size() * sizeof(float), hipMemcpyDeviceToHost));
+        double worst = 0, big = 0;
+        for (int c = 0; c < c0; ++c) {
+            double ref = 0, got = 0;
+            for (int s = 0; s < n; ++s) for (size_t i = 0; i < plane; ++i) ref += (double)hg[s * plane + i] * hx[((size_t)s * c0 + c) * plane + i];
+            for (int b = 0; b < used; ++b) got += parts[(size_t)b * c0 + c];
+            worst = fmax(worst, fabs(got - ref)); big = fmax(big, fabs(ref));
+        }
+        printf("final-conv weight gradient from %d block partials: max |diff| %.3e of max |ref| %.3e\n", used, worst, big);
+        return 0;
+    }
     vs.push_back({"dgrad_wino3<4> OPT16 (weight DMA at V end)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 16>(p, u1, s); }});
     vs.push_back({"dgrad_wino3<4> OPT32 (setprio 1 in M phases)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 0, 32>(p, u1, s); }});
     vs.push_back({"wino3 no dY tile load (8)", [&](hipStream_t s) { return launch_dgrad_wino3<4, 8, 0>(p, u1, s); }});
