@@ -242,7 +242,9 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 if constexpr ((EXP & 2) != 0) asm volatile("" ::"v"(src[r][hh][0]), "v"(src[r][hh][1]), "v"(src[r][hh][2]), "v"(src[r][hh][3]));
-                else st4(src[r][hh], orr, vlane + 16u * hh, soff(tile_b, gq, r));
+                // (offset all in the vector register: behind a 16-byte store with a SCALAR offset register the compiler inserts no wait state before
+                // a VALU write of the data registers -- td_dgrad_kernels.h lost the first dword of 0.1 % of such stores)
+                else st4(src[r][hh], orr, vlane + 16u * hh + soff(tile_b, gq, r), 0u);
             }
     };
 

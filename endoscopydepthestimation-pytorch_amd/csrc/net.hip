@@ -20,6 +20,7 @@
 #include "dgrad_kernels.h"
 #include "dgrad_block_kernels.h"
 #include "dgrad_newmap_kernels.h"
+#include "td_dgrad_kernels.h"
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
@@ -661,7 +662,8 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
 //                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h), 3 (default) = 1 as persistent blocks where that form applies
 //                            (dgrad_wino3p_kernels.h: at most 144 base channels), the per-tile kernel elsewhere
-//   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 (default) = persistent blocks (dgrad_newmap_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
+//   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 = persistent blocks (dgrad_newmap_kernels.h), 3 (default) = 2 and the transition-down data gradient as
+//                            persistent blocks too (td_dgrad_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
 //                            DMA of the gradient tiles (dgrad_block_kernels.h)
 //   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
 //   ENDO_OPT_WINO_MIN_TILES  a Winograd kernel is used from this many tiles per launch on (default 1024: the levels whose launches fill
@@ -673,7 +675,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
     opt[ENDO_OPT_WINO_DGRAD] = 3;
-    opt[ENDO_OPT_DGRAD_VEC] = 2;
+    opt[ENDO_OPT_DGRAD_VEC] = 3;
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
     opt[ENDO_OPT_MFMA_BF16] = 0;
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
@@ -1186,6 +1188,10 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         p.acc_from = 0;
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
+        // levels 0 / 1 of configs[1] (96 / 144 channels, whole 32 x 8 tiles): persistent blocks, weights LDS-resident, 16-byte DMA (td_dgrad_kernels.h)
+        if (c.net->opt[ENDO_OPT_DGRAD_VEC] >= 3 && !mfma_bf16_dgrad(c) && td_dgrad_ok(p))
+            rc = launch_td_dgrad(p, c.net->cus, c.stream);
+        else
         rc = (nx.w % 4 == 0) ? (mfma_bf16_dgrad(c) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4, 2, 1, 1>(p, c.stream)
                                                   : launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream))
                              : launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream);

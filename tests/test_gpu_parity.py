@@ -1089,6 +1089,41 @@ def test_persistent_base_pass_matches_the_per_tile_kernel(shape):
         shape, worst, fin[0][0] if fin else float("nan")))
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 96, 160), (8, 128, 160)], ids=lambda v: "x".join(str(i) for i in v))
+def test_persistent_transition_down_dgrad_matches_the_per_tile_kernel(shape):
+    """ENDO_OPT_DGRAD_VEC = 3 (round 6, default): the data gradient of the transition-down layers with 96 / 144 channels (levels 0 / 1) runs
+    as persistent blocks (csrc/td_dgrad_kernels.h: weights LDS-resident, pooled gradient + argmax codes by 16-byte DMA through a swizzled
+    source, x / old gradient requested ahead of a pass's MFMAs) where the level has whole 32 x 8 tiles, instead of one block per
+    (tile, 32 output channels) (= 2, conv_dma_kernel<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN>).  Same products per pixel in the same k order;
+    BN-backward sums in another order.  Bounds as for the other persistent forms.  64 x 96: level 0 only (level 1 is 32 x 48: a partial
+    tile, per-tile kernel in both runs); 96 x 160 and 128 x 160: level 0 (96 channels, two tile buffers) and, at 128 x 160, level 1
+    (144 channels, one buffer: 64 x 80 has partial tiles -- per-tile kernel)."""
+    n, h, w = shape
+    rng = np.random.default_rng(37)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
+    results = []
+    for form in (3, 2):
+        _, model = make_model(69)
+        model.set_kernel_option(OPT_DGRAD_VEC, form)
+        model.train()
+        y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+        ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
+        torch.cuda.synchronize()
+        results.append({nm: p.grad.detach().clone() for nm, p in model.named_parameters()})
+    ga, gb = results
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    rows = []
+    for nm in ga:
+        assert torch.isfinite(ga[nm]).all(), nm
+        scale = max(float(gb[nm].abs().max()), 1e-2 * gmax)
+        rows.append((float((ga[nm] - gb[nm]).abs().max()) / scale, nm, float(gb[nm].abs().max())))
+    rows.sort(reverse=True)
+    worst = rows[0][0]
+    assert worst <= 5e-5, "gradients differ between the persistent and the per-tile transition-down data gradient: " + "; ".join("%s %.2e (max %.2e)" % (nm, d, mx) for d, nm, mx in rows[:6])
+    print("persistent vs per-tile transition-down data gradient %s: worst gradient difference %.2e of the tensor's maximum" % (shape, worst))
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])
 def test_wgrad_overlap_is_transparent(shape):
     """endo_net_bwd runs the weight gradients on a side stream, overlapped with the data-gradient chain.
