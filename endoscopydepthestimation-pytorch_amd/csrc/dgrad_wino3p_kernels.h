@@ -64,9 +64,10 @@ struct DgradWino3PGeom {
     static constexpr int kG = NL * 12 * kCS;
     static constexpr int kMaxGroupSlots = kMaxCount / 32 + 1;           // per worker: its whole groups + the split group
     static constexpr int kFw = 2 * kMaxGroupSlots * 4 * 16;             // [worker][group slot][wave][16]
+    static constexpr int kFw64 = 2 * kMaxCount;                          // FW: the block's running sums, one double per channel (owned by thread = channel)
     static constexpr int kTouch = 256;                                  // dummy target of the x touches (4 dword DMAs)
     static constexpr int kDbg = 2 * 64 * 2;                             // EXP & 16: barrier time stamps of one tile, [worker][64] x 8 bytes
-    static constexpr int kFloats = kG + 4 * kU + NL * kMaxCount * 4 + 2 * kMaxSteps * kRedStep + kFw + kDbg + kTouch;
+    static constexpr int kFloats = kG + 4 * kU + NL * kMaxCount * 4 + 2 * kMaxSteps * kRedStep + kFw + kDbg + kTouch + kFw64;
     static constexpr size_t kBytes = sizeof(float) * kFloats;
     static constexpr int kFlushTiles = 4;                               // the final-conv weight sums leave the block every this many tiles (fp32 in between)
     static_assert(kBytes <= 160 * 1024, "one block per CU");
@@ -115,6 +116,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
     const int g_first = wk;                          // p.count >= 32: every worker has at least one whole group
     unsigned long long* s_dbg = reinterpret_cast<unsigned long long*>(s_fw + G::kFw);
     float* s_touch = s_fw + G::kFw + G::kDbg;
+    double* s_fw64 = reinterpret_cast<double*>(s_touch + G::kTouch);
     int dbg_i = 0;
     bool dbg_on = false;
     auto stamp = [&]() {
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
     }
     for (int i = tid; i < 2 * G::kMaxSteps * G::kRedStep + G::kFw; i += G::kThreads) s_red[i] = 0.f;
     if constexpr (FW) {
-        for (int i = tid; i < p.count; i += G::kThreads) fw_parts[static_cast<int64_t>(blockIdx.x) * p.count + i] = 0.0;
+        for (int i = tid; i < p.count; i += G::kThreads) { fw_parts[static_cast<int64_t>(blockIdx.x) * p.count + i] = 0.0; s_fw64[i] = 0.0; }
     }
     if (t_begin >= t_end) return;          // (never with bpg <= tiles per group; block-uniform)
 
@@ -645,7 +647,9 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
                     float* a = s_fw + (w * G::kMaxGroupSlots + gslot) * 64 + j;
                     const double v = static_cast<double>(a[0]) + static_cast<double>(a[16]) + static_cast<double>(a[32]) + static_cast<double>(a[48]);
                     a[0] = 0.f; a[16] = 0.f; a[32] = 0.f; a[48] = 0.f;
-                    fw_parts[static_cast<int64_t>(blockIdx.x) * p.count + i] += v;
+                    const double run = s_fw64[i] + v;          // (thread i owns channel i: no atomics; the block's partial leaves once, behind its last tile)
+                    s_fw64[i] = run;
+                    if (!has_next_tile) fw_parts[static_cast<int64_t>(blockIdx.x) * p.count + i] = run;
                 }
             }
         }

@@ -568,13 +568,13 @@ __global__ void __launch_bounds__(256) final_bwd_weight_kernel(const float* __re
     }
 }
 
-// dW_final[c] += sum over the persistent base pass's blocks of its partial (fixed order, fp64)
+// dW_final[c] += sum over the persistent base pass's blocks of its partial: one wave per channel, fixed order (fp64)
 __global__ void __launch_bounds__(64) final_w_reduce_kernel(const double* __restrict__ parts, int nblocks, int count, float* __restrict__ gw) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= count) return;
+    const int c = blockIdx.x;
     double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += parts[static_cast<int64_t>(b) * count + c];
-    atomicAdd(gw + c, static_cast<float>(t));
+    for (int b = threadIdx.x; b < nblocks; b += 64) t += parts[static_cast<int64_t>(b) * count + c];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) atomicAdd(gw + c, static_cast<float>(t));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1125,7 +1125,7 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                 int used = 0;
                 rc = run_dgrad_wino3p_nl4(p, u, c.net->cus < kFwPartBlocks ? c.net->cus : kFwPartBlocks, fwp, &used, c.stream);
                 if (rc == 0 && fwp) {
-                    final_w_reduce_kernel<<<(c0 + 63) / 64, 64, 0, c.stream>>>(fwp, used, c0, fv->gw + ic0);
+                    final_w_reduce_kernel<<<c0, 64, 0, c.stream>>>(fwp, used, c0, fv->gw + ic0);
                     ENDO_LAUNCH_CHECK();
                 }
             } else {
@@ -1191,6 +1191,10 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         // levels 0 / 1 of configs[1] (96 / 144 channels, whole 32 x 8 tiles): persistent blocks, weights LDS-resident, 16-byte DMA (td_dgrad_kernels.h)
         if (c.net->opt[ENDO_OPT_DGRAD_VEC] >= 3 && !mfma_bf16_dgrad(c) && td_dgrad_ok(p))
             rc = launch_td_dgrad(p, c.net->cus, c.stream);
+        else if (c.net->opt[ENDO_OPT_DGRAD_VEC] >= 3 && !mfma_bf16_dgrad(c) && nx.w % 4 != 0 && td_dgrad_small_ok(p))
+            // pooled rows without whole code dwords (level 4 of configs[1]: 8 x 10): 128-pixel runs, the routed gradient expanded on its way into
+            // LDS -- 46 instead of the register-staged kernel's 100 us.  (At levels 2 / 3 the LDS-DMA kernel stays: 103 / 63 against 139 / 69 us, tools/td_bench)
+            rc = launch_td_dgrad_small(p, c.stream);
         else
         rc = (nx.w % 4 == 0) ? (mfma_bf16_dgrad(c) ? launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4, 2, 1, 1>(p, c.stream)
                                                   : launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, c.stream))

@@ -302,4 +302,154 @@ inline int launch_td_dgrad(const ConvParams& p, int blocks, hipStream_t stream) 
     return p.cin == 96 ? launch_td_dgrad_t<96>(p, blocks, stream) : launch_td_dgrad_t<144>(p, blocks, stream);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same function at the coarse levels (64 x 80 ... 16 x 20 pixels, 192 ... 288 channels), where conv_dma_kernel<1, 16, 2, IN_UNPOOL>
+// is a chain of 12 - 18 K-chunks per block that waits for dword LDS-DMA (140 / 63 us at levels 2 / 3 in the step) and, at level 4 -- the
+// pooled rows are 10 bytes of codes: no whole dwords -- the register-staged conv_mfma_kernel takes 119 us for 0.85 GFLOP.
+// Here a block owns 128 consecutive pixels of a sample's plane (any width that is a multiple of 4: rows are not tiles) x 48 output
+// channels; a K-chunk of 16 pooled-gradient channels is EXPANDED on its way into LDS -- thread (pixel, channel) loads the pooled value and
+// its argmax byte and stores the routed value U[o][p] -- so the K loop is plain fragment reads; loads of chunk k + 1 are in registers while
+// chunk k is multiplied; x and the old gradient are requested before the K loop as in td_dgrad_kernel.
+constexpr int kTdsPix = 128, kTdsN = 48, kTdsKC = 16;
+constexpr int kTdsUS = kTdsPix + 16;          // U row stride == 16 (mod 32) dwords: the two k-lanes of a 32-lane pass read disjoint bank halves
+
+__global__ void __launch_bounds__(256) td_dgrad_small_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float s_u[2][kTdsKC * kTdsUS];
+    __shared__ __attribute__((aligned(16))) float s_w[2][kTdsKC * kTdsN];
+    __shared__ float s_sum[4][kTdsN][2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lk = lane >> 4;
+    const int plane = p.h * p.w;
+    const int P0 = blockIdx.x * kTdsPix;
+    const int c0 = blockIdx.y * kTdsN;
+    const int grp = p.group_n > 0 ? blockIdx.z / p.group_n : 0;
+    const int n = blockIdx.z - grp * p.group_n;
+    const int64_t grp_off = grp * p.gs;
+    const float* dy_n = p.in + grp_off + static_cast<int64_t>(n) * p.in_ns;
+    const uint8_t* idx_n = p.in_idx + 4 * grp_off + static_cast<int64_t>(n) * p.idx_ns;
+    const float* x_n = p.x + grp_off + static_cast<int64_t>(n) * p.x_ns;
+    float* out_n = p.out + grp_off + static_cast<int64_t>(n) * p.out_ns;
+
+    // ---- staging role: pixel P0 + (tid & 127), channels (tid >> 7) + 2 i of a chunk ----
+    const int sp = P0 + (tid & 127);
+    const bool sp_ok = sp < plane;
+    const int sy = sp_ok ? sp / p.w : 0, sx = sp_ok ? sp - sy * p.w : 0;
+    const int spp = (sy >> 1) * p.in_w + (sx >> 1);
+    const unsigned swant = 2u * (sy & 1) + (sx & 1);
+    float rg[8]; unsigned rc[8]; float rw[3];
+    const int nchunks = p.cin / kTdsKC;
+    auto fetch = [&](int chunk) {
+        const int o0 = chunk * kTdsKC + (tid >> 7);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int64_t off = static_cast<int64_t>(o0 + 2 * i) * p.in_cs + spp;
+            rg[i] = sp_ok ? dy_n[off] : 0.f;
+            rc[i] = sp_ok ? idx_n[off] : 255u;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = tid + 256 * i, o = e / kTdsN, c = e - o * kTdsN;
+            rw[i] = p.wgt[static_cast<int64_t>(chunk * kTdsKC + o) * p.w_cin + c0 + c];
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s_u[buf][((tid >> 7) + 2 * i) * kTdsUS + (tid & 127)] = rc[i] == swant ? rg[i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) s_w[buf][tid + 256 * i] = rw[i];
+    };
+
+    // ---- the lane's output pixels: row tile 2 wave + tt, pixels 4 lk .. 4 lk + 3; channels c0 + 16 nt + li ----
+    f32x4 xv[2][3], ov[2][3];
+    bool px_ok[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int pp = P0 + (2 * wave + tt) * 16 + 4 * lk;
+        px_ok[tt] = pp < plane;          // (plane % 4 == 0: a quad is all in or all out)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) {
+            const int64_t o = static_cast<int64_t>(c0 + nt * 16 + li) * p.out_cs + pp;
+            xv[tt][nt] = px_ok[tt] ? *reinterpret_cast<const f32x4*>(x_n + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+            ov[tt][nt] = px_ok[tt] ? *reinterpret_cast<const f32x4*>(out_n + o) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    f32x4 acc[2][3];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        if (chunk + 1 < nchunks) fetch(chunk + 1);
+#pragma unroll
+        for (int ks = 0; ks < kTdsKC / 4; ++ks) {
+            float a[2], b[3];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) a[tt] = s_u[buf][(4 * ks + lk) * kTdsUS + (2 * wave + tt) * 16 + li];
+#pragma unroll
+            for (int nt = 0; nt < 3; ++nt) b[nt] = s_w[buf][(4 * ks + lk) * kTdsN + nt * 16 + li];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int nt = 0; nt < 3; ++nt) acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], b[nt], acc[tt][nt], 0, 0, 0);
+        }
+        if (chunk + 1 < nchunks) stash(buf ^ 1);          // (the other buffer: its readers passed the barrier that ended chunk - 1)
+        __syncthreads();
+    }
+    // ---- epilogue: ReLU mask, BN backward, read-modify-write, sums (td_dgrad_kernel's, pixel quads outside the plane skipped) ----
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+        const int co = c0 + nt * 16 + li;
+        const float mean = p.bn_saved[grp_off + 2 * co], rstd = p.bn_saved[grp_off + 2 * co + 1];
+        const float scale = p.bn_gamma[co] * rstd, beta = p.bn_beta[co];
+        const bool accumulate = co >= p.acc_from;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            if (!px_ok[tt]) continue;
+            f32x4 o = ov[tt][nt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xc = xv[tt][nt][e] - mean;
+                const float z = fmaf(xc, scale, beta);
+                const float dz = z > 0.f ? acc[tt][nt][e] : 0.f;
+                s1 += dz;
+                s2 += dz * (xc * rstd);
+                o[e] = (accumulate ? o[e] : 0.f) + scale * dz;
+            }
+            *reinterpret_cast<f32x4*>(out_n + static_cast<int64_t>(co) * p.out_cs + P0 + (2 * wave + tt) * 16 + 4 * lk) = o;
+        }
+        s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (lk == 0) { s_sum[wave][nt * 16 + li][0] = s1; s_sum[wave][nt * 16 + li][1] = s2; }
+    }
+    __syncthreads();
+    if (tid < 2 * kTdsN) {
+        const int j = tid >> 1, which = tid & 1;
+        const double t = static_cast<double>(s_sum[0][j][which]) + static_cast<double>(s_sum[1][j][which]) + static_cast<double>(s_sum[2][j][which]) +
+                         static_cast<double>(s_sum[3][j][which]);
+        atomicAdd(p.bn_scratch + grp_off / 2 + bn_slot_offset(p.bn_slot_stride) + 2 * (c0 + j) + which, t);
+    }
+}
+
+inline bool td_dgrad_small_ok(const ConvParams& p) {
+    return p.cin == p.cout && p.w_cin == p.cin && (p.cin % kTdsN) == 0 && (p.w % 4) == 0 && (p.h % 2) == 0 && p.in_w == p.w / 2 && p.out_w == p.w &&
+           p.out_cs == p.h * p.w && p.x_cs == p.out_cs && (p.out_cs % 4) == 0 && (p.out_ns % 4) == 0 && (p.x_ns % 4) == 0 && p.ksplit == 0 &&
+           (reinterpret_cast<uintptr_t>(p.out) % 16) == 0 && (reinterpret_cast<uintptr_t>(p.x) % 16) == 0;
+}
+
+inline int launch_td_dgrad_small(const ConvParams& p, hipStream_t stream) {
+    if (!td_dgrad_small_ok(p)) return ENDO_E_UNSUPPORTED;
+    td_dgrad_small_kernel<<<dim3((p.h * p.w + kTdsPix - 1) / kTdsPix, p.cout / kTdsN, p.n), 256, 0, stream>>>(p);
+    ENDO_LAUNCH_CHECK();
+    return 0;
+}
+
 }  // namespace endo

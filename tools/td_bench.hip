@@ -43,8 +43,10 @@ int main(int argc, char** argv) {
     int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus = prop.multiProcessorCount; }
     struct V { std::string name; std::function<int()> run; };
     std::vector<V> vs;
-    vs.push_back({"conv_dma<1,16,2,UNPOOL,DGRAD_BN> (per tile)", [&]() { return launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, 0); }});
-    vs.push_back({"td_dgrad persistent, one block per CU", [&]() { return launch_td_dgrad(p, cus, 0); }});
+    if ((w / 2) % 4 == 0) vs.push_back({"conv_dma<1,16,2,UNPOOL,DGRAD_BN> (per tile)", [&]() { return launch_conv_dma_auto<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, 0); }});
+    else vs.push_back({"conv_mfma<1,16,3,UNPOOL,DGRAD_BN> (register-staged)", [&]() { return launch_conv_auto<1, 16, 3, IN_UNPOOL, EPI_DGRAD_BN, 4>(p, 0); }});
+    if (td_dgrad_ok(p)) vs.push_back({"td_dgrad persistent, one block per CU", [&]() { return launch_td_dgrad(p, cus, 0); }});
+    if (td_dgrad_small_ok(p)) vs.push_back({"td_dgrad_small (128-pixel runs, expanded chunks)", [&]() { return launch_td_dgrad_small(p, 0); }});
     std::vector<float> ref, cur(hx.size());
     std::vector<double> sref, sraw(scr_n);
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
