@@ -21,6 +21,7 @@
 #include "dgrad_block_kernels.h"
 #include "dgrad_newmap_kernels.h"
 #include "td_dgrad_kernels.h"
+#include "td_fwd_kernels.h"
 #include "wgrad_taps_kernels.h"
 #include "wgrad1x1_kernels.h"
 #include "wgrad_nsplit_kernels.h"
@@ -662,8 +663,7 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_WINO_DGRAD      fused base-channel data gradient at the fine levels: 0 = direct, 1 = Winograd, phase-skewed (dgrad_wino3_kernels.h),
 //                            2 = Winograd, round-2 kernel (dgrad_wino_kernels.h), 3 (default) = 1 as persistent blocks where that form applies
 //                            (dgrad_wino3p_kernels.h: at most 144 base channels), the per-tile kernel elsewhere
-//   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 = persistent blocks (dgrad_newmap_kernels.h), 3 (default) = 2 and the transition-down data gradient as
-//                            persistent blocks too (td_dgrad_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
+//   ENDO_OPT_DGRAD_VEC       new-channel passes: 2 (default) = persistent blocks (dgrad_newmap_kernels.h), 1 / 0 = one block per tile with 16-byte / dword
 //                            DMA of the gradient tiles (dgrad_block_kernels.h)
 //   ENDO_OPT_MFMA_BF16       1 = bf16 MFMA operands in the dense layers' kernels (a different function: DESIGN.md 4.10)
 //   ENDO_OPT_WINO_MIN_TILES  a Winograd kernel is used from this many tiles per launch on (default 1024: the levels whose launches fill
@@ -672,16 +672,18 @@ static double conv_flops(const endo_net* net, int level, int cin, int cout, int 
 //   ENDO_OPT_WGRAD_OVERLAP   1 = weight gradients on the side stream, 0 = in line on the caller's stream
 //   ENDO_OPT_WGRAD_F34       1 = dense weight gradients of the fine levels in the Winograd domain F(3x3, 4x4) (wgrad_f34_kernels.h)
 //   ENDO_OPT_FINAL_VIRTUAL   1 = the final convolution's data gradient is not written out: the last up block's kernels form g * w[c] (FinalVirt)
+//   ENDO_OPT_TD_PERSIST      transition-down layers as persistent blocks: bit 0 the data gradient (td_dgrad_kernels.h), bit 1 the forward (td_fwd_kernels.h)
 static void default_options(int (&opt)[ENDO_OPT_COUNT]) {
     opt[ENDO_OPT_WINO_FWD] = 5;          // F(4x4, 3x3) where its 64 x 16 blocks fill the chip (level 0 of configs[1]), F(2x2, 3x3) below: depth 5e-6 of its maximum from fp64 against the 1e-4 of the parity target
     opt[ENDO_OPT_WINO_DGRAD] = 3;
-    opt[ENDO_OPT_DGRAD_VEC] = 3;
+    opt[ENDO_OPT_DGRAD_VEC] = 2;
     opt[ENDO_OPT_WINO_MIN_TILES] = 1024;
     opt[ENDO_OPT_MFMA_BF16] = 0;
     opt[ENDO_OPT_WGRAD_OVERLAP] = 1;
     opt[ENDO_OPT_MFMA_X3] = 0;
     opt[ENDO_OPT_WGRAD_F34] = 1;
     opt[ENDO_OPT_FINAL_VIRTUAL] = 1;
+    opt[ENDO_OPT_TD_PERSIST] = 3;
 }
 static int wino_fwd_mode(const Ctx& c) { return c.net->opt[ENDO_OPT_WINO_FWD]; }
 static bool wino_fwd_enabled(const Ctx& c) { return wino_fwd_mode(c) != 0; }
@@ -837,6 +839,8 @@ static int td_fwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
     p.out_sums = c.out_sums(next, oc0);
     ProfScope prof(kProfConv1x1Pool, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin + cv.cout / 4.0));
+    // levels 0 / 1 of configs[1] (96 / 144 channels, whole 32 x 8 tiles): persistent blocks, weights LDS-resident, all output channels per tile (td_fwd_kernels.h)
+    if ((c.net->opt[ENDO_OPT_TD_PERSIST] & 2) && !mfma_bf16_fwd(c) && c.training && td_fwd_ok(p)) return launch_td_fwd(p, c.net->cus, c.stream);
     if (mfma_bf16_fwd(c)) return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 2, 1, 1>(p, c.stream);
     return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(p, c.stream);    // 32x8 tiles: -6 % in the in-job A/B (Q = 6 was 10 % slower; round 5: K-chunks of 16 channels +-0, of 32 +40 % on the family, Q = 6 with 16 +14 %)
 }
@@ -1189,9 +1193,9 @@ static int td_bwd(const Ctx& c, int level, const BnP& b, const ConvP& cv) {
         ProfScope prof(kProfDgradOther, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 1), 4.0 * c.nt() * lv.plane * 3.0 * cv.cin);
         // pooled rows of whole code dwords -> LDS-DMA kernel; otherwise the register-staged one
         // levels 0 / 1 of configs[1] (96 / 144 channels, whole 32 x 8 tiles): persistent blocks, weights LDS-resident, 16-byte DMA (td_dgrad_kernels.h)
-        if (c.net->opt[ENDO_OPT_DGRAD_VEC] >= 3 && !mfma_bf16_dgrad(c) && td_dgrad_ok(p))
+        if ((c.net->opt[ENDO_OPT_TD_PERSIST] & 1) && !mfma_bf16_dgrad(c) && td_dgrad_ok(p))
             rc = launch_td_dgrad(p, c.net->cus, c.stream);
-        else if (c.net->opt[ENDO_OPT_DGRAD_VEC] >= 3 && !mfma_bf16_dgrad(c) && nx.w % 4 != 0 && td_dgrad_small_ok(p))
+        else if ((c.net->opt[ENDO_OPT_TD_PERSIST] & 1) && !mfma_bf16_dgrad(c) && nx.w % 4 != 0 && td_dgrad_small_ok(p))
             // pooled rows without whole code dwords (level 4 of configs[1]: 8 x 10): 128-pixel runs, the routed gradient expanded on its way into
             // LDS -- 46 instead of the register-staged kernel's 100 us.  (At levels 2 / 3 the LDS-DMA kernel stays: 103 / 63 against 139 / 69 us, tools/td_bench)
             rc = launch_td_dgrad_small(p, c.stream);

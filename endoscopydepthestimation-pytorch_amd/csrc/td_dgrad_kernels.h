@@ -14,7 +14,8 @@
 //   * output channels in passes of 48 (3 MFMA column tiles; a wave owns one row of 32 pixels = 2 row tiles, 6 accumulators): the x and
 //     old-gradient values of a pass are requested BEFORE its K loop and used after it -- the HBM latency of the read-modify-write hides
 //     under the pass's MFMAs instead of ending the block;
-//   * the BN-backward sums go to per-wave LDS slots and leave per tile (fixed order over the waves, fp64 atomics), like dgrad_wino3p.
+//   * the BN-backward sums run in per-wave LDS slots over the block's tiles (fp32: 8 pixels per tile and slot) and leave once, the waves
+//     in a fixed order, one fp64 atomic per (channel, sum) and block.
 // MFMA roles as everywhere: A[i = pixel x][k = o], B[k = o][j = c]; D lands with 4 consecutive pixels per lane for c = lane & 15.
 #pragma once
 
@@ -160,17 +161,15 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
         const __amdgpu_buffer_rsrc_t xr = rsrc(x_n), orr = rsrc(out_n);
         const unsigned tile_b = 4u * static_cast<unsigned>(y0 * p.out_w + x0);
         const bool has_next = t + 1 < t_end;
-        if (G::kBufs == 2 && has_next) issue_tile(t + 1, buf ^ 1);          // lands while this tile is computed
-        // this tile's DMA has landed: everything but the kBufs == 2 prefetch just issued (C / 4 + C / 16 instructions over 8 waves)
-        if (G::kBufs == 2 && has_next) {
-            constexpr int kMine = (C / 4 + 7) / 8 + (C / 16 + 7) / 8;          // an upper bound of this wave's share (a wave without the last one waits for more)
-            __builtin_amdgcn_s_waitcnt((kMine & 15) | 0x0070 | ((kMine >> 4) << 14));
-        } else {
-            __builtin_amdgcn_s_waitcnt(0x0070);
-        }
+        // This tile's maps have landed.  Two buffers: every wave has CONSUMED register loads younger than its DMA of this tile (the previous tile's
+        // passes; loads retire in order), so only the first tile needs a wait; the barrier publishes the maps and retires the previous tile's
+        // reads of the other buffer, which the next tile's DMA -- issued behind it -- then takes.  One buffer: the DMA went out behind the
+        // previous tile's last K loop, nothing younger has been consumed: wait for it.
+        if (G::kBufs == 1 || t == t_begin) __builtin_amdgcn_s_waitcnt(0x0070); else __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (G::kBufs == 2 && has_next) issue_tile(t + 1, buf ^ 1);          // lands while this tile is computed
         const float* s_dy = s_t + buf * G::kTileFloats;
 
 #pragma unroll 1
@@ -247,29 +246,27 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
                 // a build with them overwrote the first dword of 0.1 % of the stores; the two LDS round trips are per pass here, not per step)
                 s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
                 s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (lk == 0) {
+                if (lk == 0) {          // the wave's slot runs over the block's whole run of tiles (owned: plain read-add-write, fp32; fp64 at the end)
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<f32x2*>(s_sum + (wave * C + co) * 2) = f32x2{s1, s2};
+                    f32x2* slot = reinterpret_cast<f32x2*>(s_sum + (wave * C + co) * 2);
+                    *slot = *slot + f32x2{s1, s2};
                 }
             }
-                    // the next pass's operands become this pass's
+            // the next pass's operands become this pass's
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int nt = 0; nt < 3; ++nt) { xv[tt][nt] = xn[tt][nt]; ov[tt][nt] = on[tt][nt]; }
         }
-        // ---- the tile's sums: the 8 waves' slots in a fixed order, one fp64 atomic per (channel, sum) ----
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (tid < 2 * C) {
-            double v = 0.0;
-#pragma unroll
-            for (int wv = 0; wv < 8; ++wv) v += static_cast<double>(s_sum[wv * C * 2 + tid]);
-            atomicAdd(p.bn_scratch + grp_off / 2 + bn_slot_offset(p.bn_slot_stride) + tid, v);
-        }
         buf ^= (G::kBufs == 2) ? 1 : 0;
+    }
+    // ---- once per block: the 8 waves' slots in a fixed order, one fp64 atomic per (channel, sum) ----
+    __syncthreads();
+    if (tid < 2 * C) {
+        double v = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) v += static_cast<double>(s_sum[wv * C * 2 + tid]);
+        atomicAdd(p.bn_scratch + grp_off / 2 + bn_slot_offset(p.bn_slot_stride) + tid, v);
     }
 }
 

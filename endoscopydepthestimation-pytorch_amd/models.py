@@ -292,7 +292,7 @@ class FCDenseNet(nn.Module):
 
     # kernel-form / precision options (include/endo_hip.h ENDO_OPT_*) belong to THIS module object -- like everything else about a
     # reference module (train.py:191): they apply to every native handle it owns, present and future, and to no other model
-    _OPTION_DEFAULTS = {0: 5, 1: 1, 2: 2, 3: 1024, 4: 0, 5: 1, 6: 0, 7: 1, 8: 1}          # default_options() of csrc/net.hip
+    _OPTION_DEFAULTS = {0: 5, 1: 3, 2: 2, 3: 1024, 4: 0, 5: 1, 6: 0, 7: 1, 8: 1, 9: 3}          # default_options() of csrc/net.hip
 
     def set_kernel_option(self, option_id, value):
         """Returns the previous value."""

@@ -41,7 +41,7 @@ extern "C" {
  * 4: round 3 -- the 16-bit-storage family (endo_net16_*, endo_net16h_*, endo_bf16_*, endo_f16_*).
  * 5: round 4 -- the non-finite-loss guard moves onto the device: endo_loss_head writes a FOURTH float (the flag),
  * endo_sgd_clip_step takes a `skip_flag` device pointer; endo_net16_offset what = 7; adds endo_hsv_full. */
-#define ENDO_ABI_VERSION 5
+#define ENDO_ABI_VERSION 6
 int endo_abi_version(void);
 /* hipGetErrorString for positive codes, a fixed string for ENDO_E_* */
 const char* endo_error_string(int code);
@@ -242,7 +242,11 @@ int endo_net_groups(const endo_net* net);
  *                            layer is formed by that layer's F(4x4,3x3) launch (final_fwd_kernel reads 12 planes instead of 192), and the first
  *                            convolution's gradient preparation (G = d + P x + Q, bias gradient) is folded into its weight-gradient kernel;
  *                            0 = the separate kernels (final_bwd_data_kernel, the full final_fwd_kernel, prep_dy) as before.  Same function up
- *                            to summation order. */
+ *                            to summation order.
+ *   ENDO_OPT_TD_PERSIST      transition-down layers (models.py:56-67) with 96 / 144 channels on whole 32 x 8 tiles (levels 0 / 1 of configs[1]) as
+ *                            persistent blocks that keep the 1x1 weights in LDS: bit 0 (1) = the data gradient (csrc/td_dgrad_kernels.h; also the
+ *                            128-pixel-run kernel where the pooled rows have no whole code dwords), bit 1 (2) = the training-mode forward
+ *                            (csrc/td_fwd_kernels.h).  Default 3; 0 = the per-tile kernels (conv_dma_kernel).  Same function up to summation order. */
 #define ENDO_OPT_WINO_FWD 0
 #define ENDO_OPT_WINO_DGRAD 1
 #define ENDO_OPT_DGRAD_VEC 2
@@ -252,7 +256,8 @@ int endo_net_groups(const endo_net* net);
 #define ENDO_OPT_MFMA_X3 6
 #define ENDO_OPT_WGRAD_F34 7
 #define ENDO_OPT_FINAL_VIRTUAL 8
-#define ENDO_OPT_COUNT 9
+#define ENDO_OPT_TD_PERSIST 9
+#define ENDO_OPT_COUNT 10
 int endo_net_set_option(endo_net* net, int option_id, int value);
 int endo_net_get_option(const endo_net* net, int option_id);
 int64_t endo_net_group_stride(const endo_net* net);

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), "libendo_hip.so does not export %s" % name
     assert sorted(ea._lib.SIGNATURES) == names, "ctypes table and header disagree"
     lib = ea._lib.load()
-    assert lib.endo_abi_version() == 5          # ENDO_ABI_VERSION of include/endo_hip.h
+    assert lib.endo_abi_version() == 6          # ENDO_ABI_VERSION of include/endo_hip.h
     assert lib.endo_net_param_floats() == 1374865
     assert lib.endo_net_bn_floats() == 21168
     assert b"bad argument" in lib.endo_error_string(-1)

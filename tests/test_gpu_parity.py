@@ -975,6 +975,7 @@ def test_checkpoint_resume_matches_reference(golden):
 
 
 OPT_FINAL_VIRTUAL = 8
+OPT_TD_PERSIST = 9
 
 
 @pytest.mark.parametrize("forced", [False, True], ids=["default-forms", "winograd-forms"])
@@ -1091,7 +1092,7 @@ def test_persistent_base_pass_matches_the_per_tile_kernel(shape):
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (3, 96, 160), (8, 128, 160)], ids=lambda v: "x".join(str(i) for i in v))
 def test_persistent_transition_down_dgrad_matches_the_per_tile_kernel(shape):
-    """ENDO_OPT_DGRAD_VEC = 3 (round 6, default): the data gradient of the transition-down layers with 96 / 144 channels (levels 0 / 1) runs
+    """ENDO_OPT_TD_PERSIST bit 0 (round 6, default on): the data gradient of the transition-down layers with 96 / 144 channels (levels 0 / 1) runs
     as persistent blocks (csrc/td_dgrad_kernels.h: weights LDS-resident, pooled gradient + argmax codes by 16-byte DMA through a swizzled
     source, x / old gradient requested ahead of a pass's MFMAs) where the level has whole 32 x 8 tiles, instead of one block per
     (tile, 32 output channels) (= 2, conv_dma_kernel<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN>).  Same products per pixel in the same k order;
@@ -1103,9 +1104,9 @@ def test_persistent_transition_down_dgrad_matches_the_per_tile_kernel(shape):
     xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
     cots = [torch.from_numpy(rng.standard_normal((n, 1, h, w)).astype(np.float32)) for _ in range(2)]
     results = []
-    for form in (3, 2):
+    for form in (3, 2):          # bit 1 (the forward) on in both
         _, model = make_model(69)
-        model.set_kernel_option(OPT_DGRAD_VEC, form)
+        model.set_kernel_option(OPT_TD_PERSIST, form)
         model.train()
         y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
         ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
@@ -1122,6 +1123,32 @@ def test_persistent_transition_down_dgrad_matches_the_per_tile_kernel(shape):
     worst = rows[0][0]
     assert worst <= 5e-5, "gradients differ between the persistent and the per-tile transition-down data gradient: " + "; ".join("%s %.2e (max %.2e)" % (nm, d, mx) for d, nm, mx in rows[:6])
     print("persistent vs per-tile transition-down data gradient %s: worst gradient difference %.2e of the tensor's maximum" % (shape, worst))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 96), (3, 96, 160), (8, 128, 160)], ids=lambda v: "x".join(str(i) for i in v))
+def test_persistent_transition_down_forward_matches_the_per_tile_kernel(shape):
+    """ENDO_OPT_TD_PERSIST bit 1 (round 6, default on): the training-mode forward of the transition-down layers with 96 / 144 channels on whole
+    32 x 8 tiles runs as persistent blocks (csrc/td_fwd_kernels.h: transposed weights LDS-resident, all output channels per tile, the input
+    planes once through three LDS stages of 16-byte DMA with a swizzled source) instead of one block per (tile, 48 output channels)
+    (conv_dma_kernel<1, 8, 3, IN_BNRELU, EPI_FWD_POOL>).  The 1x1 products are summed in the same channel order (k = 0 .. C - 1 through the
+    same MFMA), so the pooled activations agree to the last bits and the depth to 1e-6 of its maximum; running statistics and the saved
+    (mean, rstd) -- written by the kernel's first blocks -- agree to 1e-6."""
+    n, h, w = shape
+    rng = np.random.default_rng(41)
+    xs = [torch.from_numpy(rng.uniform(-1, 1, (n, 3, h, w)).astype(np.float32)) for _ in range(2)]
+    outs = []
+    for form in (3, 1):
+        _, model = make_model(70)
+        model.set_kernel_option(OPT_TD_PERSIST, form)
+        model.train()
+        y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
+        torch.cuda.synchronize()
+        outs.append((y1.detach().clone(), y2.detach().clone(), {k: v.detach().clone() for k, v in model.state_dict().items() if "running" in k}))
+    (a1, a2, ra), (b1, b2, rb) = outs
+    assert_close(a1, b1, 1e-6, "depth of frame 1, persistent vs per-tile transition-down forward")
+    assert_close(a2, b2, 1e-6, "depth of frame 2, persistent vs per-tile transition-down forward")
+    for k in ra:
+        assert_close(ra[k], rb[k], 1e-6, "running statistic %s" % k)
 
 
 @pytest.mark.parametrize("shape", [(2, 64, 96), (4, 128, 160)])

@@ -1,7 +1,8 @@
 // Transition-down data-gradient microbenchmark (development tool): conv_dma_kernel<1, 16, 2, IN_UNPOOL, EPI_DGRAD_BN> (one block per tile and
 // 32 output channels) against td_dgrad_kernel (persistent blocks, td_dgrad_kernels.h); cross-checks outputs and BN-backward sums.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics tools/td_bench.hip -o tools/bin/td_bench
-//   tools/bin/td_bench [C] [n] [h] [w]      (C = 96 at level 0, 144 at level 1; h, w = the full-resolution side)
+//   tools/bin/td_bench [C] [n] [h] [w] [f]  (C = 96 at level 0, 144 at level 1; h, w = the full-resolution side; f = 1: the FORWARD kernels --
+//   conv_dma_kernel<1, 8, 3, IN_BNRELU, EPI_FWD_POOL> against td_fwd_kernel)
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -9,6 +10,7 @@
 #include <string>
 #include <functional>
 #include "../endoscopydepthestimation-pytorch_amd/csrc/td_dgrad_kernels.h"
+#include "../endoscopydepthestimation-pytorch_amd/csrc/td_fwd_kernels.h"
 using namespace endo;
 endo::ProfScope::ProfScope(int f, hipStream_t s, double, double) : family(f), stream(s), slot(nullptr) {}
 endo::ProfScope::~ProfScope() {}
@@ -40,6 +42,65 @@ int main(int argc, char** argv) {
     p.out = out; p.out_ns = (int64_t)C * plane; p.out_cs = (int)plane; p.out_w = w; p.cout = C;
     p.x = x; p.x_ns = (int64_t)C * plane; p.x_cs = (int)plane;
     p.bn_saved = saved; p.bn_gamma = gam; p.bn_beta = bet; p.bn_scratch = scr; p.bn_slot_stride = 2 * C; p.acc_from = 0;
+    if (argc > 5 && atoi(argv[5]) == 1) {
+        // ---- forward: BN (batch statistics from the sums) -> ReLU -> conv1x1 -> maxpool2 with argmax codes and output statistics ----
+        std::vector<double> hsum(2 * C);
+        for (int c = 0; c < C; ++c) { hsum[2 * c] = 0.02 * (c % 5) * n * plane; hsum[2 * c + 1] = (0.35 + 0.0004 * (c % 5) * (c % 5)) * n * plane; }
+        std::vector<float> hrun(2 * C, 0.5f), hbias(C);
+        for (auto& v : hbias) v = rnd(-0.1f, 0.1f);
+        double* insums = to_dev(hsum); float* run = to_dev(hrun); float* bias = to_dev(hbias);
+        float* savedf; CK(hipMalloc(&savedf, 2 * C * sizeof(float)));
+        float* pout; CK(hipMalloc(&pout, (size_t)n * C * pplane * sizeof(float)));
+        uint8_t* pidx; CK(hipMalloc(&pidx, (size_t)n * C * pplane));
+        double* osums; CK(hipMalloc(&osums, 2 * C * sizeof(double)));
+        ConvParams q{};
+        q.n = n; q.h = h; q.w = w;
+        q.in = x; q.in_ns = (int64_t)C * plane; q.in_cs = (int)plane; q.in_w = w; q.cin = C;
+        q.in_sums = insums; q.gamma = gam; q.beta = bet; q.running_mean = run; q.running_var = run + C; q.saved = savedf; q.count = (double)n * plane;
+        q.eps = 1e-5f; q.momentum = 0.1f; q.training = 1;
+        q.wgt = wgt; q.bias = bias; q.w_cout = C; q.w_cin = C;
+        q.out = pout; q.out_ns = (int64_t)C * pplane; q.out_cs = (int)pplane; q.out_w = w / 2; q.cout = C;
+        q.out_idx = pidx; q.idx_ns = (int64_t)C * pplane; q.out_sums = osums;
+        int cus2 = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus2 = prop.multiProcessorCount; }
+        struct V { std::string name; std::function<int()> run; };
+        std::vector<V> vs;
+        vs.push_back({"conv_dma<1,8,3,BNRELU,FWD_POOL> (per tile)", [&]() { return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(q, 0); }});
+        if (td_fwd_ok(q)) vs.push_back({"td_fwd persistent, one block per CU", [&]() { return launch_td_fwd(q, cus2, 0); }});
+        if (td_fwd_ok(q) && C == 96) {
+            vs.push_back({"td_fwd no input DMA (1)", [&]() { return launch_td_fwd_t<96, 1>(q, cus2, 0); }});
+            vs.push_back({"td_fwd no epilogue (2)", [&]() { return launch_td_fwd_t<96, 2>(q, cus2, 0); }});
+            vs.push_back({"td_fwd no MFMAs (4)", [&]() { return launch_td_fwd_t<96, 4>(q, cus2, 0); }});
+            vs.push_back({"td_fwd no BN + ReLU (8)", [&]() { return launch_td_fwd_t<96, 8>(q, cus2, 0); }});
+            vs.push_back({"td_fwd no DMA, no epilogue (3)", [&]() { return launch_td_fwd_t<96, 3>(q, cus2, 0); }});
+            vs.push_back({"td_fwd MFMAs + LDS reads only (11)", [&]() { return launch_td_fwd_t<96, 11>(q, cus2, 0); }});
+            vs.push_back({"td_fwd neither DMA, epilogue nor MFMA (7)", [&]() { return launch_td_fwd_t<96, 7>(q, cus2, 0); }});
+        }
+        std::vector<float> ref, cur((size_t)n * C * pplane);
+        std::vector<uint8_t> iref, icur((size_t)n * C * pplane);
+        std::vector<double> sref, scur(2 * C);
+        hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        const double flops = 2.0 * n * plane * C * C;
+        for (auto& v : vs) {
+            CK(hipMemset(pout, 0, cur.size() * sizeof(float))); CK(hipMemset(pidx, 0, icur.size())); CK(hipMemset(osums, 0, 2 * C * sizeof(double)));
+            CK(hipMemcpy(run, hrun.data(), 2 * C * sizeof(float), hipMemcpyHostToDevice));
+            int rc = v.run(); if (rc) { printf("%-48s launch failed rc=%d\n", v.name.c_str(), rc); continue; }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(cur.data(), pout, cur.size() * sizeof(float), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(icur.data(), pidx, icur.size(), hipMemcpyDeviceToHost));
+            CK(hipMemcpy(scur.data(), osums, 2 * C * sizeof(double), hipMemcpyDeviceToHost));
+            if (ref.empty()) { ref = cur; iref = icur; sref = scur; }
+            double md = 0, mr = 0, sd = 0, sm = 0; size_t codes = 0;
+            for (size_t i = 0; i < cur.size(); ++i) { md = fmax(md, fabs((double)cur[i] - ref[i])); mr = fmax(mr, fabs((double)ref[i])); codes += icur[i] != iref[i]; }
+            for (int i = 0; i < 2 * C; ++i) { sd = fmax(sd, fabs(scur[i] - sref[i])); sm = fmax(sm, fabs(sref[i])); }
+            for (int i = 0; i < 3; ++i) v.run();
+            CK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rr = 0; rr < 3; ++rr) { CK(hipEventRecord(a, 0)); for (int i = 0; i < 10; ++i) v.run(); CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); float ms; CK(hipEventElapsedTime(&ms, a, b)); best = fminf(best, ms / 10); }
+            printf("%-48s %8.1f us %7.1f TFLOP/s  pooled out diff %.2e / %.2e  argmax codes that differ %zu of %zu  sums diff %.2e / %.2e\n", v.name.c_str(), best * 1e3,
+                   flops / best * 1e-9, md, mr, codes, cur.size(), sd, sm);
+        }
+        return 0;
+    }
     int cus = 256; { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus = prop.multiProcessorCount; }
     struct V { std::string name; std::function<int()> run; };
     std::vector<V> vs;
