@@ -24,28 +24,34 @@
 
 namespace endo {
 
-template <int C>
+// WAVES = 8: one block per CU, a wave owns two rows x 16 pixels (2 MFMA row tiles), three LDS stages.  WAVES = 4 (C = 96 only: 77 KB of LDS): TWO
+// blocks per CU, a wave owns two rows x 32 pixels (4 row tiles), two stages -- the blocks drift apart and one's epilogue / DMA waits
+// run under the other's MFMAs (with one block per CU the phases of a tile add up: tools/td_bench's diagnostic builds)
+template <int C, int WAVES = 8>
 struct TdFwdGeom {
     static_assert(C % 16 == 0, "whole MFMA column tiles and K-chunks");
-    static constexpr int kThreads = 512;
+    static_assert(WAVES == 8 || WAVES == 4, "waves per block");
+    static constexpr int kThreads = 64 * WAVES;
+    static constexpr int kMT = 16 / WAVES;                              // MFMA row tiles per wave
+    static constexpr int kCPW = 16 / WAVES;                             // channels of a K-chunk a wave DMAs
     static constexpr int kTileX = 32, kTileY = 8;
     static constexpr int kKC = 16;                                      // input channels per K-chunk
-    static constexpr int kStages = 3;
+    static constexpr int kStages = WAVES == 8 ? 3 : 2;
     static constexpr int kChunkFloats = kKC * 256;
     static constexpr int kWS = (C % 32 == 16) ? C : C + 16;            // weight row stride == 16 (mod 32) dwords
     static constexpr int kNT = C / 16;                                  // column tiles
     static constexpr int kChunks = C / kKC;                             // K-chunks per tile
-    static constexpr int kFloats = C * kWS + kStages * kChunkFloats + 4 * C + 8 * C * 2;
+    static constexpr int kFloats = C * kWS + kStages * kChunkFloats + 4 * C + WAVES * C * 2;
     static constexpr size_t kBytes = sizeof(float) * kFloats;
-    static_assert(kBytes <= 160 * 1024, "one block per CU");
+    static_assert(kBytes <= (WAVES == 8 ? 160 : 80) * 1024, "blocks per CU");
 };
 
 // p0: the ConvParams of the per-tile launch (td_fwd).  tiles_xy = tiles per sample, gn = samples per group, bpg = blocks per group.
 // EXP: diagnostic bit mask for tools/td_bench (0 in the library; timing only): 1 = no input DMA, 2 = no epilogue (stores, statistics), 4 = no MFMAs,
 // 8 = no BN + ReLU on the fragment read
-template <int C, int EXP = 0>
-__global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int tiles_xy, int gn, int bpg) {
-    using G = TdFwdGeom<C>;
+template <int C, int WAVES = 8, int EXP = 0>
+__global__ void __launch_bounds__(64 * WAVES, 2) td_fwd_kernel(const ConvParams p0, int tiles_xy, int gn, int bpg) {
+    using G = TdFwdGeom<C, WAVES>;
     const int groups = gridDim.x / bpg;
     const int grp = blockIdx.x / bpg;
     const int r0 = blockIdx.x - grp * bpg;
@@ -59,7 +65,7 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
     float* s_w = smem;                                   // [c][kWS]: W[o][c] TRANSPOSED (a B fragment's lanes run over o: contiguous; its k-lanes over c: rows)
     float* s_x = s_w + C * G::kWS;                       // [stage][channel 16][256] (odd channels: 16-pixel halves exchanged)
     float* s_bn = s_x + G::kStages * G::kChunkFloats;    // [C][scale, mean, beta, -]: one 16-byte read per k-step
-    float* s_sum = s_bn + 4 * C;                         // [wave 8][C][2]
+    float* s_sum = s_bn + 4 * C;                         // [wave][C][2]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -82,7 +88,7 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
             *reinterpret_cast<f32x4*>(s_bn + 4 * c) = f32x4{scale, mean, beta, 0.f};
         }
     }
-    for (int i = tid; i < 8 * C * 2; i += G::kThreads) s_sum[i] = 0.f;
+    for (int i = tid; i < WAVES * C * 2; i += G::kThreads) s_sum[i] = 0.f;
     if (t_begin >= t_end) return;          // (block-uniform)
 
     auto tile_origin = [&](int t, int& n, int& x0, int& y0) {
@@ -103,19 +109,23 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
         int n, x0, y0;
         tile_origin(t, n, x0, y0);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + static_cast<int64_t>(n) * p.in_ns), 0, 0x7ffffffc, 0x00020000);
-        float* dst = s_x + (q % G::kStages) * G::kChunkFloats + (2 * wave) * 256;
-        const unsigned so = 4u * static_cast<unsigned>((ch0 + 2 * wave) * p.in_cs + y0 * p.in_w + x0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)dst, 16, src_even, so, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(dst + 256), 16, src_odd, so + 4u * static_cast<unsigned>(p.in_cs), 0, 0);
+        float* dst = s_x + (q % G::kStages) * G::kChunkFloats + (G::kCPW * wave) * 256;
+        unsigned so = 4u * static_cast<unsigned>((ch0 + G::kCPW * wave) * p.in_cs + y0 * p.in_w + x0);
+#pragma unroll
+        for (int i = 0; i < G::kCPW; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lptr_t)(dst + i * 256), 16, (i & 1) ? src_odd : src_even, so, 0, 0);
+            so += 4u * static_cast<unsigned>(p.in_cs);
+        }
     };
 
-    // ---- fragment addressing: the wave's rows 2 (wave >> 1), + 1, columns 16 (wave & 1) + li; A for row tt, channel 4 ks + lk ----
-    const int rp = wave >> 1, ch = wave & 1;
-    int a_off[2];
+    // ---- fragment addressing: row tile mt of the wave = (row 2 rp + (mt & 1), 16-pixel column half chh); A for channel 4 ks + lk ----
+    const int rp = WAVES == 8 ? wave >> 1 : wave;
+    int a_off[G::kMT];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int unit = (2 * rp + tt) * 8 + 4 * ch + (li >> 2);
-        a_off[tt] = lk * 256 + ((unit ^ (4 * (lk & 1))) * 4) + (li & 3);          // + ks * 1024
+    for (int mt = 0; mt < G::kMT; ++mt) {
+        const int chh = WAVES == 8 ? (wave & 1) : (mt >> 1);
+        const int unit = (2 * rp + (mt & 1)) * 8 + 4 * chh + (li >> 2);
+        a_off[mt] = lk * 256 + ((unit ^ (4 * (lk & 1))) * 4) + (li & 3);          // + ks * 1024
     }
 
     // statistics of the stored values: per lane over the block's whole run (fp32: 2 values per tile and column tile), reduced ONCE at the end --
@@ -124,25 +134,25 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
 #pragma unroll
     for (int nt = 0; nt < G::kNT; ++nt) { st1[nt] = 0.f; st2[nt] = 0.f; }
     issue_chunk(0);
-    if (nq > 1) issue_chunk(1);
+    if (G::kStages == 3 && nq > 1) issue_chunk(1);
     int q = 0;
     for (int t = t_begin; t < t_end; ++t) {
         int n, x0, y0;
         tile_origin(t, n, x0, y0);
-        f32x4 acc[2][G::kNT];
+        f32x4 acc[G::kMT][G::kNT];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < G::kMT; ++tt)
 #pragma unroll
             for (int nt = 0; nt < G::kNT; ++nt) acc[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
         for (int kc = 0; kc < G::kChunks; ++kc, ++q) {
-            // chunk q has landed (everything but the newest chunk's 2 DMAs of this wave); the barrier publishes it and retires the reads of
-            // chunk q - 1, whose stage chunk q + 2 then takes
-            if (q + 1 < nq) __builtin_amdgcn_s_waitcnt(0x0072); else __builtin_amdgcn_s_waitcnt(0x0070);
+            // chunk q has landed (three stages: everything but the newest chunk's DMAs of this wave); the barrier publishes it and retires the
+            // reads of chunk q - 1, whose stage the next chunk to be requested then takes
+            if (G::kStages == 3 && q + 1 < nq) __builtin_amdgcn_s_waitcnt(0x0070 | G::kCPW); else __builtin_amdgcn_s_waitcnt(0x0070);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 2 < nq) issue_chunk(q + 2);
+            if (q + G::kStages - 1 < nq) issue_chunk(q + G::kStages - 1);
             const float* sx = s_x + (q % G::kStages) * G::kChunkFloats;
             const int c0 = kc * G::kKC;
 #pragma unroll
@@ -150,14 +160,14 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
                 const int c = c0 + 4 * ks + lk;
                 const f32x4 bn = *reinterpret_cast<const f32x4*>(s_bn + 4 * c);
                 const float sc = bn[0], mn = bn[1], bt = bn[2];
-                float a[2];
+                float a[G::kMT];
 #pragma unroll
-                for (int tt = 0; tt < 2; ++tt) a[tt] = (EXP & 8) ? sx[a_off[tt] + ks * 1024] : __builtin_fmaxf(fmaf(sx[a_off[tt] + ks * 1024] - mn, sc, bt), 0.f);
+                for (int tt = 0; tt < G::kMT; ++tt) a[tt] = (EXP & 8) ? sx[a_off[tt] + ks * 1024] : __builtin_fmaxf(fmaf(sx[a_off[tt] + ks * 1024] - mn, sc, bt), 0.f);
 #pragma unroll
                 for (int nt = 0; nt < G::kNT; ++nt) {
                     const float b = s_w[c * G::kWS + nt * 16 + li];
 #pragma unroll
-                    for (int tt = 0; tt < 2; ++tt) {
+                    for (int tt = 0; tt < G::kMT; ++tt) {
                         if constexpr ((EXP & 4) != 0) acc[tt][nt][0] += a[tt] * b;
                         else acc[tt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tt], b, acc[tt][nt], 0, 0, 0);
                     }
@@ -167,39 +177,43 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
         if constexpr ((EXP & 2) != 0) {
             float keep = 0.f;
 #pragma unroll
-            for (int nt = 0; nt < G::kNT; ++nt) keep += acc[0][nt][0] + acc[1][nt][1];
+            for (int nt = 0; nt < G::kNT; ++nt) keep += acc[0][nt][0] + acc[G::kMT - 1][nt][1];
             if (keep == 123.456f) p.out[0] = keep;
             continue;
         }
-        // ---- epilogue: bias, 2x2 max-pool + argmax (the lane's 4 pixels of 2 rows = 2 windows), stores, statistics ----
+        // ---- epilogue: bias, 2x2 max-pool + argmax (per column half: the lane's 4 pixels of 2 rows = 2 windows), stores, statistics ----
         const int yp = (y0 >> 1) + rp;
-        const int xp = (x0 >> 1) + 8 * ch + 2 * lk;
         float* out_n = p.out + static_cast<int64_t>(n) * p.out_ns;
         uint8_t* idx_n = p.out_idx + static_cast<int64_t>(n) * p.idx_ns;
 #pragma unroll
-        for (int nt = 0; nt < G::kNT; ++nt) {
-            const int co = nt * 16 + li;
-            const float bias = p.bias ? p.bias[co] : 0.f;
-            float best2[2];
-            unsigned code2[2];
+        for (int hb = 0; hb < G::kMT / 2; ++hb) {
+            const int chh = WAVES == 8 ? (wave & 1) : hb;
+            const int xp = (x0 >> 1) + 8 * chh + 2 * lk;
 #pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                const int e = 2 * w2;
-                float best = acc[0][nt][e] + bias;
-                unsigned code = 0;
-                float v = acc[0][nt][e + 1] + bias;
-                if (v > best) { best = v; code = 1; }
-                v = acc[1][nt][e] + bias;
-                if (v > best) { best = v; code = 2; }
-                v = acc[1][nt][e + 1] + bias;
-                if (v > best) { best = v; code = 3; }
-                best2[w2] = best; code2[w2] = code;
-                st1[nt] += best; st2[nt] += best * best;
+            for (int nt = 0; nt < G::kNT; ++nt) {
+                const int co = nt * 16 + li;
+                const float bias = p.bias ? p.bias[co] : 0.f;
+                float best2[2];
+                unsigned code2[2];
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    const int e = 2 * w2;
+                    float best = acc[2 * hb][nt][e] + bias;
+                    unsigned code = 0;
+                    float v = acc[2 * hb][nt][e + 1] + bias;
+                    if (v > best) { best = v; code = 1; }
+                    v = acc[2 * hb + 1][nt][e] + bias;
+                    if (v > best) { best = v; code = 2; }
+                    v = acc[2 * hb + 1][nt][e + 1] + bias;
+                    if (v > best) { best = v; code = 3; }
+                    best2[w2] = best; code2[w2] = code;
+                    st1[nt] += best; st2[nt] += best * best;
+                }
+                const int64_t o = static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp;
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<f32x2*>(out_n + o) = f32x2{best2[0], best2[1]};
+                *reinterpret_cast<uint16_t*>(idx_n + o) = static_cast<uint16_t>(code2[0] | (code2[1] << 8));
             }
-            const int64_t o = static_cast<int64_t>(co) * p.out_cs + yp * p.out_w + xp;
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<f32x2*>(out_n + o) = f32x2{best2[0], best2[1]};
-            *reinterpret_cast<uint16_t*>(idx_n + o) = static_cast<uint16_t>(code2[0] | (code2[1] << 8));
         }
     }
     // ---- once per block: the statistics (rows of the wave, waves in a fixed order, one fp64 atomic per (channel, sum)) ----
@@ -215,7 +229,7 @@ __global__ void __launch_bounds__(512, 2) td_fwd_kernel(const ConvParams p0, int
         if (tid < 2 * C) {
             double v = 0.0;
 #pragma unroll
-            for (int wv = 0; wv < 8; ++wv) v += static_cast<double>(s_sum[wv * C * 2 + tid]);
+            for (int wv = 0; wv < WAVES; ++wv) v += static_cast<double>(s_sum[wv * C * 2 + tid]);
             atomicAdd(p.out_sums + tid, v);
         }
     }
@@ -229,26 +243,27 @@ inline bool td_fwd_ok(const ConvParams& p) {
            static_cast<int64_t>(p.cin) * p.in_cs * 4 < (1ll << 31);
 }
 
-template <int C, int EXP = 0>
+template <int C, int WAVES = 8, int EXP = 0>
 inline int launch_td_fwd_t(ConvParams p, int blocks, hipStream_t stream) {
-    using G = TdFwdGeom<C>;
+    using G = TdFwdGeom<C, WAVES>;
     p.tiles_x = p.w / G::kTileX;
     const int tiles_xy = p.tiles_x * (p.h / G::kTileY);
     const int groups = p.group_n > 0 ? p.n / p.group_n : 1;
     const int gn = p.group_n > 0 ? p.group_n : p.n;
-    int bpg = blocks / groups;
+    int bpg = blocks * (WAVES == 8 ? 1 : 2) / groups;          // one or two blocks per CU
     if (bpg >= 8) bpg &= ~7;
     if (bpg > tiles_xy * gn) bpg = tiles_xy * gn;
     if (bpg < 1) bpg = 1;
-    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(td_fwd_kernel<C, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::kBytes)));
-    td_fwd_kernel<C, EXP><<<dim3(bpg * groups), G::kThreads, G::kBytes, stream>>>(p, tiles_xy, gn, bpg);
+    ENDO_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(td_fwd_kernel<C, WAVES, EXP>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(G::kBytes)));
+    td_fwd_kernel<C, WAVES, EXP><<<dim3(bpg * groups), G::kThreads, G::kBytes, stream>>>(p, tiles_xy, gn, bpg);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
+// blocks = compute units of the device
 inline int launch_td_fwd(const ConvParams& p, int blocks, hipStream_t stream) {
     if (!td_fwd_ok(p)) return ENDO_E_UNSUPPORTED;
-    return p.cin == 96 ? launch_td_fwd_t<96>(p, blocks, stream) : launch_td_fwd_t<144>(p, blocks, stream);
+    return p.cin == 96 ? launch_td_fwd_t<96, 4>(p, blocks, stream) : launch_td_fwd_t<144, 8>(p, blocks, stream);
 }
 
 }  // namespace endo

@@ -67,13 +67,12 @@ int main(int argc, char** argv) {
         vs.push_back({"conv_dma<1,8,3,BNRELU,FWD_POOL> (per tile)", [&]() { return launch_conv_dma_auto<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4>(q, 0); }});
         if (td_fwd_ok(q)) vs.push_back({"td_fwd persistent, one block per CU", [&]() { return launch_td_fwd(q, cus2, 0); }});
         if (td_fwd_ok(q) && C == 96) {
-            vs.push_back({"td_fwd no input DMA (1)", [&]() { return launch_td_fwd_t<96, 1>(q, cus2, 0); }});
-            vs.push_back({"td_fwd no epilogue (2)", [&]() { return launch_td_fwd_t<96, 2>(q, cus2, 0); }});
-            vs.push_back({"td_fwd no MFMAs (4)", [&]() { return launch_td_fwd_t<96, 4>(q, cus2, 0); }});
-            vs.push_back({"td_fwd no BN + ReLU (8)", [&]() { return launch_td_fwd_t<96, 8>(q, cus2, 0); }});
-            vs.push_back({"td_fwd no DMA, no epilogue (3)", [&]() { return launch_td_fwd_t<96, 3>(q, cus2, 0); }});
-            vs.push_back({"td_fwd MFMAs + LDS reads only (11)", [&]() { return launch_td_fwd_t<96, 11>(q, cus2, 0); }});
-            vs.push_back({"td_fwd neither DMA, epilogue nor MFMA (7)", [&]() { return launch_td_fwd_t<96, 7>(q, cus2, 0); }});
+            vs.push_back({"td_fwd 8 waves, one block per CU", [&]() { return launch_td_fwd_t<96, 8>(q, cus2, 0); }});
+            vs.push_back({"td_fwd 4 waves, two blocks per CU", [&]() { return launch_td_fwd_t<96, 4>(q, cus2, 0); }});
+            vs.push_back({"td_fwd<4> no input DMA (1)", [&]() { return launch_td_fwd_t<96, 4, 1>(q, cus2, 0); }});
+            vs.push_back({"td_fwd<4> no epilogue (2)", [&]() { return launch_td_fwd_t<96, 4, 2>(q, cus2, 0); }});
+            vs.push_back({"td_fwd<4> no MFMAs (4)", [&]() { return launch_td_fwd_t<96, 4, 4>(q, cus2, 0); }});
+            vs.push_back({"td_fwd<4> MFMAs + LDS reads only (11)", [&]() { return launch_td_fwd_t<96, 4, 11>(q, cus2, 0); }});
         }
         std::vector<float> ref, cur((size_t)n * C * pplane);
         std::vector<uint8_t> iref, icur((size_t)n * C * pplane);
