@@ -495,7 +495,7 @@ def main():
     ev1.record()
     torch.cuda.synchronize()
     warp_kernel_ms = ev0.elapsed_time(ev1) / reps
-    warp_bytes = 160.0 * batch_size * height * width
+    warp_bytes = float(lib.endo_warp_consistency_bytes(batch_size, height, width))          # the library's own count (160 B per pixel of a pair)
 
     breakdown = None
     if args.breakdown and rank == 0:
@@ -570,7 +570,12 @@ def main():
                      "family_gflop_per_step": {"implied_by_timed_launches": (fl / cnt) * lps / 1e9 if cnt and lps else None,
                                                "survey": 391.8336 * (height * width) / (256.0 * 320.0) * batch_size / 8.0},
                      "algorithmic_gbs": by / ms / 1e6 if ms > 0 else None,
-                     "concurrent": True},
+                     "concurrent": True,
+                     # the dense-layer families one kernel at a time (the warm-up steps with the side stream off): ms per step and TFLOP/s
+                     "serial_families_ms_per_step": None if fam_warm is None else {
+                         lib.endo_prof_family_name(f).decode(): fam_warm[f][0] / serial_steps for f in MFMA_FAMILIES},
+                     "serial_families_tflops": None if fam_warm is None else {
+                         lib.endo_prof_family_name(f).decode(): fam_warm[f][2] / fam_warm[f][0] / 1e9 for f in MFMA_FAMILIES}},
         "roofline_serial": None if fam_warm is None else {
             "note": "stand-alone kernel durations: %d warm-up steps with the weight-gradient side stream off (ENDO_OPT_WGRAD_OVERLAP = 0), followed by %d warm-up steps in the product configuration" % (serial_steps, product_steps),
             "kernel": dom_name, "achieved": fam_warm[dominant][2] / fam_warm[dominant][0] / 1e9,

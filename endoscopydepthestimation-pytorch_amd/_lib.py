@@ -39,6 +39,7 @@ SIGNATURES = {
     "endo_loss_head_workspace_floats": (_L, [_I, _I, _I]),
     "endo_loss_head": (_I, [_P] * 16 + [_F, _F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
     "endo_warp_consistency_workspace_floats": (_L, [_I, _I, _I]),
+    "endo_warp_consistency_bytes": (_L, [_I, _I, _I]),
     "endo_warp_consistency": (_I, [_P] * 8 + [_F, _F] + [_P] * 4 + [_I, _I, _I, _P]),
     "endo_warp_fallback_blocks": (_I, [_P, _P, _I]),
     "endo_bf16_pack_nhwc": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

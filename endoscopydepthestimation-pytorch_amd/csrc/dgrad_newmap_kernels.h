@@ -206,11 +206,14 @@ __global__ void __launch_bounds__(kConvThreads, NewMapGeom<NL>::kBlocksPerCu) dg
         }
     };
 
-    // BN-backward sums: fp32 per lane over its 12 pixels of every tile of the run (<= a few hundred terms, as many as one block of
-    // dgrad_block_kernel adds up in fp32), fp64 from there
+    // BN-backward sums: fp32 per lane over its 12 pixels of at most kFlushTiles tiles (<= 96 terms, fewer than one block of
+    // dgrad_block_kernel adds up in fp32), then into fp64 registers: the run of a block grows with image size and batch, the fp32 part does not
+    constexpr int kFlushTiles = 8;
     float fs1[NL], fs2[NL];
+    double ds1[NL], ds2[NL];
+    int tiles_since_flush = 0;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) fs1[l] = fs2[l] = 0.f;
+    for (int l = 0; l < NL; ++l) { fs1[l] = fs2[l] = 0.f; ds1[l] = ds2[l] = 0.0; }
     dma_tile(cur);
     issue_chunk(0, 0);
     Tile nxt = cur;
@@ -312,6 +315,14 @@ __global__ void __launch_bounds__(kConvThreads, NewMapGeom<NL>::kBlocksPerCu) dg
                 po_full = cur_full;
                 cur = nxt;
                 advance(nxt);
+                if (++tiles_since_flush == kFlushTiles) {
+                    tiles_since_flush = 0;
+#pragma unroll
+                    for (int k = 0; k < NL; ++k) {
+                        ds1[k] += static_cast<double>(fs1[k]); ds2[k] += static_cast<double>(fs2[k]);
+                        fs1[k] = 0.f; fs2[k] = 0.f;
+                    }
+                }
             }
             stage ^= 1;
             // keep the stage a run-time value: with an even NL it is a compile-time constant per unrolled layer, and that build computed wrong
@@ -327,7 +338,7 @@ __global__ void __launch_bounds__(kConvThreads, NewMapGeom<NL>::kBlocksPerCu) dg
     double* red = reinterpret_cast<double*>(smem);          // [4 waves][NL][16][2]
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
-        double a = static_cast<double>(fs1[l]), b = static_cast<double>(fs2[l]);
+        double a = ds1[l] + static_cast<double>(fs1[l]), b = ds2[l] + static_cast<double>(fs2[l]);
         a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
         b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
         if (lk == 0) {
@@ -351,7 +362,10 @@ __global__ void __launch_bounds__(kConvThreads, NewMapGeom<NL>::kBlocksPerCu) dg
 }
 
 // the shapes the persistent form is written for: float4 rows (the 16-byte DMA and the float4 epilogue), one 16-channel group
-inline bool dgrad_newmap_ok(const DgradBlockParams& p) { return p.count <= 16 && p.acc_from == 0; }
+// (the gradient maps of a sample and the x / out tile offsets go through 32-bit byte offsets: larger frames keep the per-tile pointer kernels)
+inline bool dgrad_newmap_ok(const DgradBlockParams& p) {
+    return p.count <= 16 && p.acc_from == 0 && 36ll * p.g_cs * 4 < (1ll << 31) && (16ll * p.cs + static_cast<int64_t>(p.h) * p.w) * 4 < (1ll << 32);
+}
 
 template <int NL>
 inline int launch_dgrad_newmap(DgradBlockParams p, hipStream_t stream) {

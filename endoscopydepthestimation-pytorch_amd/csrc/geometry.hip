@@ -1085,6 +1085,15 @@ extern "C" int64_t endo_warp_consistency_workspace_floats(int n, int h, int w) {
     return 4 * (p + 3) + (4 * kStatStride + 16) * n + 64;
 }
 
+// Algorithmic HBM bytes of one endo_warp_consistency call, as SURVEY.md 8(d) counts the chain per pixel and frame pair, both directions:
+// forward 2 x (read depth_1, depth_2, boundary; 4-tap gather of the source depth; write warped depth + intersect mask) = 2 x 36 B,
+// backward 2 x (read the two maps, the mask, the forward's warped / intersect planes; write d loss / d depth of the target; 4-tap
+// scatter into the source's gradient) = 2 x 44 B: 160 B per pixel of a pair.  bench.py's roofline_depth_warp divides by the device time.
+extern "C" int64_t endo_warp_consistency_bytes(int n, int h, int w) {
+    if (n <= 0 || h <= 0 || w <= 0) return -1;
+    return static_cast<int64_t>(160) * n * h * w;
+}
+
 // phase 1: memset + forward kernel (loss, coefficients, and -- zero_grads -- cleared gradients); phase 2: backward kernel (atomic adds
 // into grad_depth_*).  endo_warp_consistency runs both; endo_loss_head (head.hip) runs them around its other terms.
 int endo_consistency_phase(int phase, const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,

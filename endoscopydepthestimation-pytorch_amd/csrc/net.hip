@@ -890,14 +890,13 @@ static int prep_dy(const Ctx& c, int level, int c0, int count, float* bias_grad,
     int bx = static_cast<int>((lv.plane + 4095) / 4096);      // 16 pixels per thread
     bx = bx < 1 ? 1 : (bx > 32 ? 32 : bx);
     float* parts = nullptr;
-    if (bias_grad && c.bias_parts) {          // (no room: the kernel falls back to its atomics)
+    if (bias_grad && c.bias_parts) {          // a full table is an error, not a silent fall-back to the kernel's atomics (whose order is not fixed)
         BiasParts& bp = *c.bias_parts;
         const int64_t need = static_cast<int64_t>(count) * c.nt() * bx;
-        if (bp.table.n < kBiasPartLaunches && bp.used + need <= c.net->bias_parts_floats) {
-            parts = c.gradws + c.net->bias_parts_off + bp.used;
-            bp.table.e[bp.table.n++] = {parts, bias_grad, count, c.nt() * bx};
-            bp.used += need;
-        }
+        if (bp.table.n >= kBiasPartLaunches || bp.used + need > c.net->bias_parts_floats) return ENDO_E_UNSUPPORTED;          // (sized from the network table: endo_net_create_grouped)
+        parts = c.gradws + c.net->bias_parts_off + bp.used;
+        bp.table.e[bp.table.n++] = {parts, bias_grad, count, c.nt() * bx};
+        bp.used += need;
     }
     ProfScope prof(kProfSmall, c.stream, 0.0, 12.0 * c.nt() * lv.plane * count);
     prep_dy_kernel<<<dim3(bx, count, c.nt()), 256, 0, c.stream>>>(c.gbuf(level) + c0 * lv.plane, c.act(level) + c0 * lv.plane,
@@ -1044,8 +1043,8 @@ static int dense_block_bwd(const Ctx& c, int level, int ic0, int c0, const BnP* 
                 rc = dense_wgrad(cw, level, ic0, new0 + kGrowth * jj, bn[jj], cv[jj], &red, jj);
                 if (rc) return rc;
             }
-            if (j == 0) {          // (the side stream runs its launches in order: all four are ahead of this one)
-                ProfScope prof(kProfWgradDense, cw.stream, 0.0, 0.0);
+            if (j == 0 && red.count > 0) {          // (the side stream runs its launches in order: all four are ahead of this one)
+                ProfScope prof(kProfSmall, cw.stream, 0.0, 0.0);          // (not a convolution launch: kept out of the weight-gradient family's per-launch figures)
                 rc = launch_wgrad_f34_reduce_batch(red, cw.stream);
                 if (rc) return rc;
             }
@@ -1308,6 +1307,15 @@ extern "C" int endo_net_create_grouped(endo_net** out, int n, int h, int w, int 
     net->gplane_off = align_up(net->wd_off + tb.wino_dgrad_floats, 64);
     net->bias_parts_off = net->gplane_off + align_up(static_cast<int64_t>(n) * h * w, 64);
     net->bias_parts_floats = static_cast<int64_t>(kBiasPartChannels) * n * groups * 32;
+    {   // the BiasParts limits against THIS network's table: one prep_dy launch per convolution with a bias, its output channels in all
+        int launches = 1, channels = tb.first.cout;
+        for (int l = 0; l < kLevels; ++l) {
+            for (int j = 0; j < kLayers; ++j) { launches += 2; channels += tb.down_conv[l][j].cout + tb.up_conv[l][j].cout; }
+            launches += 2; channels += tb.td_conv[l].cout + tb.tu_conv[l].cout;
+        }
+        for (int j = 0; j < kLayers; ++j) { ++launches; channels += tb.bott_conv[j].cout; }
+        if (launches > kBiasPartLaunches || channels > kBiasPartChannels) { delete net; return ENDO_E_UNSUPPORTED; }
+    }
     net->fw_parts_off = net->bias_parts_off + align_up(net->bias_parts_floats, 64);
     net->gradws_floats = net->fw_parts_off + 2 * static_cast<int64_t>(kFwPartBlocks) * 192;
     {

@@ -223,7 +223,9 @@ __global__ void __launch_bounds__(kConvThreads) wgrad1x1_dma_kernel(const WgradP
 
 // needs whole code dwords per pooled row segment (pooled width % 4 == 0) and even H, W
 inline bool wgrad1x1_dma_ok(const WgradParams& p) {
-    return (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.idx_ns % 4 == 0) && (p.h % 2 == 0) && (p.w % 2 == 0) &&
+    // (channel planes are addressed through buffer descriptors with 32-bit byte ranges and offsets: a tile past the last channel must still fit)
+    const bool fits = (static_cast<int64_t>(p.cin) + kP1Tile) * p.in_cs * 4 < (1ll << 31) && (static_cast<int64_t>(p.cout) + kP1Tile) * p.dy_cs * 4 < (1ll << 31);
+    return fits && (p.dy_w % 4 == 0) && (p.dy_cs % 4 == 0) && (p.idx_ns % 4 == 0) && (p.h % 2 == 0) && (p.w % 2 == 0) &&
            (reinterpret_cast<uintptr_t>(p.dy_idx) % 4 == 0);
 }
 

@@ -165,6 +165,8 @@ int endo_loss_head(const float* pred_1, const float* pred_2, const float* bounda
  * depth_k: the (scaled) depth maps N x 1 x H x W; poses and intrinsics as endo_loss_head.  This is the chain BASELINE.json's second
  * metric times ("depth-warp fwd+bwd ms / pair").  workspace: endo_warp_consistency_workspace_floats(n, h, w) floats, 16-byte aligned. */
 int64_t endo_warp_consistency_workspace_floats(int n, int h, int w);
+/* algorithmic HBM bytes of one call (160 B per pixel of a frame pair, both directions, forward and backward) */
+int64_t endo_warp_consistency_bytes(int n, int h, int w);
 int endo_warp_consistency(const float* depth_1, const float* depth_2, const float* boundaries, const float* t_1_wrt_2,
                           const float* r_1_wrt_2, const float* t_2_wrt_1, const float* r_2_wrt_1, const float* intrinsics,
                           float dcl_weight, float eps, float* loss, float* grad_depth_1, float* grad_depth_2,

@@ -978,8 +978,9 @@ OPT_FINAL_VIRTUAL = 8
 OPT_TD_PERSIST = 9
 
 
+@pytest.mark.parametrize("extra", [{}, {4: 1}, {2: 0}, {2: 1}], ids=["fp32", "bf16-operands", "dgrad-vec-0", "dgrad-vec-1"])
 @pytest.mark.parametrize("forced", [False, True], ids=["default-forms", "winograd-forms"])
-def test_final_conv_fusions_are_transparent(forced):
+def test_final_conv_fusions_are_transparent(forced, extra):
     """ENDO_OPT_FINAL_VIRTUAL (round 5, default on): the final 1x1 convolution's forward sum over the last dense layer's 180 input channels is
     formed by that layer's F(4x4,3x3) launch, its rank-one data gradient g * w[c] by the last up block's kernels (never written to the 192
     level-0 planes), and the first convolution's prep_dy is folded into its weight-gradient kernel.  With the option off the separate kernels
@@ -996,6 +997,8 @@ def test_final_conv_fusions_are_transparent(forced):
         with kernel_options({OPT_WINO_MIN_TILES: 1} if forced else {}):
             _, model = make_model(66)
         model.set_kernel_option(OPT_FINAL_VIRTUAL, virtual)
+        for option_id, value in extra.items():          # ENDO_OPT_MFMA_BF16 = 1: the virtual old gradient goes through dgrad_block_kernel<..., BF = 1>;
+            model.set_kernel_option(option_id, value)   # ENDO_OPT_DGRAD_VEC = 0 / 1: the per-tile new-map kernels with the virtual gradient
         model.train()
         y1, y2 = model.forward_pair(xs[0].to(dev()), xs[1].to(dev()))
         ((y1 * cots[0].to(dev())).sum() + (y2 * cots[1].to(dev())).sum()).backward()
@@ -1407,15 +1410,17 @@ def test_train_step_full_size_golden(golden, forward_form):
         e_probe = abs(float((got.numpy() * probe).sum()) - p64[i]) / scale
         r_probe = abs(p32[i] - p64[i]) / scale
         report.append((max(e_norm, e_probe), nm, e_norm, r_norm, e_probe, r_probe))
-        check(e_norm <= 5e-2, "grad norm %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_norm, r_norm))
-        check(e_probe <= 5e-2, "grad projection %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_probe, r_probe))
+        # per-tensor bound 3e-2, at most 2 tensors beyond 1e-2, medians within 2x the reference's own (round 6: the bounds follow what is
+        # measured -- 0 / 1 tensors beyond 1e-2 and medians 1.7x in the two forward forms; if one trips on another box, report the numbers)
+        check(e_norm <= 3e-2, "grad norm %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_norm, r_norm))
+        check(e_probe <= 3e-2, "grad projection %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e_probe, r_probe))
     beyond = [r[1] for r in report if r[0] > 1e-2]
     print("forward form %s: %d of %d tensors further than 1e-2 from fp64" % (forward_form, len(beyond), len(report)))
-    check(len(beyond) <= 5, "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:10]))
+    check(len(beyond) <= 2, "%d tensors further than 1e-2 from fp64: %s" % (len(beyond), beyond[:10]))
     med = [float(np.median([r[k] for r in report])) for k in (2, 3, 4, 5)]
     print("median over %d tensors: norm err hip %.2e / reference %.2e, projection err hip %.2e / reference %.2e" % (len(report), *med))
-    check(med[0] <= max(3.0 * med[1], 1e-4), "median gradient-norm distance from fp64: hip %.3e, reference %.3e" % (med[0], med[1]))
-    check(med[2] <= max(3.0 * med[3], 1e-4), "median gradient-projection distance from fp64: hip %.3e, reference %.3e" % (med[2], med[3]))
+    check(med[0] <= max(2.0 * med[1], 1e-4), "median gradient-norm distance from fp64: hip %.3e, reference %.3e" % (med[0], med[1]))
+    check(med[2] <= max(2.0 * med[3], 1e-4), "median gradient-projection distance from fp64: hip %.3e, reference %.3e" % (med[2], med[3]))
     report.sort(reverse=True)
     print("worst gradient tensors (name, norm err hip / ref32, projection err hip / ref32):")
     for row in report[:8]:
@@ -1427,7 +1432,7 @@ def test_train_step_full_size_golden(golden, forward_form):
         r = float((r32 - r64).abs().max()) / scale
         print("   kept %-46s hip-vs-fp64 %.2e  reference-vs-fp64 %.2e" % (nm, e, r))
         if not nm.endswith("conv.bias") and not nm.endswith("convTrans.1.bias"):
-            check(e <= 5e-2, "grad tensor %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e, r))
+            check(e <= 3e-2, "grad tensor %s: hip-vs-fp64 %.3e, reference-vs-fp64 %.3e" % (nm, e, r))
     norm = opt.step()
     e = abs(float(norm) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
     r = abs(float(g["grad_norm"]) - float(g["o64_grad_norm"])) / float(g["o64_grad_norm"])
