@@ -54,7 +54,7 @@ def classify(name):
         return "wgrad_dense" if a[1] == "1" else "other"
     if base == "wgrad_mfma_kernel":                       # <KS, IN_MODE, ...>: the register-staged fallback
         return "wgrad_dense" if a[0] == "3" and a[1] == "1" else "other"
-    if base in ("dgrad_block_kernel", "dgrad_newmap_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_dense_kernel"):
+    if base in ("dgrad_block_kernel", "dgrad_newmap_kernel", "dgrad_block8_kernel", "dgrad_wino8_kernel", "dgrad_wino3_kernel", "dgrad_wino3p_kernel", "dgrad_dense_kernel"):
         return "dgrad_dense"
     if base in ("wino_fwd_kernel", "wino4_fwd_kernel", "finalize_partial_kernel"):
         return "conv3x3_dense_fwd"
@@ -79,7 +79,7 @@ def classify(name):
         return "wgrad_dense"
     if base in ("wgrad1x1_dma_kernel", "wgrad1x1_mfma_kernel", "tu_wgrad_subpix_kernel", "tu_wgrad_subpix_reduce_kernel", "wino_fwd_weights_kernel", "wino4_fwd_weights_kernel",
                 "dgrad_wino_weights_kernel", "tu_subpix_dgrad_weights_kernel", "wgrad_wino_weights_kernel", "td_bwd_prep_kernel",
-                "td_dgrad_gemm_kernel", "td_wgrad_gemm_kernel", "td_wgrad_reduce_kernel"):
+                "td_dgrad_gemm_kernel", "td_wgrad_gemm_kernel", "td_wgrad_reduce_kernel", "td_dgrad_kernel", "td_dgrad_small_kernel", "td_fwd_kernel"):
         return "other"
     raise SystemExit("pmc_traffic: convolution-like kernel %r belongs to no family -- extend classify()" % name)
 
