@@ -46,10 +46,16 @@ constexpr int kF34WavesPerXcd = 256;               // 32 CUs x 2 blocks x 4 wave
 
 struct F34Plan {
     int groups;          // 16-channel groups
-    int wpg;             // waves per group and XCD
+    int wpg;             // waves per group and XCD (>= 4 or the only ones): waves [g * wpg, (g + 1) * wpg) of an XCD work on group g
     int segq;            // quads (16 rows) per column segment, the unit of work
-    int slots;           // partial-sum rows per (group, tap): 8 * wpg
+    int spb;             // partial-sum rows per (group, XCD): one per block that holds waves of the group (the largest count over the groups)
+    int slots;           // partial-sum rows per (group, tap): 8 * spb (the rows past a group's last block are never written nor read)
 };
+// blocks (of four waves) of an XCD that hold waves of group g: first, count
+__host__ __device__ inline int f34_first_block(const F34Plan& plan, int g) { return (g * plan.wpg) >> 2; }
+__host__ __device__ inline int f34_block_count(const F34Plan& plan, int g) { return (((g + 1) * plan.wpg - 1) >> 2) - ((g * plan.wpg) >> 2) + 1; }
+// is row `slot` (of the 8 * spb rows of a (group, tap)) one that a block wrote?
+__host__ __device__ inline bool f34_row_written(const F34Plan& plan, int g, int slot) { return slot % plan.spb < f34_block_count(plan, g); }
 
 // 6-point input transform B^T d (12 instructions; T = float, or f32x2 for two columns at once: v_pk_fma_f32 / v_pk_add_f32)
 template <typename T>
@@ -114,18 +120,20 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
     const int lk = lane >> 4;
 
     // this wave's channel group and its place among the group's waves on this XCD
+    // (the waves of a block belong to at most two groups: their sums meet in LDS at the end and leave as one row per group)
     const int xcd = blockIdx.x & 7;
-    const int wi = (blockIdx.x >> 3) * 4 + wave;
-    if (wi >= plan.groups * plan.wpg) return;
-    const int group = wi % plan.groups;
-    const int wq = wi / plan.groups;
+    const int bi = blockIdx.x >> 3;
+    const int wi = bi * 4 + wave;
+    const bool active = wi < plan.groups * plan.wpg;
+    const int group = active ? wi / plan.wpg : 0;
+    const int wq = wi - group * plan.wpg;
 
     // work units: column segments (sample n, segment of `segq` quads of 16 rows, strip s), numbered with s fastest
     const int S = (p.w + 15) >> 4, CY = p.h >> 4, segq = plan.segq, YS = CY / segq;          // the last strip may be partly outside (w % 4 == 0)
     const int units = p.n * YS * S;
     const int per_xcd = (units + 7) >> 3;
-    const int u_first = xcd * per_xcd + wq;
     const int u_end = min(units, (xcd + 1) * per_xcd);
+    const int u_first = active ? xcd * per_xcd + wq : u_end;
 
     f32x4 acc[36];
 #pragma unroll
@@ -329,14 +337,13 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
             float v = prep_sum;
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
-            if (lk == 0 && li < 12) atomicAdd(p.prep_bias + 12 * group + li, v);
+            if (active && lk == 0 && li < 12) atomicAdd(p.prep_bias + 12 * group + li, v);
         }
     }
     // output transform with the scales of S folded in: out[a][b] = sum_ij C[a][i] M[i][j] C[b][j]
     const float C[3][6] = {{0.25f, -1.f / 6.f, -1.f / 6.f, 1.f / 24.f, 1.f / 24.f, 0.f},
                            {0.f, -1.f / 6.f, 1.f / 6.f, 1.f / 12.f, -1.f / 12.f, 0.f},
                            {0.f, -1.f / 6.f, -1.f / 6.f, 1.f / 6.f, 1.f / 6.f, 1.f}};
-    const int slot = xcd * plan.wpg + wq;
     f32x4 h[3][6];          // rows combined: h[a][j] = sum_i C[a][i] M[i][j]
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -346,6 +353,9 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
         h[1][j] = (1.f / 6.f) * d12 + (1.f / 12.f) * d34;
         h[2][j] = -(1.f / 6.f) * s12 + (1.f / 6.f) * s34 + acc[30 + j];
     }
+    // the block's waves are done with their images: the 9 x 256 sums of each wave meet in LDS, one row per group of the block leaves
+    __syncthreads();
+    float* const red = smem + wave * (9 * 256);
 #pragma unroll
     for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -354,31 +364,50 @@ __global__ void __launch_bounds__(kConvThreads, 2) wgrad_f34_kernel(const WgradP
 #pragma unroll
             for (int j = 0; j < 6; ++j)
                 if (C[b][j] != 0.f) o += C[b][j] * h[a][j];
-            float* out = partial + ((static_cast<int64_t>(group) * 9 + (3 * a + b)) * plan.slots + slot) * 256;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) out[r * 64 + lane] = o[r];
+            for (int r = 0; r < 4; ++r) red[(3 * a + b) * 256 + r * 64 + lane] = o[r];
         }
+    __syncthreads();
+    const int total = plan.groups * plan.wpg;
+    int gw[5];                 // group of each wave of the block (-1: none)
+    int64_t row[4];            // where the sum that ends with wave w goes: the row of (group, tap 0) that belongs to this block
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        gw[w] = bi * 4 + w < total ? (bi * 4 + w) / plan.wpg : -1;
+        row[w] = ((static_cast<int64_t>(max(gw[w], 0)) * 9) * plan.slots + xcd * plan.spb + (bi - f34_first_block(plan, max(gw[w], 0)))) * 256 + tid;
+    }
+    gw[4] = -1;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (gw[w] < 0) continue;
+            sum += smem[w * (9 * 256) + t * 256 + tid];
+            if (gw[w + 1] != gw[w]) {
+                partial[row[w] + static_cast<int64_t>(t) * plan.slots * 256] = sum;
+                sum = 0.f;
+            }
+        }
+    }
 }
 
 // grid (groups * 9, slices): adds the partial rows of (group, tap) over the group's waves in a fixed order per slice
 // raw: the groups are sets of 12 output channels over the same <= 16 input channels (wgrad_f34_kernel<.., RAW>)
-__global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __restrict__ partial, int slots, int cin, float* __restrict__ dw, int raw) {
+__global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __restrict__ partial, const F34Plan plan, int cin, float* __restrict__ dw, int raw) {
     __shared__ f32x4 s_part[4][64];
     const int gm = blockIdx.x;
     const int group = gm / 9, tap = gm - group * 9;
+    const int slots = plan.slots;
     const int per = (slots + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = min(slots, b0 + per);
     if (b0 >= b1) return;
     const int q = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const f32x4* src = reinterpret_cast<const f32x4*>(partial + (static_cast<int64_t>(gm) * slots) * 256) + q;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    int b = b0 + sub;
-    for (; b + 4 < b1; b += 8) {
-        s0 += src[static_cast<int64_t>(b) * 64];
-        s1 += src[static_cast<int64_t>(b + 4) * 64];
-    }
-    if (b < b1) s0 += src[static_cast<int64_t>(b) * 64];
-    s_part[sub][q] = s0 + s1;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0 + sub; b < b1; b += 4)
+        if (f34_row_written(plan, group, b)) s0 += src[static_cast<int64_t>(b) * 64];
+    s_part[sub][q] = s0;
     __syncthreads();
     const int e = threadIdx.x;
     const float* sp = reinterpret_cast<const float*>(s_part);
@@ -394,31 +423,27 @@ __global__ void __launch_bounds__(256) wgrad_f34_reduce_kernel(const float* __re
 struct F34ReduceBatch {
     const float* partial[4];
     float* dw[4];
-    int slots[4];
+    F34Plan plan[4];
     int cin[4];
-    int groups[4];
     int count;
 };
 __global__ void __launch_bounds__(256) wgrad_f34_reduce_batch_kernel(const F34ReduceBatch a) {
     __shared__ f32x4 s_part[4][64];
     const int l = blockIdx.z;
     const int gm = blockIdx.x;
-    if (gm >= a.groups[l] * 9) return;          // (block-uniform)
-    const int slots = a.slots[l], cin = a.cin[l];
+    const F34Plan plan = a.plan[l];
+    if (gm >= plan.groups * 9) return;          // (block-uniform)
+    const int slots = plan.slots, cin = a.cin[l];
     const int group = gm / 9, tap = gm - group * 9;
     const int per = (slots + gridDim.y - 1) / gridDim.y;
     const int b0 = blockIdx.y * per, b1 = min(slots, b0 + per);
     if (b0 >= b1) return;
     const int q = threadIdx.x & 63, sub = threadIdx.x >> 6;
     const f32x4* src = reinterpret_cast<const f32x4*>(a.partial[l] + (static_cast<int64_t>(gm) * slots) * 256) + q;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
-    int b = b0 + sub;
-    for (; b + 4 < b1; b += 8) {
-        s0 += src[static_cast<int64_t>(b) * 64];
-        s1 += src[static_cast<int64_t>(b + 4) * 64];
-    }
-    if (b < b1) s0 += src[static_cast<int64_t>(b) * 64];
-    s_part[sub][q] = s0 + s1;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+    for (int b = b0 + sub; b < b1; b += 4)
+        if (f34_row_written(plan, group, b)) s0 += src[static_cast<int64_t>(b) * 64];
+    s_part[sub][q] = s0;
     __syncthreads();
     const int e = threadIdx.x;
     const float* sp = reinterpret_cast<const float*>(s_part);
@@ -465,7 +490,9 @@ inline F34Plan wgrad_f34_plan(const WgradParams& p, int waves_per_xcd = kF34Wave
         const float cost = iters * (4.f * segq + 1.5f);
         if (cost < best * 0.97f) { best = cost; plan.segq = segq; plan.wpg = wpg; }
     }
-    plan.slots = 8 * plan.wpg;
+    plan.spb = 1;
+    for (int g = 0; g < plan.groups; ++g) plan.spb = std::max(plan.spb, f34_block_count(plan, g));
+    plan.slots = 8 * plan.spb;
     return plan;
 }
 
@@ -488,10 +515,10 @@ inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t st
     ENDO_LAUNCH_CHECK();
     if (batch && !RAW && batch->count < 4) {
         const int k = batch->count++;
-        batch->partial[k] = scratch; batch->dw[k] = p.dw; batch->slots[k] = plan.slots; batch->cin[k] = p.cin; batch->groups[k] = plan.groups;
+        batch->partial[k] = scratch; batch->dw[k] = p.dw; batch->plan[k] = plan; batch->cin[k] = p.cin;
         return 0;
     }
-    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan.slots, p.cin, p.dw, RAW ? 1 : 0);
+    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan, p.cin, p.dw, RAW ? 1 : 0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
@@ -499,7 +526,7 @@ inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t st
 inline int launch_wgrad_f34_reduce_batch(F34ReduceBatch& batch, hipStream_t stream) {
     if (batch.count == 0) return 0;
     int gmax = 0;
-    for (int k = 0; k < batch.count; ++k) gmax = std::max(gmax, batch.groups[k]);
+    for (int k = 0; k < batch.count; ++k) gmax = std::max(gmax, batch.plan[k].groups);
     wgrad_f34_reduce_batch_kernel<<<dim3(gmax * 9, 8, batch.count), 256, 0, stream>>>(batch);
     ENDO_LAUNCH_CHECK();
     batch.count = 0;
