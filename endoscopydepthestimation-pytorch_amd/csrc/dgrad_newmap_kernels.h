@@ -53,26 +53,44 @@ __global__ void __launch_bounds__(kConvThreads, NewMapGeom<NL>::kBlocksPerCu) dg
     const int wx = (wave & 1) * 16;
     const int wy = (wave >> 1) * R;
 
-    // ---- this block's run of tiles: all inside one group of the batch (BN statistics are per group) ----
-    const int lb = (gridDim.x & 7) == 0 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    const int grp = lb / blocks_per_group;
+    // ---- this block's tiles: all inside one group of the batch (BN statistics are per group) ----
+    // The blocks of an XCD share one contiguous range of tiles and walk it interleaved (block j: tiles first + j, first + j + Q, ...): at any
+    // time the XCD's blocks work on neighbouring tiles, whose haloed gradient windows then meet in the XCD's L2 (round 6: with a contiguous
+    // run per block the window lines shared with the block's own next tile had left the L2 by the time it got there -- dgrad_wino3p_kernels.h)
     const int gn = p.group_n > 0 ? p.group_n : p.n;
     const int tps = p.tiles_x * tiles_y;
-    const int first = (lb - grp * blocks_per_group) * tiles_per_block;
-    const int ntiles = min(tiles_per_block, tps * gn - first);
+    const int Q = static_cast<int>(gridDim.x >> 3);
+    const bool interleave = (gridDim.x & 7) == 0 && Q > 0 && blocks_per_group % Q == 0;
+    int grp, first, t_step, t_last;          // first tile, stride, end of the range (tile indices inside the group)
+    if (interleave) {
+        const int lb0 = static_cast<int>(blockIdx.x & 7) * Q;
+        grp = lb0 / blocks_per_group;
+        const int b0 = lb0 - grp * blocks_per_group;
+        first = b0 * tiles_per_block + static_cast<int>(blockIdx.x >> 3);
+        t_last = min((b0 + Q) * tiles_per_block, tps * gn);
+        t_step = Q;
+    } else {
+        const int lb = blockIdx.x;
+        grp = lb / blocks_per_group;
+        first = (lb - grp * blocks_per_group) * tiles_per_block;
+        t_last = min(first + tiles_per_block, tps * gn);
+        t_step = 1;
+    }
+    const int ntiles = first < t_last ? (t_last - first + t_step - 1) / t_step : 0;
     if (ntiles <= 0) return;
     const int64_t grp_off = p.group_n > 0 ? grp * p.gs : 0;
 
-    struct Tile { int n, tx, ty; };
-    auto advance = [&](Tile& t) {
-        if (++t.tx == p.tiles_x) {
-            t.tx = 0;
-            if (++t.ty == tiles_y) { t.ty = 0; ++t.n; }
-        }
+    struct Tile { int n, tx, ty, idx; };
+    auto place = [&](Tile& t) {
+        t.n = t.idx / tps;
+        const int rem = t.idx - t.n * tps;
+        t.ty = rem / p.tiles_x;
+        t.tx = rem - t.ty * p.tiles_x;
     };
+    auto advance = [&](Tile& t) { t.idx += t_step; place(t); };
     Tile cur;
-    cur.n = first / tps;
-    { const int rem = first - cur.n * tps; cur.ty = rem / p.tiles_x; cur.tx = rem - cur.ty * p.tiles_x; }
+    cur.idx = first;
+    place(cur);
 
     // ---- weight slices, once: element (l, tap, c, j) <- W_l[c][w_ci_off + j][8 - tap] ----
 #pragma unroll

@@ -87,11 +87,23 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int grp = blockIdx.x / bpg;
     const int r0 = blockIdx.x - grp * bpg;
-    const int run = (bpg & 7) == 0 ? xcd_remap(r0, bpg) : r0;
     const int64_t grp_off = grp * p.gs;
     const int t_total = tiles_xy * gn;
-    const int t_begin = static_cast<int>(static_cast<int64_t>(run) * t_total / bpg);
-    const int t_end = static_cast<int>(static_cast<int64_t>(run + 1) * t_total / bpg);
+    // The blocks of an XCD (bpg / 8 per group) share one contiguous range of the group's tiles and walk it INTERLEAVED: block idx takes tiles
+    // T0 + idx, T0 + idx + bpg / 8, ... -- at any time the XCD's blocks work on neighbouring tiles, whose haloed gradient windows (10 x 40 of
+    // 8 x 32 pixels, 48 maps) then meet in the XCD's L2.  With a contiguous run per block a window's lines were fetched again by the block's
+    // next tile ~60 us later, after 16 MB of other traffic: 1.8 GB of HBM fetch per level-0 launch for 1.1 GB algorithmic (r06_b PMC passes).
+    int t_begin, t_end, t_step;
+    if ((bpg & 7) == 0) {
+        const int q = bpg >> 3, xcd = r0 & 7, idx = r0 >> 3;
+        t_begin = static_cast<int>(static_cast<int64_t>(xcd * q) * t_total / bpg) + idx;
+        t_end = static_cast<int>(static_cast<int64_t>((xcd + 1) * q) * t_total / bpg);
+        t_step = q;
+    } else {
+        t_begin = static_cast<int>(static_cast<int64_t>(r0) * t_total / bpg);
+        t_end = static_cast<int>(static_cast<int64_t>(r0 + 1) * t_total / bpg);
+        t_step = 1;
+    }
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_g = smem;                               // [NL*12][kCS]
@@ -469,7 +481,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
     }
 
     int since_flush = 0;
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t = t_begin; t < t_end; t += t_step) {
         {
             int n, x0, y0;
             tile_origin(t, n, x0, y0);
@@ -477,8 +489,8 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
             out_n = p.out + grp_off + static_cast<int64_t>(n) * p.ns;
             vg_n = p.vg ? p.vg + grp_off + static_cast<int64_t>(n) * p.cs : nullptr;
             tile_b = 4u * static_cast<unsigned>(y0 * p.w + x0);
-            has_next_tile = t + 1 < t_end;
-            if (has_next_tile) tile_origin(t + 1, n_next, x0_next, y0_next);
+            has_next_tile = t + t_step < t_end;
+            if (has_next_tile) tile_origin(t + t_step, n_next, x0_next, y0_next);
         }
         // worker 1's four waves refill the next tile's maps from inside their M phases (mfmas): the lane's units and the descriptor
         unsigned vo_next[2] = {0x80000000u, 0x80000000u};
@@ -499,7 +511,7 @@ __global__ void __launch_bounds__(512, 2) dgrad_wino3p_kernel(const DgradBlockPa
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();          // the tile's dY maps (first load or refills) and its first weight slice are in place (a raw barrier:
         __builtin_amdgcn_sched_barrier(0);     // __syncthreads()'s fence would wait for the loads just issued)
-        if constexpr ((EXP & 16) != 0) { dbg_on = blockIdx.x == 0 && t == t_begin + 2; dbg_i = 0; }
+        if constexpr ((EXP & 16) != 0) { dbg_on = blockIdx.x == 0 && t == t_begin + 2 * t_step; dbg_i = 0; }
         stamp();
         if (wk == 1) { __builtin_amdgcn_s_barrier(); stamp(); }          // the skew
         transform(0);
