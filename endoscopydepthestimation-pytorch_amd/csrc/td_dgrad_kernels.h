@@ -47,11 +47,21 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const int grp = blockIdx.x / bpg;
     const int r0 = blockIdx.x - grp * bpg;
-    const int run = (bpg & 7) == 0 ? xcd_remap(r0, bpg) : r0;
     const int64_t grp_off = grp * p.gs;
     const int t_total = tiles_xy * gn;
-    const int t_begin = static_cast<int>(static_cast<int64_t>(run) * t_total / bpg);
-    const int t_end = static_cast<int>(static_cast<int64_t>(run + 1) * t_total / bpg);
+    // the blocks of an XCD (bpg / 8 per group) share one contiguous tile range and walk it interleaved (dgrad_wino3p_kernels.h): a tile's
+    // pooled rows are 64 bytes and its code rows 16 bytes of 128-byte lines whose rest belongs to the tiles beside it
+    int t_begin, t_end, t_step;
+    if ((bpg & 7) == 0) {
+        const int q8 = bpg >> 3, xcd = r0 & 7, idx = r0 >> 3;
+        t_begin = static_cast<int>(static_cast<int64_t>(xcd * q8) * t_total / bpg) + idx;
+        t_end = static_cast<int>(static_cast<int64_t>((xcd + 1) * q8) * t_total / bpg);
+        t_step = q8;
+    } else {
+        t_begin = static_cast<int>(static_cast<int64_t>(r0) * t_total / bpg);
+        t_end = static_cast<int>(static_cast<int64_t>(r0 + 1) * t_total / bpg);
+        t_step = 1;
+    }
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_w = smem;                                   // [o][kWS]
@@ -153,14 +163,14 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
         load_pass(rsrc(p.x + grp_off + static_cast<int64_t>(n) * p.x_ns), rsrc(p.out + grp_off + static_cast<int64_t>(n) * p.out_ns),
                   4u * static_cast<unsigned>(y0 * p.out_w + x0), 0, xv, ov);
     }
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t = t_begin; t < t_end; t += t_step) {
         int n, x0, y0;
         tile_origin(t, n, x0, y0);
         const float* x_n = p.x + grp_off + static_cast<int64_t>(n) * p.x_ns;
         float* out_n = p.out + grp_off + static_cast<int64_t>(n) * p.out_ns;
         const __amdgpu_buffer_rsrc_t xr = rsrc(x_n), orr = rsrc(out_n);
         const unsigned tile_b = 4u * static_cast<unsigned>(y0 * p.out_w + x0);
-        const bool has_next = t + 1 < t_end;
+        const bool has_next = t + t_step < t_end;
         // This tile's maps have landed.  Two buffers: every wave has CONSUMED register loads younger than its DMA of this tile (the previous tile's
         // passes; loads retire in order), so only the first tile needs a wait; the barrier publishes the maps and retires the previous tile's
         // reads of the other buffer, which the next tile's DMA -- issued behind it -- then takes.  One buffer: the DMA went out behind the
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (G::kBufs == 2 && has_next) issue_tile(t + 1, buf ^ 1);          // lands while this tile is computed
+        if (G::kBufs == 2 && has_next) issue_tile(t + t_step, buf ^ 1);          // lands while this tile is computed
         const float* s_dy = s_t + buf * G::kTileFloats;
 
 #pragma unroll 1
@@ -181,7 +191,7 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
                 if (!last) load_pass(xr, orr, tile_b, pass + 1, xn, on);
                 else if (has_next) {
                     int n2, x2, y2;
-                    tile_origin(t + 1, n2, x2, y2);
+                    tile_origin(t + t_step, n2, x2, y2);
                     load_pass(rsrc(p.x + grp_off + static_cast<int64_t>(n2) * p.x_ns), rsrc(p.out + grp_off + static_cast<int64_t>(n2) * p.out_ns),
                               4u * static_cast<unsigned>(y2 * p.out_w + x2), 0, xn, on);
                 }
@@ -215,7 +225,7 @@ __global__ void __launch_bounds__(512, 2) td_dgrad_kernel(const ConvParams p, in
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                issue_tile(t + 1, 0);
+                issue_tile(t + t_step, 0);
             }
             // ---- epilogue of the pass: ReLU mask, BN backward, read-modify-write, sums ----
 #pragma unroll

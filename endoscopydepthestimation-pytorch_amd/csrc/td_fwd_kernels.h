@@ -55,11 +55,21 @@ __global__ void __launch_bounds__(64 * WAVES, 2) td_fwd_kernel(const ConvParams 
     const int groups = gridDim.x / bpg;
     const int grp = blockIdx.x / bpg;
     const int r0 = blockIdx.x - grp * bpg;
-    const int run = (bpg & 7) == 0 ? xcd_remap(r0, bpg) : r0;
     const ConvParams p = group_view(p0, grp);
     const int t_total = tiles_xy * gn;
-    const int t_begin = static_cast<int>(static_cast<int64_t>(run) * t_total / bpg);
-    const int t_end = static_cast<int>(static_cast<int64_t>(run + 1) * t_total / bpg);
+    // the blocks of an XCD (bpg / 8 per group) share one contiguous tile range and walk it interleaved (dgrad_wino3p_kernels.h): a tile's
+    // pooled rows are 64 bytes and its code rows 16 bytes of 128-byte lines whose rest belongs to the tiles beside it
+    int t_begin, t_end, t_step;
+    if ((bpg & 7) == 0) {
+        const int q8 = bpg >> 3, xcd = r0 & 7, idx = r0 >> 3;
+        t_begin = static_cast<int>(static_cast<int64_t>(xcd * q8) * t_total / bpg) + idx;
+        t_end = static_cast<int>(static_cast<int64_t>((xcd + 1) * q8) * t_total / bpg);
+        t_step = q8;
+    } else {
+        t_begin = static_cast<int>(static_cast<int64_t>(r0) * t_total / bpg);
+        t_end = static_cast<int>(static_cast<int64_t>(r0 + 1) * t_total / bpg);
+        t_step = 1;
+    }
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* s_w = smem;                                   // [c][kWS]: W[o][c] TRANSPOSED (a B fragment's lanes run over o: contiguous; its k-lanes over c: rows)
@@ -102,10 +112,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) td_fwd_kernel(const ConvParams 
     //      lane = LDS unit (row lane >> 3, 4 pixels at 4 (lane & 7)); an odd channel takes its source from unit lane ^ 4 ----
     const unsigned src_even = 4u * static_cast<unsigned>((lane >> 3) * p.in_w + 4 * (lane & 7));
     const unsigned src_odd = 4u * static_cast<unsigned>((lane >> 3) * p.in_w + 4 * ((lane & 7) ^ 4));
-    const int nq = (t_end - t_begin) * G::kChunks;
+    const int nq = ((t_end - t_begin + t_step - 1) / t_step) * G::kChunks;
     auto issue_chunk = [&](int q) {
         if constexpr ((EXP & 1) != 0) return;
-        const int t = t_begin + q / G::kChunks, ch0 = (q % G::kChunks) * G::kKC;
+        const int t = t_begin + (q / G::kChunks) * t_step, ch0 = (q % G::kChunks) * G::kKC;
         int n, x0, y0;
         tile_origin(t, n, x0, y0);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in + static_cast<int64_t>(n) * p.in_ns), 0, 0x7ffffffc, 0x00020000);
@@ -136,7 +146,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) td_fwd_kernel(const ConvParams 
     issue_chunk(0);
     if (G::kStages == 3 && nq > 1) issue_chunk(1);
     int q = 0;
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t = t_begin; t < t_end; t += t_step) {
         int n, x0, y0;
         tile_origin(t, n, x0, y0);
         f32x4 acc[G::kMT][G::kNT];
