@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(64 * QO * QI, 2) wgrad1x1_dma_kernel(const Wgr
             for (int e = 0; e < 4; ++e) {
                 const int co = co_base + wr * 48 + i * 16 + 4 * lk + e;
                 const int ci = ci_base + wc * 48 + j * 16 + li;
-                if (co < p.cout && ci < p.cin) atomicAdd(p.dw + static_cast<int64_t>(co) * p.cin + ci, acc[i][j][e]);
+                if (p.dw && co < p.cout && ci < p.cin) atomicAdd(p.dw + static_cast<int64_t>(co) * p.cin + ci, acc[i][j][e]);          // (p.dw == nullptr: tools/tdw_bench's build without the final atomics)
             }
 }
 

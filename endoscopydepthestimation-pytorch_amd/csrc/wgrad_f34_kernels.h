@@ -518,16 +518,18 @@ inline int launch_wgrad_f34(const WgradParams& p, float* scratch, hipStream_t st
         batch->partial[k] = scratch; batch->dw[k] = p.dw; batch->plan[k] = plan; batch->cin[k] = p.cin;
         return 0;
     }
-    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 8), 256, 0, stream>>>(scratch, plan, p.cin, p.dw, RAW ? 1 : 0);
+    wgrad_f34_reduce_kernel<<<dim3(plan.groups * 9, 2), 256, 0, stream>>>(scratch, plan, p.cin, p.dw, RAW ? 1 : 0);
     ENDO_LAUNCH_CHECK();
     return 0;
 }
 
+// (round 6: ONE slice -- a block adds all 8 * spb rows of its (group, tap) and issues one atomic per weight-gradient element; with 8 slices the
+// eightfold atomics on dW cost more than the shorter loops saved: 503.7 -> 507.1 frame-pairs/s with 2 slices, 506 -> 508 with 1, profiles/r06_ab_runs.txt)
 inline int launch_wgrad_f34_reduce_batch(F34ReduceBatch& batch, hipStream_t stream) {
     if (batch.count == 0) return 0;
     int gmax = 0;
     for (int k = 0; k < batch.count; ++k) gmax = std::max(gmax, batch.plan[k].groups);
-    wgrad_f34_reduce_batch_kernel<<<dim3(gmax * 9, 8, batch.count), 256, 0, stream>>>(batch);
+    wgrad_f34_reduce_batch_kernel<<<dim3(gmax * 9, 1, batch.count), 256, 0, stream>>>(batch);
     ENDO_LAUNCH_CHECK();
     batch.count = 0;
     return 0;

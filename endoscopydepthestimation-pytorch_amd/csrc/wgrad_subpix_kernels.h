@@ -206,7 +206,7 @@ inline int launch_tu_wgrad_subpix(const WgradParams& p, float* scratch, hipStrea
     blocks = (chunks_total + per - 1) / per;
     tu_wgrad_subpix_kernel<<<dim3(blocks, 2), kConvThreads, 0, stream>>>(p, scratch, per);
     ENDO_LAUNCH_CHECK();
-    tu_wgrad_subpix_reduce_kernel<<<dim3(2 * 4 * 3 * kSpMG, 8), 256, 0, stream>>>(scratch, blocks, p.cin, p.dw);
+    tu_wgrad_subpix_reduce_kernel<<<dim3(2 * 4 * 3 * kSpMG, 2), 256, 0, stream>>>(scratch, blocks, p.cin, p.dw);
     ENDO_LAUNCH_CHECK();
     return 0;
 }

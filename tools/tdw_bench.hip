@@ -65,6 +65,14 @@ int main(int argc, char** argv) {
     time_it([&] { launch_wgrad1x1_dma_old<0>(p, 0); }, dw0, "wgrad1x1_dma (round 5: dword DMAs)");
     time_it([&] { launch_wgrad1x1_dma<0>(p, 0, 2); }, dw1, "16-byte DMAs, 3 x 1 waves (144 x 48 tiles)");
     time_it([&] { launch_wgrad1x1_dma<0>(p, 0, 1); }, dw1, "16-byte DMAs, 2 x 2 waves (96 x 96 tiles)");
+    {   // what the final atomics cost: the same launch with p.dw = nullptr (the sums stay in registers: the compiler keeps the MFMAs, the atomics are predicated off)
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        WgradParams q = p; q.dw = nullptr;
+        for (int i = 0; i < 3; ++i) launch_wgrad1x1_dma<0>(q, 0);
+        float sum = 0.f;
+        for (int i = 0; i < 20; ++i) { CK(hipEventRecord(a0, 0)); launch_wgrad1x1_dma<0>(q, 0); CK(hipEventRecord(a1, 0)); CK(hipEventSynchronize(a1)); float ms; CK(hipEventElapsedTime(&ms, a0, a1)); sum += ms; }
+        printf("%-44s %8.1f us\n", "library's choice without the final atomics", 1e3 * sum / 20);
+    }
     time_it([&] { launch_wgrad1x1_dma<0>(p, 0); }, dw1, "wgrad1x1_dma (library's choice)");
     std::vector<float> h0(C * C), h1(C * C);
     CK(hipMemcpy(h0.data(), dw0, C * C * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), dw1, C * C * 4, hipMemcpyDeviceToHost));
