@@ -99,7 +99,10 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
     const int tile = (gridDim.x & 7) == 0 ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     const int x0 = (tile % p.tiles_x) * G::kTileX;
     const int y0 = (tile / p.tiles_x) * G::kTileY;
-    const int co_base = p.ksplit > 0 ? 0 : blockIdx.y * NB;
+    // PH == 2: both row phases of the transition-up forward in ONE launch, the block's phase = blockIdx.y (round 6: at the coarse levels a phase
+    // is 32 - 384 blocks, and two under-filled launches of 27 us each cost what one does)
+    const int ph = PH == 2 ? static_cast<int>(blockIdx.y) : PH;
+    const int co_base = (p.ksplit > 0 || PH == 2) ? 0 : blockIdx.y * NB;
 
     // ---------------- prologue: per-channel constants (identical to conv_mfma_kernel) ----------------
     if constexpr (IN == IN_BNRELU) {
@@ -258,7 +261,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
         if constexpr (PH >= 0) {
             // compact phase weights: [ci][kPhW] floats, the 2 x 12 (row tap, column-tap x tile) slices a row phase uses
             constexpr int kUnitsW = KC * kPhW / 4;
-            const float* wsrc = p.wgt + static_cast<int64_t>(c_base) * kPhW;
+            const float* wsrc = p.wgt + static_cast<int64_t>(c_base) * kPhW + (PH == 2 ? static_cast<int64_t>(ph) * p.cin * 400 : 0);          // (tu_phase_weights_kernel: phase 1's slices 400 floats per input channel further on)
 #pragma unroll
             for (int k = 0; k < (kUnitsW + kConvThreads - 1) / kConvThreads; ++k) {
                 const int u0 = k * kConvThreads + wave * 64;
@@ -531,8 +534,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                 }
 #pragma unroll
                 for (int dy = 0; dy < KS; ++dy) {
-                    if (PH == 0 && dy == 2) continue;          // row phase 0 sees input rows y-1, y; phase 1 rows y, y+1
-                    if (PH == 1 && dy == 0) continue;
+                    if (PH >= 0 && dy == (ph == 0 ? 2 : 0)) continue;          // row phase 0 sees input rows y-1, y; phase 1 rows y, y+1 (PH == 2: block-uniform at run time)
                     if constexpr (IN == IN_SUBPIX) {
                         if (dy == (sub_alpha == 0 ? 0 : 2)) continue;     // alpha = 0 sees rows y, y+1; alpha = 1 rows y-1, y
                     }
@@ -545,7 +547,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                             b = s_w[(quad * 4 + lk) * kSubW + (tyi * 2 + txi) * NB + q * 16 + li];
                         } else if constexpr (PH >= 0) {
                             const int slot = dx == 0 ? q : (dx == 1 ? Q / 2 + q : Q / 2 + Q + (q - Q / 2));
-                            b = s_w[(quad * 4 + lk) * kPhW + ((dy - PH) * 2 * Q + slot) * 16 + li];
+                            b = s_w[(quad * 4 + lk) * kPhW + ((dy - ph) * 2 * Q + slot) * 16 + li];
                         } else {
                             b = b_base[(dy * KS + dx) * KC * NB + q * 16];
                         }
@@ -657,7 +659,7 @@ __global__ void __launch_bounds__(kConvThreads, MINW) conv_dma_kernel(const Conv
                     f32x4 lo, hi;
                     lo[0] = acc[r][q][0] + bias; lo[1] = acc[r][q + QH][0] + bias; lo[2] = acc[r][q][1] + bias; lo[3] = acc[r][q + QH][1] + bias;
                     hi[0] = acc[r][q][2] + bias; hi[1] = acc[r][q + QH][2] + bias; hi[2] = acc[r][q][3] + bias; hi[3] = acc[r][q + QH][3] + bias;
-                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + static_cast<int64_t>(2 * y + PH) * p.out_w + 2 * px;
+                    float* dst = p.out + n * p.out_ns + static_cast<int64_t>(co) * p.out_cs + static_cast<int64_t>(2 * y + ph) * p.out_w + 2 * px;
                     *reinterpret_cast<f32x4*>(dst) = lo;
                     *reinterpret_cast<f32x4*>(dst + 4) = hi;
 #pragma unroll
@@ -693,7 +695,7 @@ inline int launch_conv_dma_vec(ConvParams p, hipStream_t stream) {
     p.tiles_x = (p.w + G::kTileX - 1) / G::kTileX;
     p.bn_cap = (IN == IN_BNRELU) ? ((p.cin + KC - 1) / KC * KC + 15) / 16 * 16 : 0;
     const int tiles_y = (p.h + G::kTileY - 1) / G::kTileY;
-    dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (PH >= 0 ? 1 : (p.cout + 16 * Q - 1) / (16 * Q)), p.n);
+    dim3 grid(p.tiles_x * tiles_y, p.ksplit > 0 ? p.ksplit : (PH >= 0 ? (PH == 2 ? 2 : 1) : (p.cout + 16 * Q - 1) / (16 * Q)), p.n);
     const size_t smem = S::bytes(p.bn_cap);
     static size_t configured_by_device[16] = {};          // the attribute belongs to the (function, device) pair
     int dev = 0;

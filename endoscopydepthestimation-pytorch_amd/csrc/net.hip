@@ -851,24 +851,21 @@ static int tu_fwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
     ProfScope prof(kProfConv3x3Up, c.stream, conv_flops(c.net, level, cv.cin, cv.cout, 3),
                    4.0 * c.nt() * c.net->lv[level].plane * (cv.cin / 4.0 + cv.cout));
     if (sv.w % 4 == 0 && cv.cout == kNew && cv.cin % 4 == 0) {
-        // sub-pixel form: two launches (row phases) on the low-resolution grid, 4/9 of the MACs.  The tap-summed weights
+        // sub-pixel form: the two row phases on the low-resolution grid, 4/9 of the MACs.  The tap-summed weights
         // go to the (idle) split-K scratch of group 0's tape; they are shared by all groups.
         float* w3 = c.tape + c.net->partial_off;
         tu_phase_weights_kernel<<<(2 * cv.cin * 384 + 255) / 256, 256, 0, c.stream>>>(c.params + cv.w, cv.cout, cv.cin, w3);
         ENDO_LAUNCH_CHECK();
-        for (int a = 0; a < 2; ++a) {
+        {   // ONE launch for both row phases (gridDim.y = 2, conv_dma_kernel<.., PH = 2>)
             ConvParams p{};
             fill_grid(c, p, src_level);                     // the launch runs over the low-resolution pixels
             fill_in(c, p, c.act(src_level), src_level, src_c0, cv.cin);
-            p.wgt = w3 + static_cast<int64_t>(a) * cv.cin * 400; p.w_cout = 2 * cv.cout; p.w_cin = cv.cin;
+            p.wgt = w3; p.w_cout = 2 * cv.cout; p.w_cin = cv.cin;
             p.bias = c.params + cv.b;
             fill_out(c, p, c.act(level), level, 0, cv.cout);
             p.out_sums = c.out_sums(level, 0);
-            int rc = a == 0 ? launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 0>(p, c.stream)
-                            : launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 1>(p, c.stream);
-            if (rc) return rc;
+            return launch_conv_dma_vec<3, 4, 6, IN_PLAIN, EPI_FWD, 2, 4, 2, 1, 4, 0, 0, 2>(p, c.stream);
         }
-        return 0;
     }
     ConvParams p{};
     fill_grid(c, p, level);
