@@ -1238,7 +1238,13 @@ static int tu_bwd(const Ctx& c, int level, int src_level, int src_c0, const Conv
         p.sub_c = cv.cout;
         p.wgt = wd; p.w_cout = cv.cin; p.w_cin = 4 * cv.cout;
         fill_out(c, p, c.gbuf(src_level), src_level, src_c0, cv.cin);
-        return launch_conv_dma_vec<3, 8, 3, IN_SUBPIX, EPI_FWD, 2, 4, 2, 1, 1>(p, c.stream);
+        // Tile shape by block count (round 6): on 32 x 8 tiles the launch of level 4 is 32 blocks and that of level 3 128 -- each walking all 24 K-chunks,
+        // 93 and 103 us for 0.1 and 0.4 GFLOP.  16 x 8 / 16 x 4 tiles where 32 x 8 ones leave the chip under-filled.
+        const long t32 = static_cast<long>((sv.w + 31) / 32) * ((sv.h + 7) / 8) * c.nt();
+        const long t16 = static_cast<long>((sv.w + 15) / 16) * ((sv.h + 7) / 8) * c.nt();
+        if (t32 >= 1024) return launch_conv_dma_vec<3, 8, 3, IN_SUBPIX, EPI_FWD, 2, 4, 2, 1, 1>(p, c.stream);
+        if (t16 >= 512) return launch_conv_dma_vec<3, 8, 3, IN_SUBPIX, EPI_FWD, 1, 2, 2, 1, 1>(p, c.stream);
+        return launch_conv_dma_vec<3, 8, 3, IN_SUBPIX, EPI_FWD, 1, 1, 2, 1, 1>(p, c.stream);
     }
     ConvParams p{};
     fill_grid(c, p, level);

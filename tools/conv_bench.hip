@@ -216,6 +216,14 @@ int main(int argc, char** argv) {
         vs.push_back({"td fwd KC8 Q3 32x4 (R 2)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 2, 2, 2, 1, 4, 0>(q, s); }});
         vs.push_back({"td fwd KC8 Q3 64x4 (WX 4)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 4, 4, 2, 1, 4, 0>(q, s); }});
         vs.push_back({"td fwd KC8 Q2 32x8", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 2, IN_BNRELU, EPI_FWD_POOL, 2, 4, 2, 1, 4, 0>(q, s); }});
+        // the coarse levels' shape (16 x 8 tiles: launch_conv_dma_auto's last branch) and its variants
+        vs.push_back({"td fwd KC8 Q3 16x8 (library at levels 2-4)", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 1, 2, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q3 16x8 MINW 2", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 1, 2, 2, 2, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC16 Q3 16x8", [&](hipStream_t s) { return launch_conv_dma_vec<1, 16, 3, IN_BNRELU, EPI_FWD_POOL, 1, 2, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC16 Q3 16x8 MINW 2", [&](hipStream_t s) { return launch_conv_dma_vec<1, 16, 3, IN_BNRELU, EPI_FWD_POOL, 1, 2, 2, 2, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC8 Q3 16x4", [&](hipStream_t s) { return launch_conv_dma_vec<1, 8, 3, IN_BNRELU, EPI_FWD_POOL, 1, 1, 2, 1, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC16 Q3 16x4 MINW 2", [&](hipStream_t s) { return launch_conv_dma_vec<1, 16, 3, IN_BNRELU, EPI_FWD_POOL, 1, 1, 2, 2, 4, 0>(q, s); }});
+        vs.push_back({"td fwd KC16 Q2 16x8 MINW 2", [&](hipStream_t s) { return launch_conv_dma_vec<1, 16, 2, IN_BNRELU, EPI_FWD_POOL, 1, 2, 2, 2, 4, 0>(q, s); }});
         bench(vs, tout, (size_t)C * pplane, 2.0 * n * plane * C * C);
     }
     return 0;
